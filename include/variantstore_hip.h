@@ -1,0 +1,167 @@
+/* variantstore_hip.h -- C ABI of the MI355X variant-query engine.
+ *
+ * The reference (Kingsford-Group/variantstore) has no plugin / FFI interface;
+ * its query path is entered from `query_main` (reference src/commands.cc:114-215)
+ * through two C++ calls on two objects built from an index directory:
+ *
+ *   Index idx(prefix);                         include/index.h:108-117
+ *   VariantGraph vg(prefix, mode);             include/variant_graph.h:366-446
+ *   get_var_in_ref(&vg,&idx,x,y,print,file)    include/query.h:736-784   (query type 6)
+ *   get_sample_var_in_ref(...,sample,...)      include/query.h:618-729   (query type 4)
+ *
+ * This header is that seam as a C ABI: plain pointers and sizes, int error
+ * codes, no exceptions, no C++ or torch types.  One vs_index per device; calls on
+ * one handle must be serialised by the caller; different handles may be used
+ * from different host threads.  Every entry point that computes runs on the GPU:
+ * there is no CPU fallback, and a handle opened without a device refuses queries
+ * with VS_ERR_NO_DEVICE.
+ */
+#ifndef VARIANTSTORE_HIP_H
+#define VARIANTSTORE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vs_index vs_index;   /* replaces the (Index, VariantGraph) pair: host copy + HBM image */
+typedef struct vs_result vs_result; /* replaces std::vector<Variant> per region (query.h:30-36), batched */
+
+enum {
+  VS_OK = 0,
+  VS_ERR_IO = -1,          /* index directory / file unreadable or malformed   */
+  VS_ERR_FORMAT = -2,      /* on-disk structure violates the layout contract   */
+  VS_ERR_NO_DEVICE = -3,   /* no usable GPU / handle opened host-only          */
+  VS_ERR_HIP = -4,         /* a HIP runtime call failed                        */
+  VS_ERR_ARG = -5,         /* bad argument                                     */
+  VS_ERR_UNKNOWN_SAMPLE = -6,
+  VS_ERR_UNSUPPORTED = -7,
+  VS_ERR_INTERNAL = -8
+};
+const char* vs_strerror(int code);
+/* message of the last failure on the calling thread (empty string if none) */
+const char* vs_last_error(void);
+
+/* ---- region ------------------------------------------------------------ */
+typedef struct { uint64_t x, y; } vs_region; /* [pos_x, pos_y), 1-based: std::get<0>/<1> of commands.cc:64-93 */
+
+/* ---- construction: `variantstore construct` (commands.cc:33-60) ---------- */
+typedef struct {
+  uint64_t num_vars, num_mutations, num_mutations_samples;  /* the "Num mutations" log line */
+  uint64_t num_vertices, num_edges, seq_length;              /* the "Graph stats" log line  */
+  uint64_t num_classes;                                       /* "Number of sample vector classes" */
+  uint32_t use_bit_vector;
+} vs_construct_stats;
+
+/* Build a graph from FASTA + VCF entirely in memory and open it on `device`
+ * (device < 0: host-only handle, for inspection/export; queries are refused). */
+int vs_index_from_vcf(const char* fasta, const char* vcf, int device, vs_construct_stats* stats, vs_index** out);
+
+/* Deterministic synthetic cohort (bench / scale tests): a random reference of
+ * `ref_length` bases, `num_variants` sites (SNP / insertion / deletion mix, some
+ * multi-allelic), `num_samples` samples with a skewed allele-frequency spectrum,
+ * fed record by record through the same constructor as a VCF would be. */
+typedef struct {
+  uint64_t ref_length;
+  uint64_t num_variants;
+  uint32_t num_samples;
+  uint64_t seed;
+  uint64_t first_pos;        /* variants are placed in [first_pos, ref_length) */
+  double frac_ins, frac_del; /* remaining fraction are SNPs                    */
+  double frac_multi;         /* fraction of SNP sites with a second ALT        */
+  uint32_t max_indel;        /* indel length 1..max_indel                      */
+  double af_exponent;        /* AF = min(0.5, 10^(-af_exponent * U))           */
+} vs_synth_params;
+int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats* stats, vs_index** out);
+
+/* Open an index directory written by `variantstore construct` (Index(prefix) +
+ * VariantGraph(prefix, mode): index.h:108-117, variant_graph.h:366-446). */
+int vs_index_open(const char* prefix, int device, vs_index** out);
+/* Write the index directory (VariantGraph::serialize + Index::serialize). */
+int vs_index_save(const vs_index* idx, const char* prefix);
+void vs_index_close(vs_index* idx);
+
+typedef struct {
+  uint64_t ref_length, num_vertices, num_edges_csr, ref_path_nodes, index_nodes;
+  uint64_t num_classes, num_sites, num_carriers, seq_length;
+  uint32_t num_samples;      /* includes "ref" */
+  uint32_t use_bit_vector;
+  uint64_t device_bytes;     /* HBM held by the image */
+  int device;
+} vs_index_info;
+int vs_index_get_info(const vs_index* idx, vs_index_info* info);
+/* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */
+int vs_index_sample_id(const vs_index* idx, const char* name, uint32_t* id);
+const char* vs_index_sample_name(const vs_index* idx, uint32_t id);
+const char* vs_index_chr(const vs_index* idx);
+/* Dump the decoded index content in the flat format the test oracle reads. */
+int vs_index_export_plain(const vs_index* idx, const char* path);
+/* Host-side inspection used by structure tests (no GPU needed):
+ * out-neighbours of v in the reference's iteration order; returns the degree. */
+int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, uint64_t cap);
+
+/* ---- queries ------------------------------------------------------------ */
+/* type 6: get_var_in_ref for each of the n regions (query.h:736-784) */
+int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out);
+/* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
+int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
+                               vs_result** out);
+/* batched Index::find (index.h:119-133): vertex id of the ref node covering each position */
+int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out);
+
+/* Result of one batch.  Arrays live in HBM until a view is requested. */
+enum { VS_REGION_EMPTY = 1,   /* Index::is_empty early-out fired (query.h:745-756 prints the other label) */
+       VS_REGION_INVALID = 2  /* pos_x < 1: the reference aborts (index.h:151-154) */ };
+enum { VS_VAR_DROPPED = 1 };  /* suppressed by the reference's "already seen" rule, query.h:397-414 */
+#define VS_CARRIER_ID(c) ((c) & 0x1FFFFFFFu)
+#define VS_CARRIER_GT(c) ((c) >> 29)         /* bit0 phase ('|'), bit1 gt_1, bit2 gt_2 */
+
+typedef struct {
+  uint64_t n_regions;
+  const uint8_t* region_flags;   /* [n_regions] */
+  const uint64_t* var_begin;     /* [n_regions+1] slot range of each region */
+  const uint64_t* var_count;     /* [n_regions]   variants the reference reports (slots minus dropped) */
+  uint64_t n_slots;
+  const uint64_t* pos;           /* [n_slots] Variant::var_pos */
+  const uint32_t* ref_off;       /* [n_slots] Variant::ref = seq_pool[ref_off, ref_off+ref_len) */
+  const uint32_t* ref_len;
+  const uint32_t* alt_off;       /* Variant::alt likewise */
+  const uint32_t* alt_len;
+  const uint32_t* var_flags;     /* VS_VAR_* */
+  const uint64_t* car_begin;     /* [n_slots] first carrier of the slot */
+  const uint32_t* car_count;     /* [n_slots] Variant::samples.size() */
+  uint64_t n_carriers;
+  const uint32_t* carriers;      /* sample id | gt << 29, s_info order; NULL when carriers were not fetched */
+  const char* seq_pool;          /* index-owned: one character per base */
+} vs_result_view;
+
+/* Copy the result to host memory (owned by the vs_result).  with_carriers = 0
+ * leaves the carrier lists in HBM (view->carriers == NULL). */
+int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view);
+/* Totals without any copy of the arrays. */
+int vs_result_totals(const vs_result* r, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers,
+                     uint64_t* n_bases);
+/* The `-o` file of region q (print_header + print_var, query.h:38-50) as text owned by the result. */
+int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len);
+/* Order-independent 64-bit digest of (region, pos, ref, alt, carriers) computed
+ * on the device -- the "checksum of checksums" used by full-size property tests. */
+int vs_result_digest(vs_result* r, uint64_t* digest);
+/* Device pointers for zero-copy consumers (e.g. a collective over the hit lists).
+ * headers: n_slots records of 4 x uint64 {pos, ref_off|ref_len<<32, alt_off|alt_len<<32, region}. */
+int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t* n_records);
+void vs_result_free(vs_result* r);
+
+/* ---- timing of the last batch on this handle (HIP events on the engine's stream) ---- */
+typedef struct {
+  float ms_total;    /* first launch to last kernel completion */
+  float ms_bounds;   /* rank / region-bounds kernel            */
+  float ms_scan;     /* offset scans + dedup                   */
+  float ms_emit;     /* variant-header kernel                  */
+  float ms_fill;     /* carrier-expansion kernel (dominant)    */
+  uint64_t fill_launches;
+} vs_timing;
+int vs_index_last_timing(const vs_index* idx, vs_timing* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

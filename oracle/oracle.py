@@ -1,0 +1,113 @@
+"""ctypes front-end of the CPU oracle (oracle/vs_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvs_oracle.so")
+REF_GQF_PATH = os.path.join(_HERE, "_ref", "libgqf_ref.so")
+
+
+def build(verbose=False):
+    out = subprocess.run(["make", "-s", "-C", _HERE], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout, end="")
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+                os.path.join(_HERE, "vs_oracle.cpp")):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        lib.vso_open.restype = C.c_void_p
+        lib.vso_open.argtypes = [C.c_char_p]
+        lib.vso_close.argtypes = [C.c_void_p]
+        lib.vso_get_var_in_ref.restype = C.c_long
+        lib.vso_get_var_in_ref.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
+        lib.vso_get_sample_var_in_ref.restype = C.c_long
+        lib.vso_get_sample_var_in_ref.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_int)]
+        lib.vso_last_text.restype = C.c_void_p
+        lib.vso_last_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.vso_ub_events.restype = C.c_uint64
+        lib.vso_ub_events.argtypes = [C.c_void_p]
+        lib.vso_find.restype = C.c_uint32
+        lib.vso_find.argtypes = [C.c_void_p, C.c_uint64]
+        lib.vso_is_empty.restype = C.c_int
+        lib.vso_is_empty.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        lib.vso_num_vertices.restype = C.c_uint64
+        lib.vso_num_vertices.argtypes = [C.c_void_p]
+        lib.vso_out_neighbors.restype = C.c_uint64
+        lib.vso_out_neighbors.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64]
+        lib.vso_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _lib = lib
+    return _lib
+
+
+class Oracle:
+    """Literal CPU restatement of the reference query path over a plain dump."""
+
+    def __init__(self, plain_path):
+        self._lib = _load()
+        self._h = self._lib.vso_open(str(plain_path).encode())
+        if not self._h:
+            raise IOError(f"cannot read plain dump {plain_path}")
+
+    def close(self):
+        if self._h:
+            self._lib.vso_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_var_in_ref(self, x, y, text=True):
+        """(n_variants, early_out, text).  n == -1: the reference walk does not terminate."""
+        e = C.c_int()
+        n = self._lib.vso_get_var_in_ref(self._h, x, y, C.byref(e))
+        return n, bool(e.value), (self.last_text() if text else None)
+
+    def get_sample_var_in_ref(self, x, y, sample, text=True):
+        e = C.c_int()
+        n = self._lib.vso_get_sample_var_in_ref(self._h, x, y, sample.encode(), C.byref(e))
+        return n, bool(e.value), (self.last_text() if text else None)
+
+    def last_text(self):
+        n = C.c_uint64()
+        p = self._lib.vso_last_text(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode("latin-1")
+
+    def last_counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._lib.vso_last_counts(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
+    def ub_events(self):
+        return int(self._lib.vso_ub_events(self._h))
+
+    def find(self, pos):
+        return int(self._lib.vso_find(self._h, pos))
+
+    def is_empty(self, x, y):
+        return bool(self._lib.vso_is_empty(self._h, x, y))
+
+    def num_vertices(self):
+        return int(self._lib.vso_num_vertices(self._h))
+
+    def out_neighbors(self, v):
+        buf = (C.c_uint32 * 4096)()
+        n = self._lib.vso_out_neighbors(self._h, v, buf, 4096)
+        return [int(buf[i]) for i in range(min(n, 4096))]

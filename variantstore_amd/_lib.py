@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI (include/variantstore_hip.h).
+
+The engine is a hipcc-built shared library; there is no Python or CPU
+implementation behind it.  Importing this module fails loudly when the library
+has not been built (`python -m variantstore_amd.build`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvariantstore_hip.so")
+
+
+class Region(C.Structure):
+    _fields_ = [("x", C.c_uint64), ("y", C.c_uint64)]
+
+
+class ConstructStats(C.Structure):
+    _fields_ = [("num_vars", C.c_uint64), ("num_mutations", C.c_uint64), ("num_mutations_samples", C.c_uint64),
+                ("num_vertices", C.c_uint64), ("num_edges", C.c_uint64), ("seq_length", C.c_uint64),
+                ("num_classes", C.c_uint64), ("use_bit_vector", C.c_uint32)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("ref_length", C.c_uint64), ("num_variants", C.c_uint64), ("num_samples", C.c_uint32),
+                ("seed", C.c_uint64), ("first_pos", C.c_uint64), ("frac_ins", C.c_double), ("frac_del", C.c_double),
+                ("frac_multi", C.c_double), ("max_indel", C.c_uint32), ("af_exponent", C.c_double)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("ref_length", C.c_uint64), ("num_vertices", C.c_uint64), ("num_edges_csr", C.c_uint64),
+                ("ref_path_nodes", C.c_uint64), ("index_nodes", C.c_uint64), ("num_classes", C.c_uint64),
+                ("num_sites", C.c_uint64), ("num_carriers", C.c_uint64), ("seq_length", C.c_uint64),
+                ("num_samples", C.c_uint32), ("use_bit_vector", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("device", C.c_int)]
+
+
+class ResultView(C.Structure):
+    _fields_ = [("n_regions", C.c_uint64), ("region_flags", C.POINTER(C.c_uint8)),
+                ("var_begin", C.POINTER(C.c_uint64)), ("var_count", C.POINTER(C.c_uint64)),
+                ("n_slots", C.c_uint64), ("pos", C.POINTER(C.c_uint64)),
+                ("ref_off", C.POINTER(C.c_uint32)), ("ref_len", C.POINTER(C.c_uint32)),
+                ("alt_off", C.POINTER(C.c_uint32)), ("alt_len", C.POINTER(C.c_uint32)),
+                ("var_flags", C.POINTER(C.c_uint32)), ("car_begin", C.POINTER(C.c_uint64)),
+                ("car_count", C.POINTER(C.c_uint32)), ("n_carriers", C.c_uint64),
+                ("carriers", C.POINTER(C.c_uint32)), ("seq_pool", C.c_void_p)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_bounds", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
+                ("ms_fill", C.c_float), ("fill_launches", C.c_uint64)]
+
+
+# every symbol include/variantstore_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "vs_strerror": (C.c_char_p, [C.c_int]),
+    "vs_last_error": (C.c_char_p, []),
+    "vs_index_from_vcf": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(ConstructStats), C.POINTER(_P)]),
+    "vs_index_synthetic": (C.c_int, [C.POINTER(SynthParams), C.c_int, C.POINTER(ConstructStats), C.POINTER(_P)]),
+    "vs_index_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "vs_index_save": (C.c_int, [_P, C.c_char_p]),
+    "vs_index_close": (None, [_P]),
+    "vs_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "vs_index_sample_id": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "vs_index_sample_name": (C.c_char_p, [_P, C.c_uint32]),
+    "vs_index_chr": (C.c_char_p, [_P]),
+    "vs_index_export_plain": (C.c_int, [_P, C.c_char_p]),
+    "vs_index_out_neighbors": (C.c_int64, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64]),
+    "vs_query_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(_P)]),
+    "vs_query_sample_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.c_uint32, C.POINTER(_P)]),
+    "vs_index_find": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),
+    "vs_result_get_view": (C.c_int, [_P, C.c_int, C.POINTER(ResultView)]),
+    "vs_result_totals": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64)]),
+    "vs_result_format_region": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),
+    "vs_result_digest": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "vs_result_pack_headers": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vs_result_free": (None, [_P]),
+    "vs_index_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the engine; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built "
+            "(run `python -m variantstore_amd.build`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's query interface, over the C ABI.
+
+The reference's driver (src/commands.cc:114-215) builds `Index idx(prefix)` and
+`VariantGraph vg(prefix, mode)` and calls `get_var_in_ref(&vg, &idx, x, y, ...)`
+(include/query.h:736) or `get_sample_var_in_ref(..., sample, ...)` (query.h:618)
+per region.  Here one `VariantStore` object plays the (vg, idx) pair and the two
+query methods take a whole batch of regions; each returns a `QueryResult` whose
+per-region content is what the reference's `std::vector<Variant>` would hold.
+All computation happens in the HIP engine.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ConstructStats, IndexInfo, Region, ResultView, SynthParams, Timing
+
+REGION_EMPTY = 1
+REGION_INVALID = 2
+VAR_DROPPED = 1
+
+
+class VariantStoreError(RuntimeError):
+    def __init__(self, code, where):
+        lib = _lib.load()
+        msg = lib.vs_last_error().decode() or lib.vs_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code})")
+        self.code = code
+
+
+def _check(code, where):
+    if code != 0:
+        raise VariantStoreError(code, where)
+
+
+@dataclass
+class Variant:  # reference include/query.h:30-36
+    var_pos: int
+    ref: str
+    alt: str
+    samples: List[Tuple[str, str]]
+
+
+def _regions_array(regions):
+    arr = np.ascontiguousarray(np.asarray(regions, dtype=np.uint64).reshape(-1, 2))
+    return arr, arr.ctypes.data_as(C.POINTER(Region)), arr.shape[0]
+
+
+class QueryResult:
+    def __init__(self, store, handle):
+        self._store = store
+        self._h = handle
+        self._lib = _lib.load()
+
+    def close(self):
+        if self._h:
+            self._lib.vs_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def totals(self):
+        """(n_regions, n_variants, n_carriers, n_bases) over the whole batch."""
+        v = [C.c_uint64() for _ in range(4)]
+        _check(self._lib.vs_result_totals(self._h, *[C.byref(x) for x in v]), "vs_result_totals")
+        return tuple(int(x.value) for x in v)
+
+    def digest(self):
+        d = C.c_uint64()
+        _check(self._lib.vs_result_digest(self._h, C.byref(d)), "vs_result_digest")
+        return int(d.value)
+
+    def view(self, with_carriers=True):
+        """Host copy of the result as numpy arrays (dict)."""
+        rv = ResultView()
+        _check(self._lib.vs_result_get_view(self._h, 1 if with_carriers else 0, C.byref(rv)), "vs_result_get_view")
+        q, a, s = int(rv.n_regions), int(rv.n_slots), int(rv.n_carriers)
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+        return {
+            "region_flags": arr(rv.region_flags, q, np.uint8),
+            "var_begin": arr(rv.var_begin, q + 1, np.uint64),
+            "var_count": arr(rv.var_count, q, np.uint64),
+            "pos": arr(rv.pos, a, np.uint64),
+            "ref_off": arr(rv.ref_off, a, np.uint32), "ref_len": arr(rv.ref_len, a, np.uint32),
+            "alt_off": arr(rv.alt_off, a, np.uint32), "alt_len": arr(rv.alt_len, a, np.uint32),
+            "var_flags": arr(rv.var_flags, a, np.uint32),
+            "car_begin": arr(rv.car_begin, a, np.uint64), "car_count": arr(rv.car_count, a, np.uint32),
+            "carriers": arr(rv.carriers, s, np.uint32) if with_carriers else None,
+        }
+
+    def region_text(self, q):
+        """The `-o` file the reference writes for region q (query.h:38-50, 774-781)."""
+        txt = C.c_char_p()
+        n = C.c_uint64()
+        _check(self._lib.vs_result_format_region(self._h, q, C.byref(txt), C.byref(n)), "vs_result_format_region")
+        return C.string_at(txt, n.value).decode("latin-1")
+
+    def region_variants(self, q) -> List[Variant]:
+        out = []
+        for line in self.region_text(q).split("\n")[1:]:
+            if not line:
+                continue
+            pos, ref, alt, samples = line.split("\t")
+            pairs = []
+            for tok in samples.split(" "):
+                if tok:
+                    name, gt = tok[:-1].rsplit("(", 1)
+                    pairs.append((name, gt))
+            out.append(Variant(int(pos), ref, alt, pairs))
+        return out
+
+
+class VariantStore:
+    """An opened index: the reference's (VariantGraph, Index) pair on one GPU."""
+
+    def __init__(self, handle, stats=None):
+        self._h = handle
+        self._lib = _lib.load()
+        self.construct_stats = stats
+
+    # ---- constructors -------------------------------------------------------
+    @classmethod
+    def from_vcf(cls, fasta, vcf, device=0):
+        lib = _lib.load()
+        h = C.c_void_p()
+        st = ConstructStats()
+        _check(lib.vs_index_from_vcf(str(fasta).encode(), str(vcf).encode(), device, C.byref(st), C.byref(h)),
+               "vs_index_from_vcf")
+        return cls(h, st)
+
+    @classmethod
+    def synthetic(cls, device=0, **kw):
+        lib = _lib.load()
+        p = SynthParams(ref_length=kw.get("ref_length", 1_000_000), num_variants=kw.get("num_variants", 10_000),
+                        num_samples=kw.get("num_samples", 100), seed=kw.get("seed", 1),
+                        first_pos=kw.get("first_pos", 1000), frac_ins=kw.get("frac_ins", 0.0),
+                        frac_del=kw.get("frac_del", 0.0), frac_multi=kw.get("frac_multi", 0.0),
+                        max_indel=kw.get("max_indel", 6), af_exponent=kw.get("af_exponent", 3.0))
+        h = C.c_void_p()
+        st = ConstructStats()
+        _check(lib.vs_index_synthetic(C.byref(p), device, C.byref(st), C.byref(h)), "vs_index_synthetic")
+        return cls(h, st)
+
+    @classmethod
+    def open(cls, prefix, device=0):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _check(lib.vs_index_open(str(prefix).encode(), device, C.byref(h)), "vs_index_open")
+        return cls(h)
+
+    def save(self, prefix):
+        _check(self._lib.vs_index_save(self._h, str(prefix).encode()), "vs_index_save")
+
+    def close(self):
+        if self._h:
+            self._lib.vs_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inspection ---------------------------------------------------------
+    def info(self) -> IndexInfo:
+        info = IndexInfo()
+        _check(self._lib.vs_index_get_info(self._h, C.byref(info)), "vs_index_get_info")
+        return info
+
+    def chr(self):
+        return self._lib.vs_index_chr(self._h).decode()
+
+    def sample_id(self, name):
+        sid = C.c_uint32()
+        _check(self._lib.vs_index_sample_id(self._h, name.encode(), C.byref(sid)), "vs_index_sample_id")
+        return int(sid.value)
+
+    def sample_name(self, sid):
+        s = self._lib.vs_index_sample_name(self._h, sid)
+        return s.decode() if s is not None else None
+
+    def export_plain(self, path):
+        _check(self._lib.vs_index_export_plain(self._h, str(path).encode()), "vs_index_export_plain")
+
+    def out_neighbors(self, v):
+        buf = (C.c_uint32 * 4096)()
+        n = self._lib.vs_index_out_neighbors(self._h, v, buf, 4096)
+        if n < 0:
+            raise IndexError(v)
+        return [int(buf[i]) for i in range(min(n, 4096))]
+
+    def last_timing(self) -> Timing:
+        t = Timing()
+        _check(self._lib.vs_index_last_timing(self._h, C.byref(t)), "vs_index_last_timing")
+        return t
+
+    # ---- queries ------------------------------------------------------------
+    def find(self, positions: Sequence[int]):
+        """Index::find for a batch of positions (index.h:119-133)."""
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.uint64))
+        out = np.zeros(pos.shape[0], dtype=np.uint32)
+        _check(self._lib.vs_index_find(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint64)), pos.shape[0],
+                                       out.ctypes.data_as(C.POINTER(C.c_uint32))), "vs_index_find")
+        return out
+
+    def get_var_in_ref(self, regions) -> QueryResult:
+        """Query type 6 over a batch of (pos_x, pos_y) regions (query.h:736-784)."""
+        arr, ptr, n = _regions_array(regions)
+        h = C.c_void_p()
+        _check(self._lib.vs_query_var_in_ref(self._h, ptr, n, C.byref(h)), "vs_query_var_in_ref")
+        return QueryResult(self, h)
+
+    def get_sample_var_in_ref(self, regions, sample) -> QueryResult:
+        """Query type 4 for one sample over a batch of regions (query.h:618-729)."""
+        sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
+        arr, ptr, n = _regions_array(regions)
+        h = C.c_void_p()
+        _check(self._lib.vs_query_sample_var_in_ref(self._h, ptr, n, sid, C.byref(h)), "vs_query_sample_var_in_ref")
+        return QueryResult(self, h)

@@ -1,0 +1,671 @@
+// engine.hip -- host side of the C ABI (include/variantstore_hip.h).
+//
+// Owns the decoded index (HostGraph), its flattened image (HostImage), the HBM
+// copy (DevImage), one HIP stream per handle and a small device-buffer pool so
+// that steady-state batches do no hipMalloc.  Mirrors the reference's seam
+// between query_main and query.h (reference src/commands.cc:114-215).
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/variantstore_hip.h"
+#include "../host/host_graph.hpp"
+#include "../host/builder.hpp"
+#include "../host/vcf.hpp"
+#include "../host/synth.hpp"
+#include "../host/device_image.hpp"
+#include "../host/index_files.hpp"
+#include "kernels.hip.h"
+
+using namespace vsamd;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(VS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define VS_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != VS_OK) return rc_; \
+  } while (0)
+
+struct DevBuf { void* p; size_t cap; };
+
+struct vs_index {
+  HostGraph g;
+  HostImage im;
+  DevImage d{};
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<void*> image_allocs;
+  uint64_t device_bytes = 0;
+  std::string seq_chars;
+  std::unordered_map<std::string, uint32_t> sample_ids;
+  std::vector<DevBuf> pool;
+  vs_timing timing{};
+  vs_construct_stats cstats{};
+  uint64_t live_results = 0;
+};
+
+struct vs_result {
+  vs_index* idx = nullptr;
+  DevResult d{};
+  std::vector<DevBuf> bufs;
+  // host copies
+  bool have_headers = false, have_carriers = false;
+  std::vector<uint8_t> h_flags;
+  std::vector<uint64_t> h_var_begin, h_var_count, h_car_base, h_pos, h_car_begin;
+  std::vector<uint32_t> h_ref_off, h_ref_len, h_alt_off, h_alt_len, h_vflags, h_car_count, h_carriers;
+  uint64_t n_variants = 0, n_carriers_kept = 0, n_bases = 0;
+  bool have_totals = false;
+  std::string text;
+  std::vector<uint32_t> slice_carriers;
+};
+
+// ------------------------------------------------------------------ helpers
+static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf>* owner) {
+  if (bytes == 0) bytes = 8;
+  bytes = (bytes + 255) & ~(size_t)255;
+  // best fit from the pool
+  int best = -1;
+  for (size_t i = 0; i < idx->pool.size(); ++i)
+    if (idx->pool[i].cap >= bytes && (best < 0 || idx->pool[i].cap < idx->pool[best].cap)) best = (int)i;
+  if (best >= 0 && idx->pool[best].cap <= 2 * bytes + (1 << 20)) {
+    DevBuf b = idx->pool[best];
+    idx->pool.erase(idx->pool.begin() + best);
+    *out = b.p;
+    if (owner) owner->push_back(b);
+    return VS_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // release the pool and retry once
+    for (auto& b : idx->pool) (void)hipFree(b.p);
+    idx->pool.clear();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(VS_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  *out = p;
+  if (owner) owner->push_back(DevBuf{p, bytes});
+  return VS_OK;
+}
+
+template <typename T>
+static int upload_image(vs_index* idx, const std::vector<T>& v, const T** dptr) {
+  size_t bytes = v.size() * sizeof(T);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
+  idx->image_allocs.push_back(p);
+  idx->device_bytes += bytes;
+  if (bytes) HIP_TRY(hipMemcpyAsync(p, v.data(), bytes, hipMemcpyHostToDevice, idx->stream));
+  *dptr = (const T*)p;
+  return VS_OK;
+}
+template <typename T>
+static int alloc_image(vs_index* idx, size_t n, T** dptr) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, n ? n * sizeof(T) : 8));
+  idx->image_allocs.push_back(p);
+  idx->device_bytes += n * sizeof(T);
+  *dptr = (T*)p;
+  return VS_OK;
+}
+
+// out[0..n) = exclusive prefix of in, out[n] = total
+template <typename T>
+static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out, std::vector<DevBuf>* scratch_owner) {
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(out, 0, 8, idx->stream));
+    return VS_OK;
+  }
+  const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
+  void* ts = nullptr;
+  VS_TRY(dev_alloc(idx, ntiles * 8, &ts, scratch_owner));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_tile_sums<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, in, n, (uint64_t*)ts);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanBlock), 0, idx->stream, (uint64_t*)ts, ntiles, out + n);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, in, n, (const uint64_t*)ts, out);
+  HIP_TRY(hipGetLastError());
+  return VS_OK;
+}
+
+static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
+  for (auto& b : bufs) idx->pool.push_back(b);
+  bufs.clear();
+  // keep the pool bounded: drop the smallest buffers beyond 64 entries
+  while (idx->pool.size() > 64) {
+    size_t k = 0;
+    for (size_t i = 1; i < idx->pool.size(); ++i)
+      if (idx->pool[i].cap < idx->pool[k].cap) k = i;
+    (void)hipFree(idx->pool[k].p);
+    idx->pool.erase(idx->pool.begin() + k);
+  }
+}
+
+// ----------------------------------------------------------- image on device
+static int build_device_image(vs_index* idx) {
+  HostImage& im = idx->im;
+  DevImage& d = idx->d;
+  HIP_TRY(hipSetDevice(idx->device));
+  HIP_TRY(hipStreamCreate(&idx->stream));
+  for (auto& e : idx->ev) HIP_TRY(hipEventCreate(&e));
+  d.ref_length = im.ref_length;
+  d.nbits = (uint64_t)im.bits.size() * 64;
+  d.num_samples = im.num_samples; d.wpc = im.wpc; d.use_bv = im.use_bit_vector;
+  d.V = im.V; d.E = im.E; d.P = im.P; d.R = im.R; d.C = im.C;
+  d.G = im.rp_cand_prefix[im.P];
+  VS_TRY(upload_image(idx, im.bits, &d.bits));
+  VS_TRY(upload_image(idx, im.blk_rank, &d.blk_rank));
+  VS_TRY(upload_image(idx, im.idx_pos, &d.idx_pos));
+  VS_TRY(upload_image(idx, im.rank_to_slot, &d.rank_to_slot));
+  VS_TRY(upload_image(idx, im.rp_vid, &d.rp_vid));
+  VS_TRY(upload_image(idx, im.rp_cand_prefix, &d.rp_cand_prefix));
+  VS_TRY(upload_image(idx, im.row_ptr, &d.row_ptr));
+  VS_TRY(upload_image(idx, im.col, &d.col));
+  VS_TRY(upload_image(idx, im.v_off, &d.v_off));
+  VS_TRY(upload_image(idx, im.v_len, &d.v_len));
+  VS_TRY(upload_image(idx, im.v_ridx, &d.v_ridx));
+  VS_TRY(upload_image(idx, im.v_class, &d.v_class));
+  VS_TRY(upload_image(idx, im.v_ncar, &d.v_ncar));
+  VS_TRY(upload_image(idx, im.v_nri, &d.v_nri));
+  VS_TRY(upload_image(idx, im.v_car_begin, &d.v_car_begin));
+  VS_TRY(upload_image(idx, im.class_rows, &d.class_rows));
+  VS_TRY(upload_image(idx, im.gt_nibbles, &d.gt_nibbles));
+  VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
+  VS_TRY(upload_image(idx, im.seq_codes, &d.seq_codes));
+  const uint64_t G = d.G;
+  VS_TRY(alloc_image(idx, G, &d.s_pos));
+  VS_TRY(alloc_image(idx, G, &d.s_ref_off));
+  VS_TRY(alloc_image(idx, G, &d.s_ref_len));
+  VS_TRY(alloc_image(idx, G, &d.s_alt_off));
+  VS_TRY(alloc_image(idx, G, &d.s_alt_len));
+  VS_TRY(alloc_image(idx, G, &d.s_vid));
+  VS_TRY(alloc_image(idx, G, &d.s_ncar));
+  VS_TRY(alloc_image(idx, G, &d.s_flags));
+  VS_TRY(alloc_image(idx, G, &d.s_dup_prev));
+  VS_TRY(alloc_image(idx, G + 1, &d.s_carpre));
+  d.sus_g = nullptr; d.sus_prev = nullptr; d.n_sus = 0;
+
+  // site table: the reference's per-node classification, once for the whole ref path
+  if (im.P) {
+    const uint64_t chunk = 1ull << 24;
+    for (uint64_t s = 0; s < im.P; s += chunk) {
+      uint64_t e = std::min<uint64_t>(im.P, s + chunk);
+      hipLaunchKernelGGL(k_build_sites, dim3((unsigned)((e - s + 255) / 256)), dim3(256), 0, idx->stream, d, s, e);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<DevBuf> scratch;
+  VS_TRY(exclusive_scan<uint32_t>(idx, d.s_ncar, G, d.s_carpre, &scratch));
+  std::vector<uint32_t> h_dup(G), h_fl(G);
+  if (G) {
+    hipLaunchKernelGGL(k_mark_dups, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_dup.data(), d.s_dup_prev, G * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(h_fl.data(), d.s_flags, G * 4, hipMemcpyDeviceToHost, idx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  release_bufs(idx, scratch);
+  std::vector<uint32_t> sus_g, sus_prev;
+  for (uint64_t g = 0; g < G; ++g) {
+    if (h_fl[g] & kSiteAlwaysDrop) { sus_g.push_back((uint32_t)g); sus_prev.push_back(kNone); }
+    else if (h_dup[g] != kNone) { sus_g.push_back((uint32_t)g); sus_prev.push_back(h_dup[g]); }
+  }
+  d.n_sus = (uint32_t)sus_g.size();
+  VS_TRY(upload_image(idx, sus_g, &d.sus_g));
+  VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  return VS_OK;
+}
+
+static int finish_open(vs_index* idx, int device) {
+  try {
+    build_host_image(idx->g, idx->im);
+  } catch (const std::exception& e) {
+    return fail(VS_ERR_FORMAT, "%s", e.what());
+  }
+  idx->seq_chars.resize(idx->g.seq.size());
+  for (size_t i = 0; i < idx->g.seq.size(); ++i) idx->seq_chars[i] = map_int(idx->g.seq[i]);
+  for (uint32_t i = 0; i < idx->g.sample_names.size(); ++i) idx->sample_ids.emplace(idx->g.sample_names[i], i);
+  idx->device = device;
+  if (device < 0) return VS_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VS_ERR_NO_DEVICE, "no HIP device is visible");
+  if (device >= ndev) return fail(VS_ERR_NO_DEVICE, "device %d requested, %d visible", device, ndev);
+  return build_device_image(idx);
+}
+
+template <typename T>
+static int ralloc(vs_result* r, size_t n, T** p) {
+  void* q = nullptr;
+  VS_TRY(dev_alloc(r->idx, n * sizeof(T), &q, &r->bufs));
+  *p = (T*)q;
+  return VS_OK;
+}
+
+static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
+  DevResult& d = r->d;
+  d.Q = n;
+  uint64_t* dreg = nullptr;
+  VS_TRY(ralloc(r, 2 * n, &dreg));
+  d.regions = dreg;
+  VS_TRY(ralloc(r, n, &d.q_flags));
+  VS_TRY(ralloc(r, n, &d.q_g0));
+  VS_TRY(ralloc(r, n, &d.q_nvar));
+  VS_TRY(ralloc(r, n, &d.q_ncar));
+  VS_TRY(ralloc(r, n + 1, &d.var_begin));
+  VS_TRY(ralloc(r, n + 1, &d.car_base));
+  VS_TRY(ralloc(r, n, &d.var_count));
+  static_assert(sizeof(vs_region) == 16, "vs_region layout");
+  if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  std::vector<DevBuf> scratch;
+  if (n) {
+    hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
+  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
+  uint64_t totals[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  d.A = totals[0];
+  d.S = totals[1];
+  VS_TRY(ralloc(r, d.A, &d.r_pos));
+  VS_TRY(ralloc(r, d.A, &d.r_ref_off));
+  VS_TRY(ralloc(r, d.A, &d.r_ref_len));
+  VS_TRY(ralloc(r, d.A, &d.r_alt_off));
+  VS_TRY(ralloc(r, d.A, &d.r_alt_len));
+  VS_TRY(ralloc(r, d.A, &d.r_flags));
+  VS_TRY(ralloc(r, d.A, &d.r_car_count));
+  VS_TRY(ralloc(r, d.A, &d.r_site));
+  VS_TRY(ralloc(r, d.A, &d.r_region));
+  VS_TRY(ralloc(r, d.A, &d.r_car_begin));
+  VS_TRY(ralloc(r, d.S, &d.carriers));
+  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  if (n) {
+    hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+    hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  if (d.A) {
+    uint64_t blocks = std::min<uint64_t>((d.A + 3) / 4, 16384);
+    hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  release_bufs(idx, scratch);
+  vs_timing& t = idx->timing;
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  t.fill_launches = d.A ? 1 : 0;
+  return VS_OK;
+}
+
+template <typename T>
+static int fetch(vs_index* idx, std::vector<T>& h, const T* dptr, size_t n) {
+  h.resize(n);
+  if (n) HIP_TRY(hipMemcpyAsync(h.data(), dptr, n * sizeof(T), hipMemcpyDeviceToHost, idx->stream));
+  return VS_OK;
+}
+
+static int fetch_headers(vs_result* r) {
+  if (r->have_headers) return VS_OK;
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  const DevResult& d = r->d;
+  VS_TRY(fetch(idx, r->h_flags, (const uint8_t*)d.q_flags, d.Q));
+  VS_TRY(fetch(idx, r->h_var_begin, (const uint64_t*)d.var_begin, d.Q + 1));
+  VS_TRY(fetch(idx, r->h_car_base, (const uint64_t*)d.car_base, d.Q + 1));
+  VS_TRY(fetch(idx, r->h_var_count, (const uint64_t*)d.var_count, d.Q));
+  VS_TRY(fetch(idx, r->h_pos, (const uint64_t*)d.r_pos, d.A));
+  VS_TRY(fetch(idx, r->h_ref_off, (const uint32_t*)d.r_ref_off, d.A));
+  VS_TRY(fetch(idx, r->h_ref_len, (const uint32_t*)d.r_ref_len, d.A));
+  VS_TRY(fetch(idx, r->h_alt_off, (const uint32_t*)d.r_alt_off, d.A));
+  VS_TRY(fetch(idx, r->h_alt_len, (const uint32_t*)d.r_alt_len, d.A));
+  VS_TRY(fetch(idx, r->h_vflags, (const uint32_t*)d.r_flags, d.A));
+  VS_TRY(fetch(idx, r->h_car_begin, (const uint64_t*)d.r_car_begin, d.A));
+  VS_TRY(fetch(idx, r->h_car_count, (const uint32_t*)d.r_car_count, d.A));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
+  r->have_headers = true;
+  return VS_OK;
+}
+
+extern "C" {
+
+const char* vs_strerror(int code) {
+  switch (code) {
+    case VS_OK: return "ok";
+    case VS_ERR_IO: return "i/o error";
+    case VS_ERR_FORMAT: return "malformed index";
+    case VS_ERR_NO_DEVICE: return "no GPU device (the query path has no CPU fallback)";
+    case VS_ERR_HIP: return "HIP runtime error";
+    case VS_ERR_ARG: return "bad argument";
+    case VS_ERR_UNKNOWN_SAMPLE: return "unknown sample";
+    case VS_ERR_UNSUPPORTED: return "unsupported";
+    case VS_ERR_INTERNAL: return "internal error";
+    default: return "unknown error code";
+  }
+}
+const char* vs_last_error(void) { return g_last_error.c_str(); }
+
+void vs_index_close(vs_index* idx) {
+  if (!idx) return;
+  if (idx->device >= 0) {
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    for (auto p : idx->image_allocs) (void)hipFree(p);
+    for (auto& b : idx->pool) (void)hipFree(b.p);
+    for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  }
+  delete idx;
+}
+
+int vs_index_from_vcf(const char* fasta, const char* vcf, int device, vs_construct_stats* stats, vs_index** out) {
+  if (!fasta || !vcf || !out) return fail(VS_ERR_ARG, "null argument");
+  vs_index* idx = new vs_index();
+  try {
+    uint64_t nk = 0, ne = 0, sl = 0;
+    ConstructStats st = construct_from_files(fasta, vcf, idx->g, &nk, &ne, &sl);
+    idx->cstats = vs_construct_stats{st.num_vars, st.num_mutations, st.num_mutations_samples, nk, ne, sl,
+                                     idx->g.num_classes, (uint32_t)st.use_bit_vector};
+  } catch (const std::exception& e) {
+    delete idx;
+    return fail(VS_ERR_IO, "%s", e.what());
+  }
+  if (stats) *stats = idx->cstats;
+  int rc = finish_open(idx, device);
+  if (rc != VS_OK) { vs_index_close(idx); return rc; }
+  *out = idx;
+  return VS_OK;
+}
+
+int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats* stats, vs_index** out) {
+  if (!p || !out) return fail(VS_ERR_ARG, "null argument");
+  vs_index* idx = new vs_index();
+  try {
+    SynthParams sp;
+    sp.ref_length = p->ref_length; sp.num_variants = p->num_variants; sp.num_samples = p->num_samples;
+    sp.seed = p->seed; sp.first_pos = p->first_pos; sp.frac_ins = p->frac_ins; sp.frac_del = p->frac_del;
+    sp.frac_multi = p->frac_multi; sp.max_indel = p->max_indel ? p->max_indel : 1; sp.af_exponent = p->af_exponent;
+    uint64_t nk = 0, ne = 0, sl = 0;
+    SynthStats st = construct_synthetic(sp, idx->g, &nk, &ne, &sl);
+    idx->cstats = vs_construct_stats{st.num_vars, st.num_mutations, st.num_mutations_samples, nk, ne, sl,
+                                     idx->g.num_classes, (uint32_t)st.use_bit_vector};
+  } catch (const std::exception& e) {
+    delete idx;
+    return fail(VS_ERR_INTERNAL, "%s", e.what());
+  }
+  if (stats) *stats = idx->cstats;
+  int rc = finish_open(idx, device);
+  if (rc != VS_OK) { vs_index_close(idx); return rc; }
+  *out = idx;
+  return VS_OK;
+}
+
+int vs_index_open(const char* prefix, int device, vs_index** out) {
+  if (!prefix || !out) return fail(VS_ERR_ARG, "null argument");
+  vs_index* idx = new vs_index();
+  try {
+    load_index_dir(prefix, idx->g);
+  } catch (const std::exception& e) {
+    delete idx;
+    return fail(VS_ERR_IO, "%s", e.what());
+  }
+  int rc = finish_open(idx, device);
+  if (rc != VS_OK) { vs_index_close(idx); return rc; }
+  *out = idx;
+  return VS_OK;
+}
+
+int vs_index_save(const vs_index* idx, const char* prefix) {
+  if (!idx || !prefix) return fail(VS_ERR_ARG, "null argument");
+  try {
+    save_index_dir(idx->g, prefix);
+  } catch (const std::exception& e) {
+    return fail(VS_ERR_IO, "%s", e.what());
+  }
+  return VS_OK;
+}
+
+int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
+  if (!idx || !info) return fail(VS_ERR_ARG, "null argument");
+  info->ref_length = idx->g.ref_length;
+  info->num_vertices = idx->im.V;
+  info->num_edges_csr = idx->im.E;
+  info->ref_path_nodes = idx->im.P;
+  info->index_nodes = idx->im.R;
+  info->num_classes = idx->im.C;
+  info->num_sites = idx->im.rp_cand_prefix.empty() ? 0 : idx->im.rp_cand_prefix[idx->im.P];
+  info->num_carriers = idx->g.car_flags.size();
+  info->seq_length = idx->g.seq.size();
+  info->num_samples = idx->g.num_samples;
+  info->use_bit_vector = idx->g.use_bit_vector;
+  info->device_bytes = idx->device_bytes;
+  info->device = idx->device;
+  return VS_OK;
+}
+
+int vs_index_sample_id(const vs_index* idx, const char* name, uint32_t* id) {
+  if (!idx || !name || !id) return fail(VS_ERR_ARG, "null argument");
+  auto it = idx->sample_ids.find(name);
+  if (it == idx->sample_ids.end()) return fail(VS_ERR_UNKNOWN_SAMPLE, "Sample not found: %s", name);
+  *id = it->second;
+  return VS_OK;
+}
+const char* vs_index_sample_name(const vs_index* idx, uint32_t id) {
+  if (!idx || id >= idx->g.sample_names.size()) return nullptr;
+  return idx->g.sample_names[id].c_str();
+}
+const char* vs_index_chr(const vs_index* idx) { return idx ? idx->g.chr.c_str() : nullptr; }
+
+int vs_index_export_plain(const vs_index* idx, const char* path) {
+  if (!idx || !path) return fail(VS_ERR_ARG, "null argument");
+  try {
+    idx->g.write_plain(path);
+  } catch (const std::exception& e) {
+    return fail(VS_ERR_IO, "%s", e.what());
+  }
+  return VS_OK;
+}
+
+int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, uint64_t cap) {
+  if (!idx || v >= idx->im.V) return -1;
+  uint32_t b = idx->im.row_ptr[v], e = idx->im.row_ptr[v + 1];
+  for (uint32_t i = b; i < e && (uint64_t)(i - b) < cap; ++i) out[i - b] = idx->im.col[i];
+  return (int64_t)(e - b);
+}
+
+int vs_index_last_timing(const vs_index* idx, vs_timing* t) {
+  if (!idx || !t) return fail(VS_ERR_ARG, "null argument");
+  *t = idx->timing;
+  return VS_OK;
+}
+
+// --------------------------------------------------------------------- queries
+void vs_result_free(vs_result* r) {
+  if (!r) return;
+  if (r->idx) {
+    (void)hipSetDevice(r->idx->device);
+    release_bufs(r->idx, r->bufs);
+    r->idx->live_results--;
+  }
+  delete r;
+}
+
+int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out) {
+  if (!idx || !out || (n && !regions)) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  int rc = run_var_in_ref(idx, regions, n, r);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id, vs_result** out) {
+  (void)idx; (void)regions; (void)n; (void)sample_id; (void)out;
+  return fail(VS_ERR_UNSUPPORTED, "query type 4 is not built yet");
+}
+
+int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out) {
+  if (!idx || (n && (!pos || !vertex_out))) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
+  HIP_TRY(hipSetDevice(idx->device));
+  if (n == 0) return VS_OK;
+  std::vector<DevBuf> bufs;
+  void *dp = nullptr, *dout = nullptr;
+  VS_TRY(dev_alloc(idx, n * 8, &dp, &bufs));
+  VS_TRY(dev_alloc(idx, n * 4, &dout, &bufs));
+  HIP_TRY(hipMemcpyAsync(dp, pos, n * 8, hipMemcpyHostToDevice, idx->stream));
+  hipLaunchKernelGGL(k_find, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, (const uint64_t*)dp, n, (uint32_t*)dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(vertex_out, dout, n * 4, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  release_bufs(idx, bufs);
+  return VS_OK;
+}
+
+// ---------------------------------------------------------------- result access
+int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
+  if (!r || !view) return fail(VS_ERR_ARG, "null argument");
+  VS_TRY(fetch_headers(r));
+  if (with_carriers && !r->have_carriers) {
+    VS_TRY(fetch(r->idx, r->h_carriers, (const uint32_t*)r->d.carriers, r->d.S));
+    HIP_TRY(hipStreamSynchronize(r->idx->stream));
+    r->have_carriers = true;
+  }
+  view->n_regions = r->d.Q;
+  view->region_flags = r->h_flags.data();
+  view->var_begin = r->h_var_begin.data();
+  view->var_count = r->h_var_count.data();
+  view->n_slots = r->d.A;
+  view->pos = r->h_pos.data();
+  view->ref_off = r->h_ref_off.data(); view->ref_len = r->h_ref_len.data();
+  view->alt_off = r->h_alt_off.data(); view->alt_len = r->h_alt_len.data();
+  view->var_flags = r->h_vflags.data();
+  view->car_begin = r->h_car_begin.data();
+  view->car_count = r->h_car_count.data();
+  view->n_carriers = r->d.S;
+  view->carriers = (with_carriers || r->have_carriers) ? r->h_carriers.data() : nullptr;
+  view->seq_pool = r->idx->seq_chars.data();
+  return VS_OK;
+}
+
+int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers, uint64_t* n_bases) {
+  vs_result* r = const_cast<vs_result*>(cr);
+  if (!r) return fail(VS_ERR_ARG, "null argument");
+  VS_TRY(fetch_headers(r));
+  if (!r->have_totals) {
+    uint64_t nv = 0, nc = 0, nb = 0;
+    for (uint64_t a = 0; a < r->d.A; ++a) {
+      if (r->h_vflags[a] & kVarDropped) continue;
+      nv++; nc += r->h_car_count[a]; nb += r->h_ref_len[a] + r->h_alt_len[a];
+    }
+    r->n_variants = nv; r->n_carriers_kept = nc; r->n_bases = nb; r->have_totals = true;
+  }
+  if (n_regions) *n_regions = r->d.Q;
+  if (n_variants) *n_variants = r->n_variants;
+  if (n_carriers) *n_carriers = r->n_carriers_kept;
+  if (n_bases) *n_bases = r->n_bases;
+  return VS_OK;
+}
+
+int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len) {
+  if (!r || !text) return fail(VS_ERR_ARG, "null argument");
+  VS_TRY(fetch_headers(r));
+  if (q >= r->d.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
+  vs_index* idx = r->idx;
+  const uint64_t a0 = r->h_var_begin[q], a1 = r->h_var_begin[q + 1];
+  const uint64_t c0 = r->h_car_base[q], c1 = r->h_car_base[q + 1];
+  const uint32_t* car = nullptr;
+  if (r->have_carriers) car = r->h_carriers.data() + c0;
+  else {
+    r->slice_carriers.resize(c1 - c0);
+    if (c1 > c0) {
+      HIP_TRY(hipMemcpyAsync(r->slice_carriers.data(), r->d.carriers + c0, (c1 - c0) * 4, hipMemcpyDeviceToHost, idx->stream));
+      HIP_TRY(hipStreamSynchronize(idx->stream));
+    }
+    car = r->slice_carriers.data();
+  }
+  std::string& out = r->text;
+  out.clear();
+  out += "Pos\tRef\tAlt\tSamples\n";  // print_header, query.h:38-41
+  for (uint64_t a = a0; a < a1; ++a) {
+    if (r->h_vflags[a] & kVarDropped) continue;
+    out += std::to_string(r->h_pos[a]);  // print_var, query.h:43-50
+    out += '\t';
+    out.append(idx->seq_chars, r->h_ref_off[a], r->h_ref_len[a]);
+    out += '\t';
+    out.append(idx->seq_chars, r->h_alt_off[a], r->h_alt_len[a]);
+    out += '\t';
+    const uint32_t* c = car + (r->h_car_begin[a] - c0);
+    for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
+      const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
+      out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
+      out += '(';
+      out += (gt & GT_1) ? '1' : '0';   // get_sample_phasing, variant_graph.h:882-900
+      out += (gt & GT_PHASE) ? '|' : '/';
+      out += (gt & GT_2) ? '1' : '0';
+      out += ") ";
+    }
+    out += '\n';
+  }
+  *text = out.c_str();
+  if (len) *len = out.size();
+  return VS_OK;
+}
+
+int vs_result_digest(vs_result* r, uint64_t* digest) {
+  if (!r || !digest) return fail(VS_ERR_ARG, "null argument");
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  std::vector<DevBuf> bufs;
+  void* dd = nullptr;
+  VS_TRY(dev_alloc(idx, 8, &dd, &bufs));
+  HIP_TRY(hipMemsetAsync(dd, 0, 8, idx->stream));
+  if (r->d.A) {
+    uint64_t blocks = std::min<uint64_t>((r->d.A + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, r->d, (uint64_t*)dd);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(digest, dd, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  release_bufs(idx, bufs);
+  return VS_OK;
+}
+
+int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t* n_records) {
+  (void)r; (void)device_dst; (void)capacity_records; (void)n_records;
+  return fail(VS_ERR_UNSUPPORTED, "header packing is not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// kernels.hip.h -- gfx950 device code of the region-query path.
+//
+// All integer / index work: the roofline that bounds these kernels is HBM
+// bandwidth (and memory latency for the gather phases), never MFMA.
+// Wavefront width is 64 throughout; one workgroup = 256 threads = 4 waves.
+//
+// Kernel                replaces (reference file:line)
+// --------------------  ------------------------------------------------------
+// k_build_sites         next_variant_in_ref's per-node branch classification
+//                       (include/query.h:308-393) + the radius-1 neighbour walk
+//                       (include/graph.h:394-431), run ONCE over the whole ref
+//                       path when an index is opened (the "site table")
+// k_mark_dups           the candidates the "already seen" rule can ever hit
+//                       (include/query.h:397-414)
+// k_region_bounds       Index::is_empty / Index::find (include/index.h:119-166)
+//                       + the stop rule ref_index+length >= end (query.h:312)
+// k_emit_headers        building std::vector<Variant> (query.h:736-771)
+// k_dedup_slow          the literal "already seen" rule for the rare regions
+//                       that contain a repeated (pos, alt)
+// k_fill_carriers       get_samples -> get_sample_id / get_sample_phasing
+//                       (query.h:268-285, variant_graph.h:875-942): expansion of
+//                       a class bit row + genotype bits into carrier lists.
+//                       This is the dominant kernel.
+// k_find                Index::find batched
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsamd {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kSiteAlwaysDrop = 2;  // branch the reference would emit with an uninitialised var_pos
+constexpr uint32_t kVarDropped = 1;
+constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionSlow = 128;
+
+struct DevImage {
+  uint64_t ref_length, nbits;
+  uint32_t num_samples, wpc, use_bv, pad_;
+  uint64_t V, E, P, R, C, G;
+  const uint64_t* bits;
+  const uint32_t* blk_rank;
+  const uint32_t* idx_pos;
+  const uint32_t* rank_to_slot;
+  const uint32_t* rp_vid;
+  const uint32_t* rp_cand_prefix;
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const uint32_t *v_off, *v_len, *v_ridx, *v_class, *v_ncar, *v_nri;
+  const uint64_t* v_car_begin;
+  const uint64_t* class_rows;
+  const uint8_t* gt_nibbles;
+  const uint32_t* car_sid;
+  const uint8_t* seq_codes;
+  // site table (one entry per branch of a ref-path node, ref-path order)
+  uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev;
+  uint64_t* s_carpre;  // [G+1] exclusive prefix of s_ncar
+  const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
+  const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
+  uint32_t n_sus, pad2_;
+};
+
+struct DevResult {
+  uint64_t Q, A, S;
+  const uint64_t* regions;  // [2Q] x,y
+  uint8_t* q_flags;         // [Q]
+  uint32_t* q_g0;           // [Q] first site of the region
+  uint64_t* q_nvar;         // [Q] slots
+  uint64_t* q_ncar;         // [Q] carriers (upper bound when a variant gets dropped)
+  uint64_t* var_begin;      // [Q+1]
+  uint64_t* car_base;       // [Q+1]
+  uint64_t* var_count;      // [Q]
+  uint64_t* r_pos;
+  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_site, *r_region;
+  uint64_t* r_car_begin;
+  uint32_t* carriers;
+};
+
+// ones in bit positions [0, p): number of ref-node start indexes <= p
+__device__ __forceinline__ uint32_t rank1(const DevImage& im, uint64_t p) {
+  if (p > im.nbits) p = im.nbits;
+  const uint64_t blk = p >> 9;
+  uint32_t r = im.blk_rank[blk];
+  const uint64_t w1 = p >> 6;
+  for (uint64_t w = blk << 3; w < w1; ++w) r += __popcll(im.bits[w]);
+  const uint32_t rem = (uint32_t)(p & 63);
+  if (rem) r += __popcll(im.bits[w1] & ((1ULL << rem) - 1));
+  return r;
+}
+
+__device__ __forceinline__ bool seq_equal(const DevImage& im, uint32_t a_off, uint32_t b_off, uint32_t len) {
+  for (uint32_t i = 0; i < len; ++i)
+    if (im.seq_codes[a_off + i] != im.seq_codes[b_off + i]) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Site table: one thread per ref-path slot.  Output position of a slot's j-th
+// branch is rp_cand_prefix[slot] + j, so no inter-lane communication is needed.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_build_sites(DevImage im, uint64_t slot_begin, uint64_t slot_end) {
+  const uint64_t i = slot_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slot_end) return;
+  const uint32_t it = im.rp_vid[i], succ = im.rp_vid[i + 1];
+  uint32_t g = im.rp_cand_prefix[i];
+  const uint32_t it_ridx = im.v_ridx[it], it_len = im.v_len[it];
+  const uint32_t e1 = im.row_ptr[it + 1];
+  for (uint32_t e = im.row_ptr[it]; e < e1; ++e) {
+    const uint32_t b = im.col[e];
+    if (b == succ) continue;
+    const uint32_t ncar = im.v_ncar[b];
+    uint32_t pos = 0, ro = 0, rl = 0, ao = 0, al = 0, fl = 0;
+    const uint32_t succ_ridx = im.v_ridx[succ];
+    if (ncar == 0) {
+      fl = kSiteAlwaysDrop;  // get_samples() false: var_pos never written in the reference
+    } else if (im.v_ridx[b] != 0) {  // deletion, query.h:336-350
+      if (succ_ridx == 0) fl = kSiteAlwaysDrop;
+      pos = succ_ridx; ro = im.v_off[succ]; rl = im.v_len[succ];
+    } else {
+      uint32_t nri = im.v_nri[b];
+      if (nri == kNone) nri = it_ridx;  // "consecutive mutation": sample keeps *it's ref entry
+      if (nri == it_ridx + it_len) {    // insertion, query.h:369-376
+        pos = nri - 1; ao = im.v_off[b]; al = im.v_len[b];
+      } else {                          // substitution, query.h:377-392
+        if (succ_ridx == 0) fl = kSiteAlwaysDrop;
+        pos = succ_ridx; ro = im.v_off[succ]; rl = im.v_len[succ];
+        ao = im.v_off[b]; al = im.v_len[b];
+      }
+    }
+    im.s_pos[g] = pos; im.s_ref_off[g] = ro; im.s_ref_len[g] = rl; im.s_alt_off[g] = ao; im.s_alt_len[g] = al;
+    im.s_vid[g] = b; im.s_ncar[g] = (fl & kSiteAlwaysDrop) ? 0u : ncar; im.s_flags[g] = fl;
+    ++g;
+  }
+}
+
+// nearest earlier site with the same (pos, alt); positions are sorted up to an
+// off-by-one (an insertion reports end-1, everything else end), so the backward
+// scan stops at the first site whose pos < p-1.
+__global__ void __launch_bounds__(256) k_mark_dups(DevImage im) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= im.G) return;
+  uint32_t res = kNone;
+  if (!(im.s_flags[g] & kSiteAlwaysDrop)) {
+    const uint32_t p = im.s_pos[g], ao = im.s_alt_off[g], al = im.s_alt_len[g];
+    for (uint64_t k = 0; k < g && k < 65536; ++k) {
+      const uint64_t i = g - 1 - k;
+      if (im.s_flags[i] & kSiteAlwaysDrop) continue;
+      const uint32_t pi = im.s_pos[i];
+      if (pi + 1 < p) break;
+      if (pi == p && im.s_alt_len[i] == al && seq_equal(im, im.s_alt_off[i], ao, al)) { res = (uint32_t)i; break; }
+    }
+  }
+  im.s_dup_prev[g] = res;
+}
+
+// ---------------------------------------------------------------------------
+// Region bounds: one thread per region.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  uint8_t fl = 0;
+  uint32_t g0 = 0, g1 = 0;
+  if (x < 1) {
+    fl = kRegionInvalid;
+  } else {
+    // Index::is_empty, index.h:150-166
+    bool empty = false;
+    if (x > im.ref_length) empty = true;
+    else {
+      const uint32_t rx = rank1(im, x);           // >= 1 because a node starts at index 1
+      if (rx >= im.R) empty = true;               // select past the last one: defined as empty
+      else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
+    }
+    if (empty) fl = kRegionEmpty;
+    else if (x < y) {
+      // Index::find(x), index.h:119-133
+      const uint64_t rf = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;
+      const uint32_t s0 = im.rank_to_slot[rf];
+      // first slot whose node ends at or after y stops the walk (query.h:312);
+      // node ends tile the reference, so that is the slot before the first start >= y
+      const uint32_t ry = rank1(im, y - 1);
+      uint32_t s1 = im.rank_to_slot[ry] - 1;      // rank_to_slot[R] == P
+      if (s1 < s0) s1 = s0;
+      g0 = im.rp_cand_prefix[s0];
+      g1 = im.rp_cand_prefix[s1];
+      // can the "already seen" rule fire inside [g0,g1)?
+      uint32_t lo = 0, hi = im.n_sus;
+      while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (im.sus_g[m] < g0) lo = m + 1; else hi = m; }
+      for (uint32_t k = lo; k < im.n_sus && im.sus_g[k] < g1; ++k) {
+        const uint32_t pv = im.sus_prev[k];
+        if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
+      }
+    }
+  }
+  r.q_flags[q] = fl;
+  r.q_g0[q] = g0;
+  r.q_nvar[q] = g1 - g0;
+  r.q_ncar[q] = im.s_carpre[g1] - im.s_carpre[g0];
+}
+
+// ---------------------------------------------------------------------------
+// Exclusive scan of a uint64 array (three launches; sizes here are <= a few 1e7).
+// ---------------------------------------------------------------------------
+constexpr int kScanBlock = 256, kScanItems = 8, kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t* total) {
+  __shared__ uint64_t wsum[kScanBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint64_t incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  uint64_t woff = 0, tot = 0;
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    if (w < wid) woff += wsum[w];
+    tot += wsum[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return woff + incl - v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kScanBlock) k_scan_tile_sums(const T* in, uint64_t n, uint64_t* tile_sums) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t s = 0;
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) s += in[base + i];
+  uint64_t tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: tile_sums -> exclusive prefix in place; writes the grand total to out[n]
+__global__ void __launch_bounds__(kScanBlock) k_scan_spine(uint64_t* tile_sums, uint64_t ntiles, uint64_t* grand_total) {
+  uint64_t carry = 0;
+  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const uint64_t v = i < ntiles ? tile_sums[i] : 0;
+    uint64_t tot;
+    const uint64_t ex = block_exclusive_scan(v, &tot);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *grand_total = carry;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kScanBlock) k_scan_apply(const T* in, uint64_t n, const uint64_t* tile_sums, uint64_t* out) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t loc[kScanItems];
+  uint64_t s = 0;
+  for (int i = 0; i < kScanItems; ++i) {
+    loc[i] = base + i < n ? (uint64_t)in[base + i] : 0;
+    s += loc[i];
+  }
+  uint64_t tot;
+  uint64_t ex = block_exclusive_scan(s, &tot) + tile_sums[blockIdx.x];
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += loc[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Variant headers: one wave per region, lanes stride the region's site range.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
+  const uint32_t g0 = r.q_g0[q];
+  const uint64_t pre0 = im.s_carpre[g0];
+  for (uint64_t j = lane; j < n; j += 64) {
+    const uint64_t a = a0 + j;
+    const uint32_t g = g0 + (uint32_t)j;
+    const uint32_t fl = im.s_flags[g];
+    r.r_pos[a] = im.s_pos[g];
+    r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
+    r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
+    r.r_flags[a] = (fl & kSiteAlwaysDrop) ? kVarDropped : 0u;
+    r.r_car_begin[a] = cb + (im.s_carpre[g] - pre0);
+    r.r_car_count[a] = im.s_ncar[g];
+    r.r_site[a] = g;
+    r.r_region[a] = (uint32_t)q;
+  }
+  if (lane == 0 && !(r.q_flags[q] & kRegionSlow)) r.var_count[q] = n;
+}
+
+// The reference's "only add var if not seen before" rule (query.h:397-414),
+// literally, for the regions flagged by k_region_bounds.  One thread per region.
+__global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
+  const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
+  uint64_t kept = 0, back = 0;
+  for (uint64_t j = 0; j < n; ++j) {
+    const uint64_t a = a0 + j;
+    if (r.r_flags[a] & kVarDropped) { r.r_car_count[a] = 0; continue; }
+    const uint64_t p = r.r_pos[a];
+    const uint32_t ao = r.r_alt_off[a], al = r.r_alt_len[a];
+    bool push = true;
+    if (kept >= 1) {
+      const bool same_back = r.r_pos[back] == p && r.r_alt_len[back] == al && seq_equal(im, r.r_alt_off[back], ao, al);
+      if (same_back) push = false;
+      else if (kept > 1 && r.r_pos[back] == p) {
+        for (uint64_t i = back + 1; i-- > a0;) {
+          if (r.r_flags[i] & kVarDropped) continue;
+          if (r.r_pos[i] < p) break;
+          if (r.r_pos[i] == p && r.r_alt_len[i] == al && seq_equal(im, r.r_alt_off[i], ao, al)) { push = false; break; }
+        }
+      }
+    }
+    if (push) { kept++; back = a; }
+    else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
+  }
+  r.var_count[q] = kept;
+}
+
+// ---------------------------------------------------------------------------
+// Carrier expansion: one wave per variant slot (grid-stride).
+// Bit-vector mode: lane w owns word w of the class row; an in-wave prefix sum
+// of the popcounts gives every word its output offset; each lane then peels its
+// set bits.  Explicit mode: a coalesced copy of the stored ids.
+// Output word = sample id | genotype bits << 29.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t a = wave; a < r.A; a += nwaves) {
+    const uint32_t cnt = r.r_car_count[a];
+    if (cnt == 0) continue;
+    const uint32_t b = im.s_vid[r.r_site[a]];
+    uint32_t* out = r.carriers + r.r_car_begin[a];
+    const uint64_t gt0 = im.v_car_begin[b];
+    if (im.use_bv) {
+      const uint64_t* row = im.class_rows + (uint64_t)im.v_class[b] * im.wpc;
+      uint32_t base = 0;
+      for (uint32_t wb = 0; wb < im.wpc; wb += 64) {
+        const uint32_t w = wb + lane;
+        uint64_t word = w < im.wpc ? row[w] : 0ULL;
+        if (w == 0) word &= ~1ULL;  // bit 0 is "ref", never a carrier (query.h:278)
+        const uint32_t pc = __popcll(word);
+        uint32_t incl = pc;
+        for (int d = 1; d < 64; d <<= 1) {
+          uint32_t t = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += t;
+        }
+        uint32_t k = base + incl - pc;
+        while (word) {
+          const uint32_t bit = __builtin_ctzll(word);
+          word &= word - 1;
+          if (k < cnt) {
+            const uint64_t c = gt0 + k;
+            const uint32_t nib = (im.gt_nibbles[c >> 1] >> ((c & 1) * 4)) & 7u;
+            out[k] = (w * 64 + bit) | (nib << 29);
+          }
+          ++k;
+        }
+        base += __shfl(incl, 63, 64);
+      }
+    } else {
+      for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint64_t c = gt0 + k;
+        const uint32_t nib = (im.gt_nibbles[c >> 1] >> ((c & 1) * 4)) & 7u;
+        out[k] = im.car_sid[c] | (nib << 29);
+      }
+    }
+  }
+}
+
+// Index::find batched (index.h:119-133)
+__global__ void __launch_bounds__(256) k_find(DevImage im, const uint64_t* pos, uint64_t n, uint32_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t p = pos[i];
+  if (p < 1) { out[i] = kNone; return; }
+  uint64_t rf = (p >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, p);
+  if (p < im.ref_length) rf = rf == 0 ? 0 : rf - 1;
+  out[i] = im.rp_vid[im.rank_to_slot[rf]];
+}
+
+// ---------------------------------------------------------------------------
+// Order-independent digest of a result: sum over kept variants of a 64-bit mix
+// of (region, pos, ref bases, alt bases, every carrier word with its rank).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_digest(DevImage im, DevResult r, uint64_t* digest) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t acc = 0;
+  for (uint64_t a = wave; a < r.A; a += nwaves) {
+    if (r.r_flags[a] & kVarDropped) continue;
+    uint64_t h = 0;
+    const uint32_t cnt = r.r_car_count[a];
+    const uint32_t* car = r.carriers + r.r_car_begin[a];
+    for (uint32_t k = lane; k < cnt; k += 64) h += mix64(((uint64_t)car[k] << 32) | k);
+    if (lane == 0) {
+      uint64_t s = mix64(r.r_region[a] * 0x9E3779B97F4A7C15ULL + r.r_pos[a]);
+      for (uint32_t i = 0; i < r.r_ref_len[a]; ++i) s = mix64(s ^ (im.seq_codes[r.r_ref_off[a] + i] + 1));
+      s = mix64(s ^ 0xABCDEFULL);
+      for (uint32_t i = 0; i < r.r_alt_len[a]; ++i) s = mix64(s ^ (im.seq_codes[r.r_alt_off[a] + i] + 1));
+      h += s;
+    }
+    for (int d = 32; d >= 1; d >>= 1) h += __shfl_down(h, d, 64);
+    // per-variant hash is then mixed once more so carriers are tied to their variant
+    if (lane == 0) acc += mix64(h);
+  }
+  if (lane == 0 && acc) atomicAdd((unsigned long long*)digest, (unsigned long long)acc);
+}
+
+}  // namespace vsamd

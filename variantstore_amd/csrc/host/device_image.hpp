@@ -1,0 +1,232 @@
+// device_image.hpp -- HostGraph -> structure-of-arrays image that is copied to HBM.
+//
+// The reference answers a region query by pointer chasing:
+// Index::find (rank on an RRR vector, include/index.h:119-133) -> walk the ref
+// path with VariantGraphPathIterator (include/variant_graph.h:1999-2049) -> per
+// node a radius-1 BFS over CQF neighbour sets (include/graph.h:265-280,394-431)
+// -> per branch get_neighbor_vertex / get_sample_from_vertex_if_exists
+// (variant_graph.h:1296-1451).  Everything those calls look up is static once an
+// index is loaded, so it is flattened here, once, into arrays whose order is the
+// order the reference visits things in:
+//
+//   rank structure   plain bit-vector of ref-node starts + per-512-bit counts
+//                    (replaces rrr_vector<127> rank/select)
+//   ref path         every node on the "ref" path in path order, zero-length
+//                    dummy nodes included (a superset of Index::node_list)
+//   CSR adjacency    out-neighbours of every vertex in the reference's hash-set
+//                    iteration order (RefOrderSet), replaces CQF + aux lists
+//   vertex table     offset / length / ref index / class / #carriers / nri
+//   class rows       one word-aligned bit row per sample class (class 0 = {ref})
+//   genotype pool    4 bits per carrier (phase, gt_1, gt_2), s_info order
+//
+// Host-only code, no GPU calls.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "host_graph.hpp"
+
+namespace vsamd {
+
+constexpr uint32_t VS_NONE = 0xFFFFFFFFu;
+
+struct HostImage {
+  // scalars
+  uint64_t ref_length = 0;
+  uint32_t num_samples = 0, wpc = 0;
+  uint32_t use_bit_vector = 0;
+  uint64_t V = 0, E = 0, P = 0, R = 0, C = 0;
+
+  // rank structure over start indexes: bit (idx-1) set <=> a ref node starts at 1-based idx
+  std::vector<uint64_t> bits;        // ceil(ref_length/64)+1 words
+  std::vector<uint32_t> blk_rank;    // ones before each 512-bit block, [nblk+1]
+  std::vector<uint32_t> idx_pos;     // [R] ascending start indexes (select)
+  std::vector<uint32_t> rank_to_slot;  // [R+1] first ref-path slot with the r-th start; [R] = P
+
+  // ref path, slot order
+  std::vector<uint32_t> rp_vid;      // [P+1]; [P] = 0 (the path iterator wraps to vertex 0)
+  std::vector<uint32_t> rp_cand_prefix;  // [P+1] branches (out-neighbours != ref successor) before slot
+
+  // CSR
+  std::vector<uint32_t> row_ptr;     // [V+1]
+  std::vector<uint32_t> col;         // [E]
+
+  // vertex table
+  std::vector<uint32_t> v_off, v_len, v_ridx, v_class, v_ncar, v_nri;
+  std::vector<uint64_t> v_car_begin;  // carrier-pool index of the first non-ref s_info entry
+
+  // classes / genotypes / explicit ids / sequence
+  std::vector<uint64_t> class_rows;  // (C+1) rows of wpc words; row 0 = {bit 0}
+  std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
+  std::vector<uint32_t> car_sid;     // explicit mode only
+  std::vector<uint8_t> seq_codes;    // DNA_MAP codes, one per base
+};
+
+// first non-ref carrier id of vertex b (sample_ids[0] in query.h:356-357), VS_NONE if none
+inline uint32_t first_carrier(const HostGraph& g, uint32_t b) {
+  if (g.car_begin[b + 1] == g.car_begin[b]) return VS_NONE;
+  if (!g.use_bit_vector) return g.car_sid[g.car_begin[b]];
+  uint32_t cls = g.class_id[b];
+  if (cls == 0) return VS_NONE;
+  const uint64_t* row = &g.class_bits[(uint64_t)(cls - 1) * g.words_per_class()];
+  for (uint32_t w = 0; w < g.words_per_class(); ++w) {
+    uint64_t x = row[w];
+    if (w == 0) x &= ~1ULL;
+    if (x) return w * 64 + __builtin_ctzll(x);
+  }
+  return VS_NONE;
+}
+
+inline bool vertex_has_sample(const HostGraph& g, uint32_t v, uint32_t sid) {
+  if (sid == 0) return g.ref_index[v] != 0;
+  if (g.use_bit_vector) return g.class_id[v] != 0 && g.class_has(g.class_id[v], sid);
+  for (uint64_t c = g.car_begin[v]; c < g.car_begin[v + 1]; ++c)
+    if (g.car_sid[c] == sid) return true;
+  return false;
+}
+
+inline void build_host_image(const HostGraph& g, HostImage& im) {
+  const uint64_t V = g.num_vertices();
+  im.ref_length = g.ref_length;
+  im.num_samples = g.num_samples;
+  im.wpc = g.words_per_class();
+  im.use_bit_vector = g.use_bit_vector;
+  im.V = V;
+  im.C = g.num_classes;
+
+  // ---- CSR in query-time neighbour order (graph.h:149-172, 265-280) ----
+  im.row_ptr.assign(V + 1, 0);
+  std::vector<std::vector<uint32_t>> aux_order(g.aux_lists.size());
+  for (size_t i = 0; i < g.aux_lists.size(); ++i) {
+    RefOrderSet s;
+    for (uint32_t n : g.aux_lists[i]) s.insert(n);
+    aux_order[i] = s.order();
+  }
+  for (uint64_t v = 0; v < V; ++v) {
+    uint32_t deg = 0;
+    if (g.topo_val[v] != 0) deg = g.topo_inplace[v] ? 1 : (uint32_t)aux_order[g.topo_val[v] - 1].size();
+    im.row_ptr[v + 1] = im.row_ptr[v] + deg;
+  }
+  im.E = im.row_ptr[V];
+  im.col.resize(im.E);
+  for (uint64_t v = 0; v < V; ++v) {
+    if (g.topo_val[v] == 0) continue;
+    uint32_t* dst = &im.col[im.row_ptr[v]];
+    if (g.topo_inplace[v]) dst[0] = g.topo_val[v];
+    else {
+      const auto& l = aux_order[g.topo_val[v] - 1];
+      for (size_t i = 0; i < l.size(); ++i) dst[i] = l[i];
+    }
+  }
+  for (uint64_t e = 0; e < im.E; ++e)
+    if (im.col[e] >= V) throw std::runtime_error("adjacency refers to a vertex that does not exist");
+
+  // ---- vertex table ----
+  im.v_off = g.off; im.v_len = g.len; im.v_ridx = g.ref_index; im.v_class = g.class_id;
+  im.v_ncar.resize(V); im.v_car_begin.resize(V);
+  for (uint64_t v = 0; v < V; ++v) {
+    im.v_ncar[v] = g.num_carriers((uint32_t)v);
+    im.v_car_begin[v] = g.car_begin[v];
+  }
+
+  // ---- ref path: vertex 0, then get_neighbor_vertex(., ref) (variant_graph.h:1402-1451, 2025-2032) ----
+  auto ref_successor = [&](uint32_t v) -> uint32_t {
+    uint32_t best = 0, min_idx = UINT32_MAX;
+    for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) {
+      uint32_t n = im.col[e];
+      if (g.ref_index[n] != 0 && min_idx > g.ref_index[n]) { best = n; min_idx = g.ref_index[n]; }
+    }
+    return best;  // 0 == none (no edge ever points at vertex 0, graph.h:214-215)
+  };
+  im.rp_vid.clear();
+  {
+    std::vector<uint8_t> on_path(V, 0);
+    uint32_t cur = 0;
+    while (true) {
+      if (on_path[cur]) throw std::runtime_error("ref path revisits a vertex");
+      on_path[cur] = 1;
+      im.rp_vid.push_back(cur);
+      uint32_t nxt = ref_successor(cur);
+      if (nxt == 0) break;
+      cur = nxt;
+    }
+  }
+  im.P = im.rp_vid.size();
+  im.rp_vid.push_back(0);  // sentinel: *next_it of the last node is vertex 0
+  // the range form relies on contiguous coverage: ridx[i+1] == ridx[i] + len[i]
+  for (uint64_t i = 0; i + 1 < im.P; ++i) {
+    uint32_t a = im.rp_vid[i], b = im.rp_vid[i + 1];
+    if (g.ref_index[a] == 0 || (uint64_t)g.ref_index[a] + g.len[a] != g.ref_index[b])
+      throw std::runtime_error("ref path is not a contiguous tiling of the reference");
+  }
+  im.rp_cand_prefix.assign(im.P + 1, 0);
+  for (uint64_t i = 0; i < im.P; ++i) {
+    uint32_t v = im.rp_vid[i], succ = im.rp_vid[i + 1], c = 0;
+    for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) c += im.col[e] != succ;
+    im.rp_cand_prefix[i + 1] = im.rp_cand_prefix[i] + c;
+  }
+
+  // ---- rank structure + rank -> first slot ----
+  im.R = g.idx_pos.size();
+  im.idx_pos = g.idx_pos;
+  const uint64_t nwords = (g.ref_length + 63) / 64 + 1;
+  im.bits.assign((nwords + 7) / 8 * 8, 0);
+  for (uint32_t p : g.idx_pos) {
+    if (p < 1 || p > g.ref_length + 1) throw std::runtime_error("index position out of range");
+    im.bits[(p - 1) >> 6] |= 1ULL << ((p - 1) & 63);
+  }
+  const uint64_t nblk = im.bits.size() / 8;
+  im.blk_rank.assign(nblk + 1, 0);
+  for (uint64_t b = 0; b < nblk; ++b) {
+    uint32_t c = 0;
+    for (int w = 0; w < 8; ++w) c += __builtin_popcountll(im.bits[b * 8 + w]);
+    im.blk_rank[b + 1] = im.blk_rank[b] + c;
+  }
+  {
+    // slot of each node_list entry: the FIRST path node at that start index (index.h:86-90)
+    std::vector<uint32_t> slot_of(V, VS_NONE);
+    for (uint64_t i = 0; i < im.P; ++i) slot_of[im.rp_vid[i]] = (uint32_t)i;
+    im.rank_to_slot.assign(im.R + 1, (uint32_t)im.P);
+    for (uint64_t r = 0; r < im.R; ++r) {
+      uint32_t v = g.node_list[r];
+      if (v >= V || slot_of[v] == VS_NONE) throw std::runtime_error("node_list entry is not on the ref path");
+      if (g.ref_index[v] != g.idx_pos[r]) throw std::runtime_error("node_list entry does not start at its index bit");
+      im.rank_to_slot[r] = slot_of[v];
+      if (slot_of[v] > 0 && g.ref_index[im.rp_vid[slot_of[v] - 1]] == g.idx_pos[r])
+        throw std::runtime_error("node_list entry is not the first path node at its index");
+    }
+  }
+
+  // ---- nri: ref index reached by one path step from a branch along its first carrier
+  //      (query.h:353-365).  VS_NONE = "consecutive mutation": the reference then
+  //      keeps the ref entry of the node the branch hangs off. ----
+  im.v_nri.assign(V, 0);
+  for (uint64_t b = 0; b < V; ++b) {
+    if (g.ref_index[b] != 0) continue;  // only alt vertices are classified through nri
+    uint32_t fc = first_carrier(g, (uint32_t)b);
+    if (fc == VS_NONE) continue;
+    uint32_t d = 0, min_idx = UINT32_MAX;
+    bool hit = false;
+    for (uint32_t e = im.row_ptr[b]; e < im.row_ptr[b + 1] && !hit; ++e) {
+      uint32_t n = im.col[e];
+      if (g.ref_index[n] != 0 && min_idx > g.ref_index[n]) { d = n; min_idx = g.ref_index[n]; }
+      if (vertex_has_sample(g, n, fc)) { d = n; hit = true; }
+    }
+    // d == 0: iterator done, it now points at vertex 0 whose ref index is 1
+    im.v_nri[b] = g.ref_index[d] != 0 ? g.ref_index[d] : VS_NONE;
+  }
+
+  // ---- class rows, genotype nibbles, explicit ids, sequence ----
+  im.class_rows.assign((im.C + 1) * (uint64_t)im.wpc, 0);
+  if (im.wpc) im.class_rows[0] = 1;  // class 0: only "ref"
+  if (g.use_bit_vector && !g.class_bits.empty())
+    std::copy(g.class_bits.begin(), g.class_bits.end(), im.class_rows.begin() + im.wpc);
+  im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 8, 0);
+  for (uint64_t c = 0; c < g.car_flags.size(); ++c)
+    im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
+  im.car_sid = g.car_sid;
+  im.seq_codes = g.seq;
+}
+
+}  // namespace vsamd
