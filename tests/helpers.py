@@ -1,0 +1,96 @@
+"""Test helpers: random FASTA/VCF cohorts and oracle comparison."""
+import os
+
+import numpy as np
+
+BASES = "ACGT"
+
+
+def write_random_cohort(dirpath, seed, ref_len=4000, n_rows=120, n_samples=6, sample_names=None,
+                        p_ins=0.12, p_del=0.12, p_multi=0.08, p_mnp=0.05, p_near=0.3, carrier_p=0.3,
+                        unphased_p=0.1, missing_p=0.03, haploid_p=0.0, chrom="c1"):
+    """The "mix" recipe of SURVEY.md §4.5: SNPs, 1-4 bp insertions/deletions, two-ALT rows, MNPs, with a
+    share of sites 1-3 bp from their predecessor.  Returns (fasta, vcf, names)."""
+    rng = np.random.default_rng(seed)
+    ref = "".join(BASES[i] for i in rng.integers(0, 4, size=ref_len))
+    if sample_names is None:
+        sample_names = [f"S{i + 1:03d}" for i in range(n_samples)]
+    n_samples = len(sample_names)
+    pos_list = []
+    p = int(rng.integers(2, 20))
+    while len(pos_list) < n_rows and p < ref_len - 12:
+        pos_list.append(p)
+        if rng.random() < p_near:
+            p += int(rng.integers(1, 4))
+        else:
+            p += int(rng.integers(4, max(5, 2 * (ref_len // max(n_rows, 1)))))
+    fasta = os.path.join(dirpath, f"r{seed}.fa")
+    vcf = os.path.join(dirpath, f"r{seed}.vcf")
+    with open(fasta, "w") as f:
+        f.write(f">{chrom} random\n")
+        for i in range(0, ref_len, 60):
+            f.write(ref[i:i + 60] + "\n")
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(sample_names) + "\n")
+        for p in pos_list:
+            t = rng.random()
+            r0 = ref[p - 1]
+            if t < p_ins:
+                k = int(rng.integers(1, 5))
+                refa, alts = r0, [r0 + "".join(BASES[i] for i in rng.integers(0, 4, size=k))]
+            elif t < p_ins + p_del:
+                k = int(rng.integers(1, 5))
+                refa, alts = ref[p - 1:p + k], [r0]
+            elif t < p_ins + p_del + p_mnp:
+                refa = ref[p - 1:p + 1]
+                alts = ["".join(BASES[(BASES.index(c) + 1 + int(rng.integers(0, 3))) % 4] for c in refa)]
+            else:
+                refa = r0
+                others = [b for b in BASES if b != r0]
+                rng.shuffle(others)
+                alts = [others[0]]
+                if rng.random() < p_multi:
+                    alts.append(others[1])
+            gts = []
+            any_car = False
+            for s in range(n_samples):
+                if rng.random() < missing_p:
+                    gts.append("./.")
+                    continue
+                if haploid_p and rng.random() < haploid_p:
+                    a = 1 if rng.random() < carrier_p else 0
+                    gts.append(str(a))
+                    any_car |= a > 0
+                    continue
+                a1 = int(rng.integers(1, len(alts) + 1)) if rng.random() < carrier_p else 0
+                a2 = int(rng.integers(1, len(alts) + 1)) if rng.random() < carrier_p else 0
+                sep = "/" if rng.random() < unphased_p else "|"
+                gts.append(f"{a1}{sep}{a2}")
+                any_car |= (a1 > 0 or a2 > 0)
+            if not any_car:
+                gts[int(rng.integers(0, n_samples))] = "1|0"
+            f.write(f"{chrom}\t{p}\t.\t{refa}\t{','.join(alts)}\t99\t.\t.\tGT\t" + "\t".join(gts) + "\n")
+    return fasta, vcf, sample_names
+
+
+def random_regions(rng, ref_len, n, max_len=600):
+    """Random regions plus the edge shapes the reference's driver can be handed."""
+    out = []
+    for _ in range(n):
+        x = int(rng.integers(1, ref_len + 1))
+        out.append((x, x + int(rng.integers(0, max_len))))
+    out += [(1, ref_len + 1), (1, ref_len), (1, ref_len + 100), (ref_len, ref_len + 5), (ref_len + 1, ref_len + 9),
+            (ref_len + 50, ref_len + 60), (5, 5), (9, 3), (1, 2), (2, 3)]
+    return out
+
+
+def oracle_texts(orc, regions, sample=None):
+    """[(n, early_out, text)] from the CPU oracle; n == -1 marks a non-terminating reference walk."""
+    out = []
+    for x, y in regions:
+        if sample is None:
+            out.append(orc.get_var_in_ref(x, y))
+        else:
+            out.append(orc.get_sample_var_in_ref(x, y, sample))
+    return out

@@ -1,0 +1,72 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol,
+the neighbour-order model matches the toolchain's std::unordered_set, host-only
+handles refuse to compute, and the product's CSR order equals the oracle's."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import write_random_cohort
+from oracle.oracle import Oracle
+from variantstore_amd import VariantStore, VariantStoreError, _lib
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "variantstore_hip.h")).read()
+    declared = set(re.findall(r"\b(vs_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/variantstore_hip.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_ref_order_set_matches_libstdcxx(tmp_path):
+    exe = os.path.join(tmp_path, "ros_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "ref_order_set_check.cpp")])
+    for seed in (1, 2, 3):
+        out = subprocess.run([exe, str(seed), "6000"], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip() == "OK", out.stdout + out.stderr
+
+
+def test_host_only_handle_refuses_queries(golden_dir):
+    vs = VariantStore.from_vcf(os.path.join(golden_dir, "x.small.fa"), os.path.join(golden_dir, "x.small.vcf"),
+                               device=-1)
+    with pytest.raises(VariantStoreError) as e:
+        vs.get_var_in_ref([(1, 80)])
+    assert e.value.code == -3  # VS_ERR_NO_DEVICE: there is no CPU fallback
+    with pytest.raises(VariantStoreError):
+        vs.find([1, 2, 3])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_csr_order_equals_real_unordered_set(seed, tmp_path):
+    names = ["S2", "S10", "S1", "b", "a", "Z"] if seed == 12 else None
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), seed, ref_len=3000, n_rows=200, n_samples=6,
+                                        sample_names=names, p_multi=0.3)
+    vs = VariantStore.from_vcf(fasta, vcf, device=-1)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    assert orc.num_vertices() == vs.info().num_vertices
+    for v in range(orc.num_vertices()):
+        assert vs.out_neighbors(v) == orc.out_neighbors(v), v
+
+
+def test_synthetic_is_deterministic_and_matches_its_vcf(tmp_path):
+    """vs_index_synthetic feeds the same constructor a VCF would: identical structure both ways."""
+    kw = dict(ref_length=30000, num_variants=600, num_samples=12, seed=5, first_pos=50, frac_ins=0.1, frac_del=0.1,
+              frac_multi=0.1, max_indel=3, af_exponent=1.5)
+    a = VariantStore.synthetic(device=-1, **kw)
+    b = VariantStore.synthetic(device=-1, **kw)
+    ia, ib = a.info(), b.info()
+    assert (ia.num_vertices, ia.num_sites, ia.num_carriers, ia.num_classes) == (
+        ib.num_vertices, ib.num_sites, ib.num_carriers, ib.num_classes)
+    pa, pb = os.path.join(tmp_path, "a.bin"), os.path.join(tmp_path, "b.bin")
+    a.export_plain(pa)
+    b.export_plain(pb)
+    assert open(pa, "rb").read() == open(pb, "rb").read()

@@ -1,0 +1,148 @@
+"""GPU parity (the parity tests proper): the HIP path, called through the C ABI,
+against the golden vectors and against the CPU oracle on the same seeded inputs.
+Bar: bit-exact text of every region (positions, REF/ALT strings, sample sets with
+phasing), plus the early-out flag."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_texts, random_regions, write_random_cohort
+from oracle.oracle import Oracle
+from variantstore_amd import VariantStore
+
+pytestmark = pytest.mark.gpu
+
+
+def _open_gpu(fasta, vcf, tmp_path):
+    vs = VariantStore.from_vcf(fasta, vcf, device=0)
+    plain = os.path.join(tmp_path, "plain.bin")
+    vs.export_plain(plain)
+    return vs, Oracle(plain)
+
+
+def _compare_t6(vs, orc, regions):
+    res = vs.get_var_in_ref(regions)
+    view = res.view(with_carriers=False)
+    want = oracle_texts(orc, regions)
+    checked = 0
+    for q, (n, early, text) in enumerate(want):
+        if n < 0:
+            continue  # the reference does not terminate on this region; nothing to be identical to
+        assert res.region_text(q) == text, (q, regions[q])
+        assert int(view["var_count"][q]) == n
+        assert bool(view["region_flags"][q] & 1) == early, (q, regions[q])
+        checked += 1
+    assert checked > 0
+    res.close()
+    return checked
+
+
+@pytest.mark.parametrize("key", ["G1", "G3", "G4"])
+def test_golden_vectors_on_gpu(key, golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors[key]
+    vs, _ = _open_gpu(os.path.join(golden_dir, g["fasta"]), os.path.join(golden_dir, g["vcf"]), tmp_path)
+    res = vs.get_var_in_ref([tuple(g["region"])])
+    assert res.region_text(0) == g["text"]
+
+
+def test_golden_g2_and_probes_on_gpu(golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors["G2"]
+    vs, _ = _open_gpu(os.path.join(golden_dir, g["fasta"]), os.path.join(golden_dir, g["vcf"]), tmp_path)
+    res = vs.get_var_in_ref([tuple(g["region"]), (10, 105)])
+    lines = res.region_text(0).split("\n")[1:-1]
+    assert len(lines) == g["count"] and lines[-1] == g["last_row"]
+    for frag in g["contains"]:
+        assert any(l.startswith(frag) for l in lines)
+    assert res.totals()[1] == g["count"] + survey_vectors["readme"]["x"]["t6_10_105"]
+    p = survey_vectors["G4_probes"]
+    vs, _ = _open_gpu(os.path.join(golden_dir, p["fasta"]), os.path.join(golden_dir, p["vcf"]), tmp_path)
+    regions = [tuple(x["region"]) for x in p["probes"]]
+    res = vs.get_var_in_ref(regions)
+    flags = res.view(False)["region_flags"]
+    for q, x in enumerate(p["probes"]):
+        assert res.region_text(q) == x["text"]
+        assert bool(flags[q] & 1) == x["early_out"]
+
+
+def test_index_find_batched(golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors["x_small_graph"]
+    vs, orc = _open_gpu(os.path.join(golden_dir, g["fasta"]), os.path.join(golden_dir, g["vcf"]), tmp_path)
+    pos = list(range(1, 120))
+    got = vs.find(pos)
+    assert [int(v) for v in got] == [orc.find(p) for p in pos]
+    for p, v in g["find"].items():
+        assert int(vs.find([int(p)])[0]) == v
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (101, dict()),                                                             # SNP/indel/MNP/two-ALT mix
+    (102, dict(sample_names=["S2", "S10", "S1", "b", "a", "Z", "m"])),          # name order != column order
+    (103, dict(p_near=0.7, p_multi=0.3, n_rows=300, ref_len=3000)),             # crowded sites, many dummies
+    (104, dict(p_ins=0.3, p_del=0.3, n_rows=250)),                              # indel heavy, overlapping deletions
+    (105, dict(n_samples=70, carrier_p=0.4)),                                   # class rows wider than one word
+    (106, dict(n_samples=130, carrier_p=0.02, n_rows=200)),                     # sparse -> explicit sample ids
+    (107, dict(unphased_p=0.5, missing_p=0.2, haploid_p=0.2)),                  # '/', './.', haploid GT
+    (108, dict(n_samples=1, carrier_p=1.0)),                                    # single sample
+])
+def test_random_cohorts_match_oracle(seed, kw, tmp_path):
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(seed)
+    ref_len = vs.info().ref_length
+    regions = random_regions(rng, ref_len, 400)
+    _compare_t6(vs, orc, regions)
+    if seed == 106:
+        assert vs.info().use_bit_vector == 0
+    # regions handed over unsorted and duplicated must not matter
+    perm = rng.permutation(len(regions))
+    _compare_t6(vs, orc, [regions[i] for i in perm][:120] + regions[:5])
+
+
+def test_invalid_and_empty_batches(tmp_path):
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 7)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    res = vs.get_var_in_ref([])
+    assert res.totals() == (0, 0, 0, 0)
+    res = vs.get_var_in_ref([(0, 50), (1, 50)])
+    v = res.view(False)
+    assert v["region_flags"][0] & 2 and int(v["var_count"][0]) == 0   # pos_x < 1: the reference aborts
+    assert res.region_text(1) == orc.get_var_in_ref(1, 50)[2]
+
+
+def test_synthetic_midsize_all_regions(tmp_path):
+    """20k variants x 200 samples: every region of a 2000-region batch, text-exact."""
+    vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6,
+                                af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(5)
+    starts = rng.integers(1, 1_990_000, size=2000)
+    regions = [(int(s), int(s) + 5000) for s in starts]
+    n = _compare_t6(vs, orc, regions)
+    assert n == 2000 and orc.ub_events() == 0
+
+
+def test_digest_properties(tmp_path):
+    """Size-independent properties used at full scale: the device digest is a function of the result
+    only (same batch twice, and any permutation of the batch re-indexed, give the same per-region
+    digests), and totals are additive over a split of the batch."""
+    vs = VariantStore.synthetic(device=0, ref_length=1_000_000, num_variants=30_000, num_samples=300, seed=9,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.01, af_exponent=3.0)
+    rng = np.random.default_rng(1)
+    starts = rng.integers(1, 990_000, size=5000)
+    regions = [(int(s), int(s) + 4000) for s in starts]
+    a = vs.get_var_in_ref(regions)
+    b = vs.get_var_in_ref(regions)
+    assert a.digest() == b.digest()
+    assert a.totals() == b.totals()
+    half = len(regions) // 2
+    t1 = vs.get_var_in_ref(regions[:half]).totals()
+    t2 = vs.get_var_in_ref(regions[half:]).totals()
+    assert tuple(x + y for x, y in zip(t1, t2)) == a.totals()
+    # a single-region batch holds the same variants as that region inside the big batch
+    for q in (0, 17, 4999):
+        single = vs.get_var_in_ref([regions[q]])
+        assert single.region_text(0) == a.region_text(q)

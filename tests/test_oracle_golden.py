@@ -1,0 +1,78 @@
+"""The CPU oracle (and the constructor feeding it) against the golden vectors:
+the reference README's published outputs and the reference outputs recorded in
+SURVEY.md §4.3/§4.4/§7.3.  No GPU needed: handles are opened host-only."""
+import os
+
+import pytest
+
+from oracle.oracle import Oracle
+from variantstore_amd import VariantStore
+
+
+def _open(golden_dir, fasta, vcf, tmp_path):
+    vs = VariantStore.from_vcf(os.path.join(golden_dir, fasta), os.path.join(golden_dir, vcf), device=-1)
+    plain = os.path.join(tmp_path, f"{fasta}.{vcf}.plain")
+    vs.export_plain(plain)
+    return vs, Oracle(plain)
+
+
+def test_readme_construct_stats(golden_dir, survey_vectors, tmp_path):
+    vs, orc = _open(golden_dir, "x.fa", "x.vcf", tmp_path)
+    want = survey_vectors["readme"]["x"]
+    st = vs.construct_stats
+    assert (st.num_mutations, st.num_mutations_samples) == (want["num_mutations"], want["num_mutations_samples"])
+    assert (st.num_vertices, st.num_edges, st.seq_length) == (want["vertices"], want["edges"], want["seq_length"])
+    assert st.num_classes == want["classes"]
+    n, early, _ = orc.get_var_in_ref(10, 105)
+    assert n == want["t6_10_105"] and not early
+    assert orc.ub_events() == 0
+
+
+@pytest.mark.parametrize("key", ["G1", "G3", "G4", "G1_t4", "G3_t4"])
+def test_golden_texts(key, golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors[key]
+    vs, orc = _open(golden_dir, g["fasta"], g["vcf"], tmp_path)
+    x, y = g["region"]
+    if g["type"] == 6:
+        n, early, text = orc.get_var_in_ref(x, y)
+    else:
+        n, early, text = orc.get_sample_var_in_ref(x, y, g["sample"])
+    assert text == g["text"]
+    assert n == g["text"].count("\n") - 1
+    if "stats" in g:
+        st = vs.construct_stats
+        assert (st.num_vertices, st.num_edges, st.seq_length, st.num_classes) == (
+            g["stats"]["vertices"], g["stats"]["edges"], g["stats"]["seq_length"], g["stats"]["classes"])
+    assert orc.ub_events() == 0
+
+
+def test_golden_g2(golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors["G2"]
+    _, orc = _open(golden_dir, g["fasta"], g["vcf"], tmp_path)
+    n, early, text = orc.get_var_in_ref(*g["region"])
+    assert n == g["count"]
+    lines = text.split("\n")[1:-1]
+    for frag in g["contains"]:
+        assert any(l.startswith(frag) for l in lines), frag
+    assert lines[-1] == g["last_row"]
+
+
+def test_golden_region_start_probes(golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors["G4_probes"]
+    _, orc = _open(golden_dir, g["fasta"], g["vcf"], tmp_path)
+    for p in g["probes"]:
+        n, early, text = orc.get_var_in_ref(*p["region"])
+        assert (text, early) == (p["text"], p["early_out"]), p["region"]
+
+
+def test_x_small_graph_dump(golden_dir, survey_vectors, tmp_path):
+    """Constructor output == the reference's graph for x.small, including the
+    query-time neighbour order, which the oracle derives with the real std::unordered_set."""
+    g = survey_vectors["x_small_graph"]
+    vs, orc = _open(golden_dir, g["fasta"], g["vcf"], tmp_path)
+    assert vs.info().num_vertices == len(g["vertices"])
+    for v, (off, length, cls, ridx, out) in g["vertices"].items():
+        assert orc.out_neighbors(int(v)) == out, v
+        assert vs.out_neighbors(int(v)) == out, v
+    for pos, v in g["find"].items():
+        assert orc.find(int(pos)) == v
