@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- region-queries/sec of the type-6 hot path on MI355X.
+
+One "step" = one pass of the hot path (vs_query_var_in_ref) over one batch of
+synthetic regions on a resident index; with N > 1 every rank owns its own shard
+of the batch (weak scaling: the per-GPU batch is fixed) and the step ends with
+the RCCL all-gatherv of the hit lists the north star asks for.
+
+Workloads (BASELINE.json `configs`):
+  chr1-2504   [default]  249,250,621 bp, 5,000,000 sites (90% SNP / 5% ins / 5% del, 1% two-ALT),
+                         2504 samples, AF = min(0.5, 10^-11U)  (~135 carriers per variant),
+                         100,000 random 10 kb regions per GPU      (configs[2]; the metric's config)
+  chr22-100              51,304,566 bp, 100,000 SNPs in [16,050,000, L), 100 samples, AF = min(.5, 10^-3U),
+                         10,000 random 1 kb regions                (configs[1])
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline`
+for the dominant kernel (k_fill_carriers) and `cpu_baseline` (the CPU oracle timed
+on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "chr1-2504": dict(ref_length=249_250_621, num_variants=5_000_000, num_samples=2504, seed=1, first_pos=10_000,
+                      frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6, af_exponent=11.0,
+                      regions=100_000, region_len=10_000, region_seed=2),
+    "chr22-100": dict(ref_length=51_304_566, num_variants=100_000, num_samples=100, seed=22, first_pos=16_050_000,
+                      frac_ins=0.0, frac_del=0.0, frac_multi=0.0, max_indel=1, af_exponent=3.0,
+                      regions=10_000, region_len=1_000, region_seed=1),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def make_regions(w, rank, n):
+    import numpy as np
+    rng = np.random.default_rng(w["region_seed"] * 1000 + rank)
+    lo = max(1, w["first_pos"] - w["region_len"])
+    starts = rng.integers(lo, w["ref_length"] - w["region_len"], size=n, dtype=np.int64)
+    starts.sort()  # the reference's read_regions sorts (src/commands.cc:91)
+    return np.stack([starts, starts + w["region_len"]], axis=1).astype(np.uint64)
+
+
+def synth_kwargs(w):
+    return {k: w[k] for k in ("ref_length", "num_variants", "num_samples", "seed", "first_pos", "frac_ins",
+                              "frac_del", "frac_multi", "max_indel", "af_exponent")}
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The CPU oracle (literal restatement of the reference path, 1 thread) on a bounded sample of the same
+    workload: same generator, same cohort size, same variant density and region length, on a 1/25-length
+    slice of the chromosome so that building + loading it stays within the bench's time budget."""
+    import tempfile
+    from oracle.oracle import Oracle
+    from variantstore_amd import VariantStore
+    scale = 25 if w["num_variants"] >= 1_000_000 else 1
+    kw = synth_kwargs(w)
+    kw["ref_length"] = max(200_000, w["ref_length"] // scale)
+    kw["num_variants"] = max(1000, w["num_variants"] // scale)
+    kw["first_pos"] = min(w["first_pos"], kw["ref_length"] // 10) if scale > 1 else w["first_pos"]
+    vs = VariantStore.synthetic(device=-1, **kw)
+    sub = dict(w, **kw)
+    regions = make_regions(sub, 12345, 4000)
+    with tempfile.TemporaryDirectory() as td:
+        plain = os.path.join(td, "slice.plain")
+        vs.export_plain(plain)
+        vs.close()
+        orc = Oracle(plain)
+    done = nvar = 0
+    t0 = time.perf_counter()
+    for x, y in regions:
+        n, _, _ = orc.get_var_in_ref(int(x), int(y), text=False)
+        nvar += max(n, 0)
+        done += 1
+        if done >= 20 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{done} regions x {w['region_len']} bp ({nvar / max(done, 1):.0f} variants/region) on a "
+                      f"1/{scale}-length slice of the same synthetic cohort ({kw['num_variants']} sites, "
+                      f"{w['num_samples']} samples), CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("VS_BENCH_WORKLOAD", "chr1-2504"), choices=sorted(WORKLOADS))
+    ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-samples", type=int, default=200)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the query path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL on one GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from variantstore_amd import VariantStore
+    from variantstore_amd.parallel import allgather_hit_lists
+
+    w = WORKLOADS[args.workload]
+    nreg = args.regions or w["regions"]
+    t_build = time.perf_counter()
+    vs = VariantStore.synthetic(device=local_rank, **synth_kwargs(w))
+    t_build = time.perf_counter() - t_build
+    info = vs.info()
+    regions = make_regions(w, rank, nreg)
+    region_base = rank * nreg
+
+    def step():
+        res = vs.get_var_in_ref(regions)
+        gathered = None
+        if use_dist:
+            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank))
+        return res, gathered
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res, _ = step()
+        res.close()
+    fence()
+    fill_ms = tot_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, _ = step()
+        t = vs.last_timing()
+        fill_ms += t.ms_fill
+        tot_ms += t.ms_total
+        if _ != args.steps - 1:
+            res.close()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    # ---- result-derived figures of one batch (last step's result is still alive) ----
+    nq, nvar, ncar, nbases = res.totals()
+    digest = res.digest()
+    W = ((info.num_samples + 63) // 64) * 8
+    # dominant kernel k_fill_carriers, bytes one launch must move with this layout:
+    #   per variant: header words it reads (car_count 4, site 4, car_begin 8, branch vertex 4, class 4,
+    #   genotype base 8) + its class row (W bytes); per carrier: half a byte of genotype in, 4 bytes out
+    fill_bytes = nvar * (32 + W) + (ncar + 1) // 2 + 4 * ncar
+    # the same kernel priced by SURVEY.md §8(d)'s encoding (3-bit genotypes in, 4+1 bytes out per carrier)
+    fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
+    fill_s = fill_ms / args.steps / 1e3
+    achieved = fill_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
+    res.close()
+
+    # ---- p50 single-region latency (submit -> result resident), outside the timed region ----
+    lat = []
+    for i in range(args.latency_samples):
+        one = regions[(i * 7919) % nreg: (i * 7919) % nreg + 1]
+        a = time.perf_counter()
+        r1 = vs.get_var_in_ref(one)
+        lat.append(time.perf_counter() - a)
+        r1.close()
+    p50 = float(np.median(lat)) * 1e6 if lat else None
+
+    if rank == 0:
+        out = {
+            "metric": "region-queries/sec (batch, query-type 6)",
+            "value": world * nreg * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {w['ref_length']} bp, {w['num_variants']} sites, "
+                            f"{w['num_samples']} samples, {nreg} random {w['region_len']} bp regions per GPU, "
+                            "query type 6 (get_var_in_ref), index + regions resident in HBM, results left in HBM",
+                "regions_per_gpu": nreg, "region_len": w["region_len"],
+                "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
+                "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists" if use_dist else ""),
+                "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
+                          "classes": info.num_classes, "carrier_records": info.num_carriers,
+                          "hbm_image_bytes": info.device_bytes, "build_s": round(t_build, 1)},
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "bytes_per_launch": fill_bytes, "bytes_per_launch_survey_encoding": fill_bytes_survey,
+                         "avg_launch_ms": fill_ms / args.steps, "pipeline_ms": tot_ms / args.steps},
+            "p50_latency_us": p50,
+            "result_digest": f"{digest:016x}",
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

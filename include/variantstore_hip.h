@@ -145,9 +145,12 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
 /* Order-independent 64-bit digest of (region, pos, ref, alt, carriers) computed
  * on the device -- the "checksum of checksums" used by full-size property tests. */
 int vs_result_digest(vs_result* r, uint64_t* digest);
-/* Device pointers for zero-copy consumers (e.g. a collective over the hit lists).
- * headers: n_slots records of 4 x uint64 {pos, ref_off|ref_len<<32, alt_off|alt_len<<32, region}. */
-int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t* n_records);
+/* Hit-list records for a collective over the shards of a batch (all-gatherv):
+ * writes n_slots records of 4 x uint64 into DEVICE memory at device_dst
+ *   {pos | dropped<<63, ref_off | ref_len<<32, alt_off | alt_len<<32, (region_base+region) | car_count<<32}.
+ * device_dst == NULL only reports the record count. */
+int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
+                           uint64_t* n_records);
 void vs_result_free(vs_result* r);
 
 /* ---- timing of the last batch on this handle (HIP events on the engine's stream) ---- */

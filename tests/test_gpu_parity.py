@@ -81,7 +81,7 @@ def test_index_find_batched(golden_dir, survey_vectors, tmp_path):
     (103, dict(p_near=0.7, p_multi=0.3, n_rows=300, ref_len=3000)),             # crowded sites, many dummies
     (104, dict(p_ins=0.3, p_del=0.3, n_rows=250)),                              # indel heavy, overlapping deletions
     (105, dict(n_samples=70, carrier_p=0.4)),                                   # class rows wider than one word
-    (106, dict(n_samples=130, carrier_p=0.02, n_rows=200)),                     # sparse -> explicit sample ids
+    (106, dict(n_samples=130, carrier_p=0.004, n_rows=200)),                    # sparse -> explicit sample ids
     (107, dict(unphased_p=0.5, missing_p=0.2, haploid_p=0.2)),                  # '/', './.', haploid GT
     (108, dict(n_samples=1, carrier_p=1.0)),                                    # single sample
 ])

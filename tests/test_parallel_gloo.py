@@ -1,0 +1,87 @@
+"""world_size-2 `gloo` test of the sharding + all-gatherv plumbing (CPU, no GPU):
+the collective code path of bench.py / parallel.py with a stand-in result object
+that packs known records into host memory."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+class FakeResult:
+    def __init__(self, recs):
+        self.recs = np.ascontiguousarray(recs, dtype=np.uint64)
+
+    def num_header_records(self):
+        return self.recs.shape[0]
+
+    def pack_headers_into(self, ptr, cap, region_base):
+        assert cap >= self.recs.shape[0]
+        r = self.recs.copy()
+        r[:, 3] += np.uint64(region_base)
+        ctypes.memmove(ptr, r.ctypes.data, r.nbytes)
+        return r.shape[0]
+
+
+def _records(rank):
+    n = 5 + 3 * rank
+    r = np.zeros((n, 4), dtype=np.uint64)
+    r[:, 0] = np.arange(n) + 1000 * (rank + 1)
+    r[:, 1] = (np.uint64(1) << np.uint64(32)) | np.uint64(7 + rank)
+    r[:, 2] = (np.uint64(2) << np.uint64(32)) | np.uint64(9)
+    r[:, 3] = (np.arange(n) % 3).astype(np.uint64) | (np.uint64(11) << np.uint64(32))
+    return r
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from variantstore_amd.parallel import allgather_hit_lists, shard_regions, unpack_records
+    regions = np.stack([np.arange(1, 12), np.arange(1, 12) + 100], axis=1)
+    mine, lo = shard_regions(regions, rank, world)
+    out, counts = allgather_hit_lists(FakeResult(_records(rank)), lo, torch.device("cpu"))
+    parts = unpack_records(out, counts)
+    ok = [int(c) for c in counts] == [5 + 3 * r for r in range(world)]
+    for r in range(world):
+        want = _records(r)
+        rlo = shard_regions(regions, r, world)[1]
+        ok &= bool(np.array_equal(parts[r]["pos"], want[:, 0]))
+        ok &= bool(np.array_equal(parts[r]["region"], (want[:, 3] & np.uint64(0xFFFFFFFF)) + np.uint64(rlo)))
+        ok &= bool(np.all(parts[r]["car_count"] == 11)) and bool(np.all(parts[r]["ref_len"] == 1))
+    q.put((rank, ok, mine.shape[0], lo))
+    dist.destroy_process_group()
+
+
+def test_allgatherv_of_hit_lists_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [r[1] for r in res] == [True, True]
+    assert [(r[2], r[3]) for r in res] == [(6, 0), (5, 6)]  # 11 regions -> 6 + 5, contiguous
+
+
+def test_shard_bounds_cover_everything():
+    from variantstore_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 8, 100003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -99,6 +99,19 @@ class QueryResult:
             "carriers": arr(rv.carriers, s, np.uint32) if with_carriers else None,
         }
 
+    def num_header_records(self):
+        n = C.c_uint64()
+        _check(self._lib.vs_result_pack_headers(self._h, None, 0, 0, C.byref(n)), "vs_result_pack_headers")
+        return int(n.value)
+
+    def pack_headers_into(self, device_ptr, capacity_records, region_base=0):
+        """Write the hit-list records (4 x uint64 per variant slot) into device memory at `device_ptr`
+        (e.g. a torch CUDA tensor's data_ptr()) for a collective over the shards of a batch."""
+        n = C.c_uint64()
+        _check(self._lib.vs_result_pack_headers(self._h, C.c_void_p(device_ptr), capacity_records, region_base,
+                                                C.byref(n)), "vs_result_pack_headers")
+        return int(n.value)
+
     def region_text(self, q):
         """The `-o` file the reference writes for region q (query.h:38-50, 774-781)."""
         txt = C.c_char_p()

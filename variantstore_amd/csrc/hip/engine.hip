@@ -663,9 +663,22 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   return VS_OK;
 }
 
-int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t* n_records) {
-  (void)r; (void)device_dst; (void)capacity_records; (void)n_records;
-  return fail(VS_ERR_UNSUPPORTED, "header packing is not built yet");
+int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
+                           uint64_t* n_records) {
+  if (!r) return fail(VS_ERR_ARG, "null argument");
+  if (n_records) *n_records = r->d.A;
+  if (!device_dst) return VS_OK;  // size query
+  if (capacity_records < r->d.A) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
+                                             (unsigned long long)capacity_records, (unsigned long long)r->d.A);
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  if (r->d.A) {
+    hipLaunchKernelGGL(k_pack_headers, dim3((unsigned)((r->d.A + 255) / 256)), dim3(256), 0, idx->stream, r->d,
+                       (uint64_t*)device_dst, region_base);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  return VS_OK;
 }
 
 }  // extern "C"

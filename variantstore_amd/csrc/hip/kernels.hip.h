@@ -375,6 +375,18 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
   }
 }
 
+// Hit-list records for a collective: 4 x uint64 per slot
+//   {pos | dropped << 63, ref_off | ref_len << 32, alt_off | alt_len << 32, region | car_count << 32}
+__global__ void __launch_bounds__(256) k_pack_headers(DevResult r, uint64_t* dst, uint64_t region_base) {
+  const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= r.A) return;
+  const uint64_t dropped = (r.r_flags[a] & kVarDropped) ? (1ULL << 63) : 0ULL;
+  dst[4 * a + 0] = r.r_pos[a] | dropped;
+  dst[4 * a + 1] = (uint64_t)r.r_ref_off[a] | ((uint64_t)r.r_ref_len[a] << 32);
+  dst[4 * a + 2] = (uint64_t)r.r_alt_off[a] | ((uint64_t)r.r_alt_len[a] << 32);
+  dst[4 * a + 3] = (region_base + r.r_region[a]) | ((uint64_t)r.r_car_count[a] << 32);
+}
+
 // Index::find batched (index.h:119-133)
 __global__ void __launch_bounds__(256) k_find(DevImage im, const uint64_t* pos, uint64_t n, uint32_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

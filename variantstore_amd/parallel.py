@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of a region batch (one process per GPU, torch.distributed).
+
+Region queries are independent (the reference's serial loop, src/commands.cc:145,
+carries no state between regions), so the batch is partitioned across ranks, the
+index image is replicated, and the only exchange is an all-gatherv of the hit
+lists: a count all-gather followed by one padded `all_gather_into_tensor` of
+4 x uint64 header records (backend "nccl" is RCCL over xGMI on ROCm; the records
+are a few MB per rank, so the collective is latency-bound, not link-bound).
+Carrier lists stay sharded in the HBM of the rank that produced them.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced [lo, hi) slice of n sorted regions for `rank`."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_regions(regions, rank, world):
+    regions = np.asarray(regions, dtype=np.uint64).reshape(-1, 2)
+    lo, hi = shard_bounds(regions.shape[0], rank, world)
+    return regions[lo:hi], lo
+
+
+def allgather_hit_lists(result, region_base, device):
+    """All-gatherv of variant header records.
+
+    `result` exposes num_header_records() and pack_headers_into(ptr, capacity, region_base)
+    (QueryResult does).  Returns (records[int64, world x max_n x 4], counts[int64, world]).
+    """
+    world = dist.get_world_size()
+    n = result.num_header_records()
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    mine = torch.tensor([n], dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, mine)
+    max_n = max(int(counts.max().item()), 1)
+    buf = torch.zeros((max_n, 4), dtype=torch.int64, device=device)
+    result.pack_headers_into(buf.data_ptr(), max_n, region_base)
+    out = torch.empty((world * max_n, 4), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    return out.view(world, max_n, 4), counts
+
+
+def unpack_records(records, counts):
+    """Host view of gathered records: list of dicts per rank with numpy arrays."""
+    out = []
+    rec = records.cpu().numpy().view(np.uint64)
+    for r in range(rec.shape[0]):
+        a = rec[r, : int(counts[r])]
+        out.append({
+            "pos": a[:, 0] & np.uint64((1 << 63) - 1),
+            "dropped": (a[:, 0] >> np.uint64(63)).astype(bool),
+            "ref_off": (a[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+            "ref_len": (a[:, 1] >> np.uint64(32)).astype(np.uint32),
+            "alt_off": (a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+            "alt_len": (a[:, 2] >> np.uint64(32)).astype(np.uint32),
+            "region": (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.uint64),
+            "car_count": (a[:, 3] >> np.uint64(32)).astype(np.uint32),
+        })
+    return out
