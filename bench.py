@@ -139,18 +139,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res, _ = step()
+    for _i in range(args.warmup):
+        res, _g = step()
         res.close()
     fence()
     fill_ms = tot_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, _ = step()
+    for i in range(args.steps):
+        res, _g = step()
         t = vs.last_timing()
         fill_ms += t.ms_fill
         tot_ms += t.ms_total
-        if _ != args.steps - 1:
+        if i != args.steps - 1:
             res.close()
     fence()
     elapsed = time.perf_counter() - t0
