@@ -200,6 +200,8 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(alloc_image(idx, G, &d.s_flags));
   VS_TRY(alloc_image(idx, G, &d.s_dup_prev));
   VS_TRY(alloc_image(idx, G + 1, &d.s_carpre));
+  VS_TRY(alloc_image(idx, G, &d.s_class));
+  VS_TRY(alloc_image(idx, G, &d.s_gt0));
   d.sus_g = nullptr; d.sus_prev = nullptr; d.n_sus = 0;
 
   // site table: the reference's per-node classification, once for the whole ref path
@@ -299,6 +301,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_site));
   VS_TRY(ralloc(r, d.A, &d.r_region));
   VS_TRY(ralloc(r, d.A, &d.r_car_begin));
+  VS_TRY(ralloc(r, d.A, &d.r_class));
+  VS_TRY(ralloc(r, d.A, &d.r_gt0));
   VS_TRY(ralloc(r, d.S, &d.carriers));
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
@@ -308,8 +312,15 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (d.A) {
-    uint64_t blocks = std::min<uint64_t>((d.A + 3) / 4, 16384);
-    hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
+    static const int fill_variant = getenv("VS_FILL_V1") ? 1 : 2;
+    if (fill_variant == 1) {
+      uint64_t blocks = std::min<uint64_t>((d.A + 3) / 4, 16384);
+      hipLaunchKernelGGL(k_fill_carriers_v1, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
+    } else {
+      const uint64_t nchunks = (d.A + 63) / 64;
+      uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
+      hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
+    }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));

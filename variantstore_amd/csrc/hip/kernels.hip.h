@@ -52,8 +52,9 @@ struct DevImage {
   const uint32_t* car_sid;
   const uint8_t* seq_codes;
   // site table (one entry per branch of a ref-path node, ref-path order)
-  uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev;
+  uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev, *s_class;
   uint64_t* s_carpre;  // [G+1] exclusive prefix of s_ncar
+  uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
   uint32_t n_sus, pad2_;
@@ -70,8 +71,9 @@ struct DevResult {
   uint64_t* car_base;       // [Q+1]
   uint64_t* var_count;      // [Q]
   uint64_t* r_pos;
-  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_site, *r_region;
+  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_site, *r_region, *r_class;
   uint64_t* r_car_begin;
+  uint64_t* r_gt0;
   uint32_t* carriers;
 };
 
@@ -128,6 +130,7 @@ __global__ void __launch_bounds__(256) k_build_sites(DevImage im, uint64_t slot_
     }
     im.s_pos[g] = pos; im.s_ref_off[g] = ro; im.s_ref_len[g] = rl; im.s_alt_off[g] = ao; im.s_alt_len[g] = al;
     im.s_vid[g] = b; im.s_ncar[g] = (fl & kSiteAlwaysDrop) ? 0u : ncar; im.s_flags[g] = fl;
+    im.s_class[g] = im.v_class[b]; im.s_gt0[g] = im.v_car_begin[b];
     ++g;
   }
 }
@@ -288,6 +291,8 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
     r.r_car_count[a] = im.s_ncar[g];
     r.r_site[a] = g;
     r.r_region[a] = (uint32_t)q;
+    r.r_class[a] = im.s_class[g];
+    r.r_gt0[a] = im.s_gt0[g];
   }
   if (lane == 0 && !(r.q_flags[q] & kRegionSlow)) r.var_count[q] = n;
 }
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 // set bits.  Explicit mode: a coalesced copy of the stored ids.
 // Output word = sample id | genotype bits << 29.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r) {
+__global__ void __launch_bounds__(256) k_fill_carriers_v1(DevImage im, DevResult r) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -371,6 +376,209 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
         const uint32_t nib = (im.gt_nibbles[c >> 1] >> ((c & 1) * 4)) & 7u;
         out[k] = im.car_sid[c] | (nib << 29);
       }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Carrier expansion v2.  One wave owns 64 consecutive variant slots; every lane
+// first gathers the metadata of "its" slot (all 64 gathers in flight together),
+// then the wave works through the chunk in two regimes:
+//
+//  sparse  (<= kSparseMax carriers): LANE PER VARIANT.  The lane walks the class
+//          row of its own variant and peels the few set bits; its genotype
+//          nibbles were fetched beforehand as three unaligned 64-bit windows, so
+//          the peel loop is pure ALU + stores.  Consecutive slots own consecutive
+//          pieces of the carrier arena, so the lanes' small stores land in a
+//          handful of adjacent cache lines.
+//  dense   (>  kSparseMax carriers): WAVE PER VARIANT, BIT PER LANE.  The row is
+//          loaded once, coalesced (lane w holds word w); for every non-zero word
+//          the lanes whose bit is set compute their rank with mbcnt and store
+//          id|gt into consecutive arena words (fully coalesced), genotype
+//          nibbles are read as consecutive bytes.  The next dense variant's row
+//          is requested before the current one is expanded.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSparseMax = 32;
+constexpr uint32_t kNibWords = 512;  // 2 KiB of staged genotype nibbles per wave
+constexpr uint32_t kMidMax = 640;    // <= this many carriers: ids are staged in LDS and copied out coalesced
+
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint64_t nchunks = (r.A + 63) >> 6;
+  const uint32_t wpc = im.wpc;
+  const uint64_t* __restrict__ class_rows = im.class_rows;
+  const uint8_t* __restrict__ gtp = im.gt_nibbles;
+  uint32_t* __restrict__ carriers = r.carriers;
+  __shared__ uint32_t lds_nib[4 * kNibWords];
+  __shared__ uint32_t lds_ids[4 * kMidMax];
+
+  for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const uint64_t a = (chunk << 6) + lane;
+    uint32_t cnt = 0, cls = 0;
+    uint64_t gt0 = 0, cb = 0;
+    if (a < r.A) {
+      cnt = r.r_car_count[a];
+      cls = r.r_class[a];
+      gt0 = r.r_gt0[a];
+      cb = r.r_car_begin[a];
+    }
+    if (!im.use_bv) {
+      // explicit sample ids: a copy, lane per variant (lists are short in this mode)
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const uint64_t c = gt0 + k;
+        const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
+        carriers[cb + k] = im.car_sid[c] | (nib << 29);
+      }
+      continue;
+    }
+
+    // ---------------- sparse: lane per variant ----------------
+    if (cnt > 0 && cnt <= kSparseMax) {
+      const uint8_t* gp = gtp + (gt0 >> 1);
+      const uint32_t odd = (uint32_t)(gt0 & 1);
+      const uint64_t n0 = load_u64_unaligned(gp), n1 = load_u64_unaligned(gp + 8), n2 = load_u64_unaligned(gp + 16);
+      const uint64_t* row = class_rows + (uint64_t)cls * wpc;
+      uint32_t* out = carriers + cb;
+      uint32_t k = 0;
+      for (uint32_t w0 = 0; w0 < wpc && k < cnt; w0 += 8) {
+        uint64_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (w0 + i < wpc) ? row[w0 + i] : 0ULL;
+        if (w0 == 0) x[0] &= ~1ULL;  // bit 0 is "ref"
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          uint64_t word = x[i];
+          while (word) {
+            const uint32_t bit = __builtin_ctzll(word);
+            word &= word - 1;
+            const uint32_t ni = k + odd;
+            const uint64_t win = ni < 16 ? n0 : (ni < 32 ? n1 : n2);
+            const uint32_t nib = (uint32_t)(win >> ((ni & 15) * 4)) & 7u;
+            if (k < cnt) out[k] = ((w0 + i) * 64 + bit) | (nib << 29);
+            ++k;
+          }
+        }
+      }
+    }
+
+    // ---------------- dense: wave per variant, bit per lane ----------------
+    uint64_t dmask = __ballot(cnt > kSparseMax);
+    if (dmask == 0) continue;
+    // Per-wave LDS staging area for one variant's genotype nibbles (2 KiB = 4096 nibbles).
+    uint8_t* nib_lds = reinterpret_cast<uint8_t*>(&lds_nib[(threadIdx.x >> 6) * kNibWords]);
+    uint32_t* ids_lds = &lds_ids[(threadIdx.x >> 6) * kMidMax];
+    int t = __builtin_ctzll(dmask);
+    uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
+    uint64_t gt0_t = wave_bcast64(gt0, t);
+    uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
+    uint64_t word_cur = 0;
+    uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};
+    // first variant: request its row and its nibbles
+    {
+      if (lane < wpc) word_cur = class_rows[(uint64_t)cls_t * wpc + lane];
+      const uint64_t b0 = (gt0_t >> 1) & ~15ULL;                        // aligned byte base
+      const uint64_t need = ((gt0_t + cnt_t + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+    }
+    while (dmask) {
+      t = __builtin_ctzll(dmask);
+      dmask &= dmask - 1;
+      cnt_t = __builtin_amdgcn_readlane(cnt, t);
+      cls_t = __builtin_amdgcn_readlane(cls, t);
+      gt0_t = wave_bcast64(gt0, t);
+      const uint64_t cb_t = wave_bcast64(cb, t);
+      const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
+      const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // nibble index of carrier 0 inside the staged block
+      const bool staged = (uint64_t)nshift + cnt_t <= kNibWords * 8;    // fits the 2 KiB block
+      // stage this variant's nibbles (fetched during the previous variant)
+      *reinterpret_cast<uint4*>(nib_lds + lane * 16) = nq0;
+      *reinterpret_cast<uint4*>(nib_lds + 1024 + lane * 16) = nq1;
+      // request the next dense variant's row and nibbles before expanding this one
+      uint64_t word_next = 0;
+      nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0};
+      if (dmask) {
+        const int tn = __builtin_ctzll(dmask);
+        const uint32_t cls_n = __builtin_amdgcn_readlane(cls, tn);
+        const uint64_t gt0_n = wave_bcast64(gt0, tn);
+        const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
+        if (lane < wpc) word_next = class_rows[(uint64_t)cls_n * wpc + lane];
+        const uint64_t bn = (gt0_n >> 1) & ~15ULL;
+        const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
+        if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
+        if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
+      }
+      uint32_t* out = carriers + cb_t;
+      if (cnt_t <= kMidMax && staged && wpc <= 64) {
+        // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
+        uint64_t mine = word_cur;
+        if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+        const uint32_t pc = __popcll(mine);
+        uint32_t incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = __shfl_up(incl, d, 64);
+          if (lane >= (uint32_t)d) incl += up;
+        }
+        uint32_t k = incl - pc;
+        const uint32_t idbase = lane * 64;
+        while (mine) {
+          const uint32_t bit = __builtin_ctzll(mine);
+          mine &= mine - 1;
+          if (k < kMidMax) ids_lds[k] = idbase + bit;
+          ++k;
+        }
+        for (uint32_t j = lane; j < cnt_t; j += 64) {
+          const uint32_t ni = nshift + j;
+          const uint32_t nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
+          out[j] = ids_lds[j] | (nib << 29);
+        }
+        word_cur = word_next;
+        continue;
+      }
+      uint32_t base = 0;
+      for (uint32_t wb = 0; wb < wpc; wb += 64) {
+        uint64_t mine = word_cur;
+        if (wb) mine = (wb + lane < wpc) ? class_rows[(uint64_t)cls_t * wpc + wb + lane] : 0ULL;
+        if (wb == 0 && lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+        uint64_t nz = __ballot(mine != 0);
+        while (nz) {
+          const int w = __builtin_ctzll(nz);
+          nz &= nz - 1;
+          const uint64_t word = wave_bcast64(mine, w);
+          const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+          if ((word >> lane) & 1) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+            const uint32_t k = base + rank;
+            uint32_t nib;
+            if (staged) {
+              const uint32_t ni = nshift + k;
+              nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
+            } else {
+              const uint64_t c = gt0_t + k;
+              nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
+            }
+            if (k < cnt_t) out[k] = ((wb + w) * 64 + lane) | (nib << 29);
+          }
+          base += __popcll(word);
+        }
+      }
+      word_cur = word_next;
     }
   }
 }

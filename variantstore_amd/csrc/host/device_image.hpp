@@ -222,7 +222,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   if (im.wpc) im.class_rows[0] = 1;  // class 0: only "ref"
   if (g.use_bit_vector && !g.class_bits.empty())
     std::copy(g.class_bits.begin(), g.class_bits.end(), im.class_rows.begin() + im.wpc);
-  im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 8, 0);
+  im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 32, 0);  // windowed 64-bit reads run up to 24 bytes past a list
   for (uint64_t c = 0; c < g.car_flags.size(); ++c)
     im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
   im.car_sid = g.car_sid;
