@@ -415,6 +415,31 @@ __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Generic (slow) expansion of one variant by a whole wave: any row width, genotype
+// nibbles read straight from global memory.  Kept out of line so that its loads do
+// not force memory waits into the tuned loops of k_fill_carriers.
+__device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, const uint8_t* gtp, uint64_t gt0,
+                                            uint32_t* out, uint32_t lane) {
+  uint32_t base = 0;
+  for (uint32_t wb = 0; wb < wpc; wb += 64) {
+    uint64_t mine = (wb + lane < wpc) ? row[wb + lane] : 0ULL;
+    if (wb == 0 && lane == 0) mine &= ~1ULL;
+    uint64_t nz = __ballot(mine != 0);
+    while (nz) {
+      const int w = __builtin_ctzll(nz);
+      nz &= nz - 1;
+      const uint64_t word = wave_bcast64(mine, w);
+      if ((word >> lane) & 1) {
+        const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, 0));
+        const uint64_t c = gt0 + k;
+        const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
+        out[k] = ((wb + w) * 64 + lane) | (nib << 29);
+      }
+      base += __popcll(word);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -469,7 +494,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
             const uint32_t ni = k + odd;
             const uint64_t win = ni < 16 ? n0 : (ni < 32 ? n1 : n2);
             const uint32_t nib = (uint32_t)(win >> ((ni & 15) * 4)) & 7u;
-            if (k < cnt) out[k] = ((w0 + i) * 64 + bit) | (nib << 29);
+            out[k] = ((w0 + i) * 64 + bit) | (nib << 29);
             ++k;
           }
         }
@@ -524,10 +549,16 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
         if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
       }
       uint32_t* out = carriers + cb_t;
-      if (cnt_t <= kMidMax && staged && wpc <= 64) {
+      if (!staged || wpc > 64) {
+        // rows wider than one wave or more than 4096 staged nibbles: generic path
+        expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, out, lane);
+        word_cur = word_next;
+        continue;
+      }
+      uint64_t mine = word_cur;
+      if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+      if (cnt_t <= kMidMax) {
         // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
-        uint64_t mine = word_cur;
-        if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
         const uint32_t pc = __popcll(mine);
         uint32_t incl = pc;
 #pragma unroll
@@ -540,7 +571,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
         while (mine) {
           const uint32_t bit = __builtin_ctzll(mine);
           mine &= mine - 1;
-          if (k < kMidMax) ids_lds[k] = idbase + bit;
+          ids_lds[k] = idbase + bit;
           ++k;
         }
         for (uint32_t j = lane; j < cnt_t; j += 64) {
@@ -548,14 +579,10 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
           const uint32_t nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
           out[j] = ids_lds[j] | (nib << 29);
         }
-        word_cur = word_next;
-        continue;
-      }
-      uint32_t base = 0;
-      for (uint32_t wb = 0; wb < wpc; wb += 64) {
-        uint64_t mine = word_cur;
-        if (wb) mine = (wb + lane < wpc) ? class_rows[(uint64_t)cls_t * wpc + wb + lane] : 0ULL;
-        if (wb == 0 && lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+      } else {
+        // ---- dense: bit per lane, one coalesced store per non-zero row word ----
+        uint32_t base = nshift;  // nibble index of the word's first carrier inside the staged block
+        uint32_t* outs = out - nshift;
         uint64_t nz = __ballot(mine != 0);
         while (nz) {
           const int w = __builtin_ctzll(nz);
@@ -563,17 +590,9 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
           const uint64_t word = wave_bcast64(mine, w);
           const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
           if ((word >> lane) & 1) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
-            const uint32_t k = base + rank;
-            uint32_t nib;
-            if (staged) {
-              const uint32_t ni = nshift + k;
-              nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
-            } else {
-              const uint64_t c = gt0_t + k;
-              nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
-            }
-            if (k < cnt_t) out[k] = ((wb + w) * 64 + lane) | (nib << 29);
+            const uint32_t ni = base + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+            const uint32_t nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
+            outs[ni] = (w * 64 + lane) | (nib << 29);
           }
           base += __popcll(word);
         }

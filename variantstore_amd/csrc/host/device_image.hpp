@@ -130,6 +130,26 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     im.v_car_begin[v] = g.car_begin[v];
   }
 
+  // The device expands a class row into exactly v_ncar carriers without bounds checks:
+  // a vertex whose s_info count disagrees with its class row is refused here
+  // (the reference only logs this condition, variant_graph.h:1303-1308).
+  if (g.use_bit_vector) {
+    std::vector<uint32_t> class_pop(g.num_classes + 1, 0);
+    for (uint64_t c = 1; c <= g.num_classes; ++c) {
+      const uint64_t* row = &g.class_bits[(c - 1) * im.wpc];
+      uint32_t pc = 0;
+      for (uint32_t w = 0; w < im.wpc; ++w) pc += __builtin_popcountll(w == 0 ? (row[w] & ~1ULL) : row[w]);
+      class_pop[c] = pc;
+    }
+    for (uint64_t v = 0; v < V; ++v) {
+      if (g.class_id[v] > g.num_classes) throw std::runtime_error("vertex refers to a sample class that does not exist");
+      if (class_pop[g.class_id[v]] != im.v_ncar[v]) throw std::runtime_error("s_info count of a vertex differs from its sample class");
+    }
+  } else {
+    for (uint32_t sid : g.car_sid)
+      if (sid >= g.num_samples) throw std::runtime_error("explicit sample id out of range");
+  }
+
   // ---- ref path: vertex 0, then get_neighbor_vertex(., ref) (variant_graph.h:1402-1451, 2025-2032) ----
   auto ref_successor = [&](uint32_t v) -> uint32_t {
     uint32_t best = 0, min_idx = UINT32_MAX;
