@@ -186,6 +186,8 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.v_nri, &d.v_nri));
   VS_TRY(upload_image(idx, im.v_car_begin, &d.v_car_begin));
   VS_TRY(upload_image(idx, im.class_rows, &d.class_rows));
+  VS_TRY(upload_image(idx, im.cls_list_begin, &d.cls_list_begin));
+  VS_TRY(upload_image(idx, im.cls_list_ids, &d.cls_list_ids));
   VS_TRY(upload_image(idx, im.gt_nibbles, &d.gt_nibbles));
   VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
   VS_TRY(upload_image(idx, im.seq_codes, &d.seq_codes));
@@ -319,7 +321,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     } else {
       const uint64_t nchunks = (d.A + 63) / 64;
       uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
-      hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
+      static const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;
+      hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
     }
     HIP_TRY(hipGetLastError());
   }

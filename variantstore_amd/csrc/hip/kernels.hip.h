@@ -48,6 +48,8 @@ struct DevImage {
   const uint32_t *v_off, *v_len, *v_ridx, *v_class, *v_ncar, *v_nri;
   const uint64_t* v_car_begin;
   const uint64_t* class_rows;
+  const uint32_t* cls_list_begin;
+  const uint32_t* cls_list_ids;
   const uint8_t* gt_nibbles;
   const uint32_t* car_sid;
   const uint8_t* seq_codes;
@@ -400,8 +402,9 @@ __global__ void __launch_bounds__(256) k_fill_carriers_v1(DevImage im, DevResult
 //          is requested before the current one is expanded.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 32;
-constexpr uint32_t kNibWords = 512;  // 2 KiB of staged genotype nibbles per wave
-constexpr uint32_t kMidMax = 640;    // <= this many carriers: ids are staged in LDS and copied out coalesced
+constexpr uint32_t kLdsWordsPerWave = 1024 + 256;  // per wave: 4 KiB genotype bytes (one per carrier) + 1 KiB output ring
+constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
+constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
 
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
   uint64_t v;
@@ -409,10 +412,30 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
   return v;
 }
 
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint32_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
 __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
   const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
   const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
   return ((uint64_t)hi << 32) | lo;
+}
+
+// 32 packed genotype nibbles (one uint4) -> 32 bytes in LDS, nibble order preserved.
+__device__ __forceinline__ void stage_unpacked(uint8_t* dst, uint4 n) {
+  uint32_t in[4] = {n.x, n.y, n.z, n.w};
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t a = in[i] & 0x07070707u, b = (in[i] >> 4) & 0x07070707u;
+    o[2 * i] = __builtin_amdgcn_perm(b, a, 0x05010400u);      // a0 b0 a1 b1
+    o[2 * i + 1] = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+  }
+  reinterpret_cast<uint4*>(dst)[0] = uint4{o[0], o[1], o[2], o[3]};
+  reinterpret_cast<uint4*>(dst)[1] = uint4{o[4], o[5], o[6], o[7]};
 }
 
 // Generic (slow) expansion of one variant by a whole wave: any row width, genotype
@@ -440,7 +463,8 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
   }
 }
 
-__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r) {
+// `ablate` is a profiling aid (bit0: skip sparse, bit1: skip medium, bit2: skip dense); 0 in production.
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -449,8 +473,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
   uint32_t* __restrict__ carriers = r.carriers;
-  __shared__ uint32_t lds_nib[4 * kNibWords];
-  __shared__ uint32_t lds_ids[4 * kMidMax];
+  __shared__ uint32_t lds_blk[4 * kLdsWordsPerWave];
 
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t a = (chunk << 6) + lane;
@@ -473,40 +496,43 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
     }
 
     // ---------------- sparse: lane per variant ----------------
-    if (cnt > 0 && cnt <= kSparseMax) {
+    // ids come from the class's decoded id list (built once at load), genotypes from
+    // three unaligned 64-bit windows of the nibble pool; the loop is loads-then-stores.
+    if (cnt > 0 && cnt <= kSparseMax && !(ablate & 1)) {
       const uint8_t* gp = gtp + (gt0 >> 1);
       const uint32_t odd = (uint32_t)(gt0 & 1);
-      const uint64_t n0 = load_u64_unaligned(gp), n1 = load_u64_unaligned(gp + 8), n2 = load_u64_unaligned(gp + 16);
-      const uint64_t* row = class_rows + (uint64_t)cls * wpc;
+      const uint64_t n0 = load_u64_unaligned(gp);
+      const uint32_t* __restrict__ ids = im.cls_list_ids + im.cls_list_begin[cls];
       uint32_t* out = carriers + cb;
-      uint32_t k = 0;
-      for (uint32_t w0 = 0; w0 < wpc && k < cnt; w0 += 8) {
-        uint64_t x[8];
+      uint4 q = load_u128_unaligned(ids);
+      uint64_t n1 = 0, n2 = 0;
+      if (cnt + odd > 16) { n1 = load_u64_unaligned(gp + 8); n2 = load_u64_unaligned(gp + 16); }
+      for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+        const uint4 cur = q;
+        if (k0 + 4 < cnt) q = load_u128_unaligned(ids + k0 + 4);
+        const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = (w0 + i < wpc) ? row[w0 + i] : 0ULL;
-        if (w0 == 0) x[0] &= ~1ULL;  // bit 0 is "ref"
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          uint64_t word = x[i];
-          while (word) {
-            const uint32_t bit = __builtin_ctzll(word);
-            word &= word - 1;
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t k = k0 + i;
+          if (k < cnt) {
             const uint32_t ni = k + odd;
             const uint64_t win = ni < 16 ? n0 : (ni < 32 ? n1 : n2);
             const uint32_t nib = (uint32_t)(win >> ((ni & 15) * 4)) & 7u;
-            out[k] = ((w0 + i) * 64 + bit) | (nib << 29);
-            ++k;
+            out[k] = v[i] | (nib << 29);
           }
         }
       }
     }
 
-    // ---------------- dense: wave per variant, bit per lane ----------------
+    // ---------------- mid / dense: wave per variant ----------------
     uint64_t dmask = __ballot(cnt > kSparseMax);
     if (dmask == 0) continue;
-    // Per-wave LDS staging area for one variant's genotype nibbles (2 KiB = 4096 nibbles).
-    uint8_t* nib_lds = reinterpret_cast<uint8_t*>(&lds_nib[(threadIdx.x >> 6) * kNibWords]);
-    uint32_t* ids_lds = &lds_ids[(threadIdx.x >> 6) * kMidMax];
+    // Per-wave LDS block (4 KiB): one genotype BYTE per carrier (unpacked from the nibble
+    // pool while staging, so the expansion loops read it with a single ds_read_u8);
+    // the medium-density path also keeps its id list in the upper part of the block.
+    uint8_t* gt_lds = reinterpret_cast<uint8_t*>(&lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave]);
+    uint32_t* ids_lds = &lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave + kMidIdsAt];
+    uint32_t* ring = &lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave + 1024];
     int t = __builtin_ctzll(dmask);
     uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
     uint64_t gt0_t = wave_bcast64(gt0, t);
@@ -529,12 +555,12 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
       gt0_t = wave_bcast64(gt0, t);
       const uint64_t cb_t = wave_bcast64(cb, t);
       const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
-      const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // nibble index of carrier 0 inside the staged block
-      const bool staged = (uint64_t)nshift + cnt_t <= kNibWords * 8;    // fits the 2 KiB block
-      // stage this variant's nibbles (fetched during the previous variant)
-      *reinterpret_cast<uint4*>(nib_lds + lane * 16) = nq0;
-      *reinterpret_cast<uint4*>(nib_lds + 1024 + lane * 16) = nq1;
-      // request the next dense variant's row and nibbles before expanding this one
+      const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
+      const bool staged = (uint64_t)nshift + cnt_t <= 4096;             // fits the 4 KiB block
+      // stage this variant's genotypes (fetched during the previous variant), one byte per carrier
+      stage_unpacked(gt_lds + lane * 32, nq0);
+      if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
+      // request the next variant's row and nibbles before expanding this one
       uint64_t word_next = 0;
       nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0};
       if (dmask) {
@@ -550,13 +576,18 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
       }
       uint32_t* out = carriers + cb_t;
       if (!staged || wpc > 64) {
-        // rows wider than one wave or more than 4096 staged nibbles: generic path
+        // rows wider than one wave or more than 4096 staged genotypes: generic path
         expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, out, lane);
         word_cur = word_next;
         continue;
       }
       uint64_t mine = word_cur;
       if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+      const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
+      uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
+      const uint32_t endpos = a0 + cnt_t;
+      if ((ablate & 2) && cnt_t <= kMidMax) { word_cur = word_next; continue; }
+      if ((ablate & 4) && cnt_t > kMidMax) { word_cur = word_next; continue; }
       if (cnt_t <= kMidMax) {
         // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
         const uint32_t pc = __popcll(mine);
@@ -574,27 +605,36 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r)
           ids_lds[k] = idbase + bit;
           ++k;
         }
-        for (uint32_t j = lane; j < cnt_t; j += 64) {
-          const uint32_t ni = nshift + j;
-          const uint32_t nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
-          out[j] = ids_lds[j] | (nib << 29);
-        }
+        // copy-out in 256-byte-aligned blocks of the arena
+        for (uint32_t pos = lane; pos < endpos; pos += 64)
+          if (pos >= a0) gbase[pos] = ids_lds[pos - a0] | ((uint32_t)gt_lds[nshift + pos - a0] << 29);
       } else {
-        // ---- dense: bit per lane, one coalesced store per non-zero row word ----
-        uint32_t base = nshift;  // nibble index of the word's first carrier inside the staged block
-        uint32_t* outs = out - nshift;
-        uint64_t nz = __ballot(mine != 0);
-        while (nz) {
-          const int w = __builtin_ctzll(nz);
-          nz &= nz - 1;
+        // ---- dense: bit per lane; carriers go through a 256-entry LDS ring and leave as
+        //      full-wave stores on 256-byte-aligned blocks of the arena (partial, unaligned
+        //      stores run at less than half the write bandwidth of aligned full ones) ----
+        uint32_t base = nshift;                    // staged genotype index of the word's first carrier
+        const uint32_t delta = a0 - nshift;        // ring position = staged index + delta (mod 2^32)
+        uint32_t nfl = 0;                          // aligned blocks already written
+        uint32_t idv = lane;
+        for (uint32_t w = 0; w < wpc; ++w, idv += 64) {
           const uint64_t word = wave_bcast64(mine, w);
+          if (word == 0) continue;
           const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
           if ((word >> lane) & 1) {
-            const uint32_t ni = base + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
-            const uint32_t nib = (nib_lds[ni >> 1] >> ((ni & 1) * 4)) & 7u;
-            outs[ni] = (w * 64 + lane) | (nib << 29);
+            const uint32_t ni = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
+            ring[(ni + delta) & 255u] = idv | ((uint32_t)gt_lds[ni] << 29);
           }
           base += __popcll(word);
+          const uint32_t full = (base + delta) >> 6;   // complete aligned blocks so far
+          while (nfl < full) {
+            const uint32_t pos = nfl * 64 + lane;
+            if (pos >= a0) gbase[pos] = ring[pos & 255u];
+            ++nfl;
+          }
+        }
+        if (nfl * 64 < endpos) {                      // tail block
+          const uint32_t pos = nfl * 64 + lane;
+          if (pos >= a0 && pos < endpos) gbase[pos] = ring[pos & 255u];
         }
       }
       word_cur = word_next;

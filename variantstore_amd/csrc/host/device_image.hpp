@@ -30,6 +30,7 @@
 namespace vsamd {
 
 constexpr uint32_t VS_NONE = 0xFFFFFFFFu;
+constexpr uint32_t kSparseClassMax = 32;  // must equal kSparseMax in kernels.hip.h
 
 struct HostImage {
   // scalars
@@ -58,6 +59,10 @@ struct HostImage {
 
   // classes / genotypes / explicit ids / sequence
   std::vector<uint64_t> class_rows;  // (C+1) rows of wpc words; row 0 = {bit 0}
+  // sparse classes (<= kSparseClassMax carriers) also decoded once into explicit id lists, so the
+  // expansion of a rare variant reads a few ids instead of scanning a whole bit row
+  std::vector<uint32_t> cls_list_begin;  // [C+2]
+  std::vector<uint32_t> cls_list_ids;    // ascending sample ids (ref excluded), padded
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
   std::vector<uint8_t> seq_codes;    // DNA_MAP codes, one per base
@@ -242,6 +247,24 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   if (im.wpc) im.class_rows[0] = 1;  // class 0: only "ref"
   if (g.use_bit_vector && !g.class_bits.empty())
     std::copy(g.class_bits.begin(), g.class_bits.end(), im.class_rows.begin() + im.wpc);
+  im.cls_list_begin.assign(im.C + 2, 0);
+  im.cls_list_ids.clear();
+  if (g.use_bit_vector) {
+    for (uint64_t c = 1; c <= im.C; ++c) {
+      const uint64_t* row = &im.class_rows[c * im.wpc];
+      uint32_t pc = 0;
+      for (uint32_t w = 0; w < im.wpc; ++w) pc += __builtin_popcountll(w == 0 ? (row[w] & ~1ULL) : row[w]);
+      im.cls_list_begin[c] = (uint32_t)im.cls_list_ids.size();
+      if (pc <= kSparseClassMax) {
+        for (uint32_t w = 0; w < im.wpc; ++w) {
+          uint64_t x = w == 0 ? (row[w] & ~1ULL) : row[w];
+          while (x) { im.cls_list_ids.push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
+        }
+      }
+    }
+    im.cls_list_begin[im.C + 1] = (uint32_t)im.cls_list_ids.size();
+  }
+  im.cls_list_ids.resize(im.cls_list_ids.size() + 8, 0);  // 16-byte reads may run past the last list
   im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 32, 0);  // windowed 64-bit reads run up to 24 bytes past a list
   for (uint64_t c = 0; c < g.car_flags.size(); ++c)
     im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
