@@ -162,15 +162,23 @@ def main():
     # ---- result-derived figures of one batch (last step's result is still alive) ----
     nq, nvar, ncar, nbases = res.totals()
     digest = res.digest()
+    v = res.view(with_carriers=False)
+    kept = (v["var_flags"] & 1) == 0
+    cc = v["car_count"][kept].astype(np.int64)
+    n_sparse = int((cc <= 32).sum())
+    car_sparse = int(cc[cc <= 32].sum())
     W = ((info.num_samples + 63) // 64) * 8
-    # dominant kernel k_fill_carriers, bytes one launch must move with this layout:
-    #   per variant: header words it reads (car_count 4, site 4, car_begin 8, branch vertex 4, class 4,
-    #   genotype base 8) + its class row (W bytes); per carrier: half a byte of genotype in, 4 bytes out
-    fill_bytes = nvar * (32 + W) + (ncar + 1) // 2 + 4 * ncar
-    # the same kernel priced by SURVEY.md §8(d)'s encoding (3-bit genotypes in, 4+1 bytes out per carrier)
+    # Dominant kernel k_fill_carriers.  `achieved` prices one launch with SURVEY.md §8(d)'s formula,
+    # restricted to the terms this kernel owns: per variant its class row (W bytes) and
+    # its car_begin word (8), per carrier 3 genotype bits in and a 4-byte id + 1-byte genotype out.
     fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
+    # The bytes this layout actually has to move (lower): 32 B of slot header per variant, the class row
+    # only for variants above 32 carriers (rarer ones read a decoded id list, 4 B per carrier), half a byte
+    # of genotype per carrier in, one packed 4-byte word per carrier out.
+    fill_bytes_layout = nvar * 32 + (nvar - n_sparse) * W + 4 * car_sparse + (ncar + 1) // 2 + 4 * ncar
     fill_s = fill_ms / args.steps / 1e3
-    achieved = fill_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
+    achieved = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
+    achieved_layout = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
     res.close()
 
     # ---- p50 single-region latency (submit -> result resident), outside the timed region ----
@@ -210,8 +218,10 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "bytes_per_launch": fill_bytes, "bytes_per_launch_survey_encoding": fill_bytes_survey,
-                         "avg_launch_ms": fill_ms / args.steps, "pipeline_ms": tot_ms / args.steps},
+                         "bytes_per_launch": fill_bytes_survey, "avg_launch_ms": fill_ms / args.steps,
+                         "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": fill_bytes_layout,
+                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                         "pipeline_ms": tot_ms / args.steps},
             "p50_latency_us": p50,
             "result_digest": f"{digest:016x}",
         }

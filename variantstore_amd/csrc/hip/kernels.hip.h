@@ -613,28 +613,27 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         //      full-wave stores on 256-byte-aligned blocks of the arena (partial, unaligned
         //      stores run at less than half the write bandwidth of aligned full ones) ----
         uint32_t base = nshift;                    // staged genotype index of the word's first carrier
-        const uint32_t delta = a0 - nshift;        // ring position = staged index + delta (mod 2^32)
+        const uint32_t delta = a0 - nshift;        // arena block position = staged index + delta (mod 2^32)
         uint32_t nfl = 0;                          // aligned blocks already written
         uint32_t idv = lane;
         for (uint32_t w = 0; w < wpc; ++w, idv += 64) {
           const uint64_t word = wave_bcast64(mine, w);
-          if (word == 0) continue;
           const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
-          if ((word >> lane) & 1) {
+          if (__builtin_amdgcn_inverse_ballot_w64(word)) {  // lane i is active iff bit i of the word is set
             const uint32_t ni = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
-            ring[(ni + delta) & 255u] = idv | ((uint32_t)gt_lds[ni] << 29);
+            ring[ni & 255u] = idv | ((uint32_t)gt_lds[ni] << 29);
           }
           base += __popcll(word);
           const uint32_t full = (base + delta) >> 6;   // complete aligned blocks so far
           while (nfl < full) {
             const uint32_t pos = nfl * 64 + lane;
-            if (pos >= a0) gbase[pos] = ring[pos & 255u];
+            if (pos >= a0) gbase[pos] = ring[(pos - delta) & 255u];
             ++nfl;
           }
         }
         if (nfl * 64 < endpos) {                      // tail block
           const uint32_t pos = nfl * 64 + lane;
-          if (pos >= a0 && pos < endpos) gbase[pos] = ring[pos & 255u];
+          if (pos >= a0 && pos < endpos) gbase[pos] = ring[(pos - delta) & 255u];
         }
       }
       word_cur = word_next;
