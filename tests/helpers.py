@@ -94,3 +94,40 @@ def oracle_texts(orc, regions, sample=None):
         else:
             out.append(orc.get_sample_var_in_ref(x, y, sample))
     return out
+
+
+def read_plain(path):
+    """Parse the plain dump (HostGraph::write_plain) into a dict of numpy arrays / lists."""
+    import struct
+    data = open(path, "rb").read()
+    assert data[:8] == b"VSPLAIN1"
+    pos = [8]
+
+    def u64():
+        v = struct.unpack_from("<Q", data, pos[0])[0]
+        pos[0] += 8
+        return v
+
+    def s():
+        n = u64()
+        v = data[pos[0]:pos[0] + n].decode("latin-1")
+        pos[0] += n
+        return v
+
+    def vec(dt):
+        n = u64()
+        a = np.frombuffer(data, dtype=dt, count=n, offset=pos[0]).copy()
+        pos[0] += n * np.dtype(dt).itemsize
+        return a
+
+    g = {"chr": s(), "ref_length": u64(), "num_samples": u64(), "use_bit_vector": u64(), "num_classes": u64()}
+    for k, dt in [("off", "<u4"), ("len", "<u4"), ("class_id", "<u4"), ("ref_index", "<u4"), ("car_begin", "<u8"),
+                  ("car_flags", "u1"), ("car_index", "<u4"), ("car_sid", "<u4"), ("seq", "u1"), ("class_bits", "<u8")]:
+        g[k] = vec(dt)
+    g["sample_names"] = [s() for _ in range(u64())]
+    g["topo_inplace"] = vec("u1")
+    g["topo_val"] = vec("<u4")
+    g["aux_lists"] = [vec("<u4") for _ in range(u64())]
+    g["idx_pos"] = vec("<u4")
+    g["node_list"] = vec("<u4")
+    return g
