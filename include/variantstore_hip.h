@@ -87,6 +87,7 @@ typedef struct {
   uint32_t use_bit_vector;
   uint64_t device_bytes;     /* HBM held by the image */
   int device;
+  uint64_t num_topology_keys; /* Graph::get_num_vertices(): vertices with an adjacency entry (graph.h:318-320) */
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);
 /* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */

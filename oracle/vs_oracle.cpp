@@ -487,7 +487,11 @@ struct Oracle {
           v_find = v; sample_found = true; sample_pos = sample_find.index;
         }
         ++it;
-        cur_ref_node_idx--;
+        // `cur_ref_node_idx--` on an unsigned counter (query.h:103): near the chromosome start it
+        // can pass zero and the reference then indexes node_list out of bounds.  Defined here
+        // (and in the HIP path) as clamping at zero, which ends the search at the first ref node.
+        if (cur_ref_node_idx == 0) ub_events++;
+        else cur_ref_node_idx--;
       }
       if (sample_found == true) break;
     }

@@ -1,0 +1,85 @@
+"""The drop-in `variantstore` command line (variantstore_amd/csrc/cli/variantstore.cpp):
+construct runs on the host; query needs the GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CLI = os.path.join(ROOT, "variantstore_amd", "bin", "variantstore")
+LOG = re.compile(r"^\[\d{4}-\d\d-\d\d \d\d:\d\d:\d\d\.\d{3}\] \[(info|error)\] (.*)$")
+
+
+def _msgs(stdout):
+    out = []
+    for line in stdout.splitlines():
+        m = LOG.match(line)
+        out.append(m.group(2) if m else line)
+    return out
+
+
+def _construct(golden_dir, d):
+    os.makedirs(d, exist_ok=True)
+    return subprocess.run([CLI, "construct", "-r", os.path.join(golden_dir, "x.fa"), "-v",
+                           os.path.join(golden_dir, "x.vcf"), "-p", d], capture_output=True, text=True)
+
+
+def test_construct_log_lines_match_the_readme(golden_dir, tmp_path):
+    out = _construct(golden_dir, str(tmp_path / "ser"))
+    assert out.returncode == 0, out.stderr
+    msgs = _msgs(out.stdout)
+    # reference README.md:51-62
+    assert "Num mutations: 75 num mutations-sample: 75" in msgs
+    assert "Chromosome: x #Vertices: 212 #Edges: 287 Seq length: 1074" in msgs
+    assert "Number of sample vector classes: 2" in msgs
+    assert msgs[0] == "Creating variant graph" and msgs[-1] == "Serializing index to disk"
+    assert all(LOG.match(l) for l in out.stdout.splitlines())
+    assert len(os.listdir(str(tmp_path / "ser"))) == 9
+
+
+def test_construct_requires_existing_directory(golden_dir, tmp_path):
+    out = subprocess.run([CLI, "construct", "-r", os.path.join(golden_dir, "x.fa"), "-v",
+                          os.path.join(golden_dir, "x.vcf"), "-p", str(tmp_path / "missing")],
+                         capture_output=True, text=True)
+    assert out.returncode != 0 and "does not seem to exist" in out.stderr
+
+
+@pytest.mark.gpu
+def test_query_type6_readme_example(golden_dir, survey_vectors, tmp_path):
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    ofile = str(tmp_path / "variant.txt")
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "6", "-r", "10:105", "-m", "0", "-s", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    # reference README.md:89-96
+    assert "Chromosome: x #Vertices: 212 #Edges: 0 Seq length: 1074" in msgs
+    assert "6. Get variants in ref coordinate. 0" in msgs
+    assert "Number of variants get_var_in_ref: 8" in msgs
+    assert re.match(r"Query1: \(query_var_in_ref\) Total Time Elapsed: \d+\.\d{6}seconds", msgs[-1])
+    assert open(ofile).read() == survey_vectors["G1"]["text"]
+
+
+@pytest.mark.gpu
+def test_query_batch_sorted_last_region_in_outfile_and_type4(golden_dir, survey_vectors, tmp_path):
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    ofile, bfile = str(tmp_path / "o.txt"), str(tmp_path / "b.txt")
+    # regions given unsorted: the driver sorts them (commands.cc:91); the -o file keeps only the last one
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "6", "-r", "1:1001,10:105,2000:2100", "-m", "1", "-o", ofile,
+                          "-v", "--batch-out", bfile], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    counts = [m for m in msgs if m.startswith("Number of variants")]
+    assert counts == ["Number of variants get_var_in_ref: 75", "Number of variants get_var_in_ref: 8",
+                      "Number of variants get_sample_var_in_ref: 0"]  # early-out prints the other label (query.h:746)
+    assert open(ofile).read() == "Pos\tRef\tAlt\tSamples\n"
+    assert "#region 1 10:105\n" + survey_vectors["G1"]["text"] in open(bfile).read()
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "4", "-r", "10:105", "-m", "1", "-s", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Number of variants get_sample_var_in_ref: 8" in _msgs(out.stdout)
+    assert open(ofile).read() == survey_vectors["G1_t4"]["text"]

@@ -146,3 +146,59 @@ def test_digest_properties(tmp_path):
     for q in (0, 17, 4999):
         single = vs.get_var_in_ref([regions[q]])
         assert single.region_text(0) == a.region_text(q)
+
+
+# ---------------------------------------------------------------- query type 4
+def _compare_t4(vs, orc, regions, sample):
+    res = vs.get_sample_var_in_ref(regions, sample)
+    view = res.view(with_carriers=False)
+    want = oracle_texts(orc, regions, sample=sample)
+    checked = 0
+    for q, (n, early, text) in enumerate(want):
+        if n < 0:
+            continue
+        assert res.region_text(q) == text, (q, regions[q], sample)
+        assert int(view["var_count"][q]) == n
+        assert bool(view["region_flags"][q] & 1) == early
+        checked += 1
+    res.close()
+    return checked
+
+
+@pytest.mark.parametrize("key", ["G1_t4", "G3_t4"])
+def test_golden_type4_on_gpu(key, golden_dir, survey_vectors, tmp_path):
+    g = survey_vectors[key]
+    vs, _ = _open_gpu(os.path.join(golden_dir, g["fasta"]), os.path.join(golden_dir, g["vcf"]), tmp_path)
+    res = vs.get_sample_var_in_ref([tuple(g["region"])], g["sample"])
+    assert res.region_text(0) == g["text"]
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (201, dict()),
+    (202, dict(sample_names=["S2", "S10", "S1", "b", "a", "Z", "m"])),
+    (203, dict(p_near=0.7, p_multi=0.3, n_rows=300, ref_len=3000)),
+    (204, dict(p_ins=0.3, p_del=0.3, n_rows=250)),
+    (205, dict(n_samples=70, carrier_p=0.4)),
+    (206, dict(n_samples=130, carrier_p=0.004, n_rows=200)),
+])
+def test_random_cohorts_type4_match_oracle(seed, kw, tmp_path):
+    fasta, vcf, names = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(seed)
+    regions = random_regions(rng, vs.info().ref_length, 150)
+    for sample in [names[0], names[-1], names[len(names) // 2]]:
+        assert _compare_t4(vs, orc, regions, sample) > 0
+
+
+def test_type4_synthetic_midsize(tmp_path):
+    vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6,
+                                af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(6)
+    starts = rng.integers(1, 1_990_000, size=400)
+    regions = [(int(s), int(s) + 5000) for s in starts]
+    for sample in ("S00001", "S00100", "S00200"):
+        assert _compare_t4(vs, orc, regions, sample) == 400

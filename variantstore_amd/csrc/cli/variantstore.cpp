@@ -1,0 +1,266 @@
+// variantstore -- drop-in command line for the query path, on top of the C ABI.
+//
+// Same sub-commands, flags, log lines and output files as the reference driver
+// (reference src/variantstore.cc:81-156 clipp grammar, src/commands.cc:33-60 construct_main,
+// :64-93 read_regions, :114-215 query_main, src/util.cc:67-80 print_time_elapsed; log lines in
+// spdlog's default pattern "[Y-m-d H:M:S.ms] [level] msg").  Query types 6 and 4 run on the GPU
+// through include/variantstore_hip.h; the other types are not part of this engine.
+//
+// Extensions for batches that do not fit a command line:
+//   -r @FILE            one "<start>:<end>" (or "<start>") per line instead of a comma list
+//   --batch-out FILE    rows of ALL regions ("#region <i> <x>:<y>" before each), since the
+//                       reference's -o file only ever holds the last region (query.h:774-781)
+//   --device N          GPU ordinal (default 0)
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "variantstore_hip.h"
+
+namespace {
+
+void log_line(const char* level, const std::string& msg) {
+  struct timeval tv;
+  gettimeofday(&tv, nullptr);
+  struct tm tm;
+  localtime_r(&tv.tv_sec, &tm);
+  char ts[64];
+  strftime(ts, sizeof(ts), "%Y-%m-%d %H:%M:%S", &tm);
+  printf("[%s.%03d] [%s] %s\n", ts, (int)(tv.tv_usec / 1000), level, msg.c_str());
+  fflush(stdout);
+}
+void info(const std::string& m) { log_line("info", m); }
+void error(const std::string& m) { log_line("error", m); }
+
+[[noreturn]] void die(int rc, const char* what) {
+  error(std::string(what) + ": " + vs_strerror(rc) + ": " + vs_last_error());
+  abort();
+}
+
+// std::stoi semantics of read_regions (commands.cc:64-93): throws std::invalid_argument on garbage
+uint64_t stoi_like(const std::string& s) { return (uint64_t)std::stoi(s); }
+
+std::vector<std::tuple<uint64_t, uint64_t>> read_regions(std::string region) {
+  std::vector<std::tuple<uint64_t, uint64_t>> regions;
+  if (!region.empty() && region[0] == '@') {
+    std::ifstream in(region.substr(1));
+    if (!in) throw std::runtime_error("cannot open region file " + region.substr(1));
+    std::string line;
+    while (std::getline(in, line)) {
+      if (line.empty()) continue;
+      auto p = line.find(':');
+      if (p == std::string::npos) regions.emplace_back(stoi_like(line), 0);
+      else regions.emplace_back(stoi_like(line.substr(0, p)), stoi_like(line.substr(p + 1)));
+    }
+  } else {
+    auto pos = region.find(',');
+    while (true) {
+      std::string token = region.substr(0, pos);
+      auto pos2 = token.find(':');
+      uint64_t beg = 0, end = 0;
+      if (pos2 == std::string::npos) beg = stoi_like(token);
+      else { end = stoi_like(token.substr(pos2 + 1)); beg = stoi_like(token.substr(0, pos2)); }
+      regions.emplace_back(beg, end);
+      if (pos == std::string::npos) break;
+      region = region.substr(pos + 1);
+      pos = region.find(',');
+    }
+  }
+  std::sort(regions.begin(), regions.end());
+  return regions;
+}
+
+void print_time_elapsed(const std::string& desc, const timeval& start, timeval end) {  // util.cc:67-80
+  if (start.tv_usec > end.tv_usec) { end.tv_usec += 1000000; end.tv_sec--; }
+  float t = ((end.tv_sec - start.tv_sec) * 1000000 + (end.tv_usec - start.tv_usec)) / 1000000.f;
+  std::cout << desc << "Total Time Elapsed: " << std::to_string(t) << "seconds" << std::endl;
+}
+
+bool dir_exists(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+struct Args {
+  std::string cmd, ref, vcf, prefix, region, outfile, sample, alt, refseq, batch_out;
+  uint32_t type = 0, mode = 0;
+  bool have_type = false, have_mode = false, verbose = false;
+  int device = 0;
+};
+
+int usage() {
+  std::cout << "SYNOPSIS\n"
+               "        variantstore construct -r <reference-file> -v <vcf-file> -p <output-prefix>\n"
+               "        variantstore query -p <output-prefix> -t <query-type> -r <region> -m <mode> [-o <outfile>]\n"
+               "                     [-s <sample-name>] [-a <alt-seq>] [-b <ref-seq>] [-v]\n"
+               "                     [--batch-out <file>] [--device <n>]\n"
+               "        variantstore help\n\n"
+               "OPTIONS\n"
+               "        <query-type>  4  Get sample's variants in reference coordinates.   (GPU)\n"
+               "                      6  Get variants in reference coordinates.            (GPU)\n"
+               "                      1,2,3,5,7 are not part of this engine.\n"
+               "        <region>      <start>:<end>, regions separated by ',', or @file with one region per line\n"
+               "        <mode>        READ_INDEX_ONLY: 0, READ_COMPLETE_GRAPH:1 (both fully resident here)\n";
+  return 0;
+}
+
+int construct_main(const Args& a) {
+  info("Creating variant graph");
+  vs_construct_stats st;
+  vs_index* idx = nullptr;
+  // stdout lines of the VariantGraph constructor (variant_graph.h:342-344, 625-626, 729-731, 1919)
+  int rc = vs_index_from_vcf(a.ref.c_str(), a.vcf.c_str(), -1, &st, &idx);
+  if (rc != VS_OK) die(rc, "construct");
+  if (st.use_bit_vector) info("Building sample vector based variant graph.");
+  vs_index_info inf;
+  vs_index_get_info(idx, &inf);
+  info("Adding mutations from: " + a.vcf + " #Samples: " + std::to_string(inf.num_samples - 1));
+  info("Num mutations: " + std::to_string(st.num_mutations) + " num mutations-sample: " + std::to_string(st.num_mutations_samples));
+  info("Num vars: " + std::to_string(st.num_vars));
+  info("Fixing sample indexes in the graph");
+  info("Graph stats:");
+  info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(st.num_vertices) +
+       " #Edges: " + std::to_string(st.num_edges) + " Seq length: " + std::to_string(st.seq_length));
+  info("Serializing variant graph to disk");
+  info("Number of sample vector classes: " + std::to_string(st.num_classes));
+  info("Creating Index");
+  info("Serializing index to disk");
+  rc = vs_index_save(idx, a.prefix.c_str());
+  if (rc != VS_OK) die(rc, "serialize");
+  vs_index_close(idx);
+  return EXIT_SUCCESS;
+}
+
+int query_main(const Args& a) {
+  info("Loading Index ...");
+  info("Loading variant graph ...");
+  info(a.mode == 0 ? "Read index only .." : "Read complete graph ..");
+  vs_index* idx = nullptr;
+  int rc = vs_index_open(a.prefix.c_str(), a.device, &idx);
+  if (rc != VS_OK) die(rc, "load");
+  vs_index_info inf;
+  vs_index_get_info(idx, &inf);
+  info("Graph stats:");
+  info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(inf.num_topology_keys + 1) +
+       " #Edges: 0 Seq length: " + std::to_string(inf.seq_length));
+
+  auto regions = read_regions(a.region);
+  struct timeval start, end;
+  gettimeofday(&start, nullptr);
+  if (a.type != 6 && a.type != 4) {
+    for (size_t i = 0; i < regions.size(); ++i) error("Unsupported query type");
+    error("query types other than 4 and 6 are not part of the GPU engine");
+    vs_index_close(idx);
+    return EXIT_FAILURE;
+  }
+  std::vector<vs_region> batch;
+  for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
+  vs_result* res = nullptr;
+  if (a.type == 6) rc = vs_query_var_in_ref(idx, batch.data(), batch.size(), &res);
+  else {
+    uint32_t sid = 0;
+    rc = vs_index_sample_id(idx, a.sample.c_str(), &sid);
+    if (rc != VS_OK) { error("Sample not found: " + a.sample); die(rc, "query"); }
+    rc = vs_query_sample_var_in_ref(idx, batch.data(), batch.size(), sid, &res);
+  }
+  if (rc != VS_OK) die(rc, "query");
+  vs_result_view v;
+  rc = vs_result_get_view(res, 0, &v);
+  if (rc != VS_OK) die(rc, "result");
+  gettimeofday(&end, nullptr);
+
+  std::ofstream batch_out;
+  if (!a.batch_out.empty()) batch_out.open(a.batch_out);
+  uint32_t query_num = 0;
+  for (uint64_t i = 0; i < v.n_regions; ++i) {
+    if (a.type == 6) info("6. Get variants in ref coordinate. " + std::to_string(i));
+    else info("4. Get sample's variants in ref coordinate. " + std::to_string(i));
+    if (v.region_flags[i] & VS_REGION_INVALID) {  // index.h:151-154
+      error("Can't find node corresponding to pos " + std::to_string(batch[i].x));
+      abort();
+    }
+    // query.h:746 prints the type-4 label on the early-out of type 6 as well
+    const char* label = (a.type == 6 && !(v.region_flags[i] & VS_REGION_EMPTY)) ? "get_var_in_ref" : "get_sample_var_in_ref";
+    std::cout << "Number of variants " << label << ": " << v.var_count[i] << '\n';
+    if (batch_out.is_open()) {
+      const char* text; uint64_t len;
+      if (vs_result_format_region(res, i, &text, &len) == VS_OK) {
+        batch_out << "#region " << i << " " << batch[i].x << ":" << batch[i].y << "\n";
+        batch_out.write(text, len);
+      }
+    }
+    if (a.verbose && i + 1 == v.n_regions) {  // the -o file is reopened (truncated) per region: the last one stays
+      const char* text; uint64_t len;
+      if (vs_result_format_region(res, i, &text, &len) == VS_OK) {
+        std::ofstream out;
+        out.open(a.outfile);
+        out.write(text, len);
+      }
+    }
+    query_num += 1;
+    if (query_num == 10 || query_num == 100 || query_num == 1000)
+      print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+  }
+  std::string dsc = "Query" + std::to_string(query_num) + ": ";
+  if (a.type == 6) dsc.append("(query_var_in_ref) ");
+  print_time_elapsed(dsc, start, end);
+  vs_result_free(res);
+  vs_index_close(idx);
+  return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args a;
+  if (argc < 2) return usage();
+  a.cmd = argv[1];
+  auto need = [&](int& i) -> std::string {
+    if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; exit(EXIT_FAILURE); }
+    return argv[++i];
+  };
+  for (int i = 2; i < argc; ++i) {
+    std::string f = argv[i];
+    if (a.cmd == "construct") {
+      if (f == "-r" || f == "--reference") a.ref = need(i);
+      else if (f == "-v" || f == "--vcf") a.vcf = need(i);
+      else if (f == "-p" || f == "--output-prefix") a.prefix = need(i);
+      else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
+    } else if (a.cmd == "query") {
+      if (f == "-p" || f == "--output-prefix") a.prefix = need(i);
+      else if (f == "-t" || f == "--type") { a.type = (uint32_t)atoi(need(i).c_str()); a.have_type = true; }
+      else if (f == "-r" || f == "--region") a.region = need(i);
+      else if (f == "-m" || f == "--mode") { a.mode = (uint32_t)atoi(need(i).c_str()); a.have_mode = true; }
+      else if (f == "-o" || f == "--output_file") a.outfile = need(i);
+      else if (f == "-s" || f == "--sample-name") a.sample = need(i);
+      else if (f == "-a" || f == "--alt-seq") a.alt = need(i);
+      else if (f == "-b" || f == "--ref-seq") a.refseq = need(i);
+      else if (f == "-v" || f == "--verbose") a.verbose = true;
+      else if (f == "--batch-out") a.batch_out = need(i);
+      else if (f == "--device") a.device = atoi(need(i).c_str());
+      else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
+    }
+  }
+  if (a.cmd == "construct") {
+    if (a.ref.empty() || a.vcf.empty() || a.prefix.empty()) return usage();
+    if (!dir_exists(a.prefix)) {
+      std::cerr << "The required input directory " << a.prefix << " does not seem to exist.\n";
+      return EXIT_FAILURE;
+    }
+    return construct_main(a);
+  }
+  if (a.cmd == "query") {
+    if (a.prefix.empty() || !a.have_type || a.region.empty() || !a.have_mode) return usage();
+    return query_main(a);
+  }
+  return usage();
+}

@@ -263,7 +263,9 @@ static int ralloc(vs_result* r, size_t n, T** p) {
   return VS_OK;
 }
 
-static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
+// sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk)
+static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone) {
+  const bool t4 = sample_id != kNone;
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -281,7 +283,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   std::vector<DevBuf> scratch;
   if (n) {
-    hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
+    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
@@ -308,8 +311,11 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.S, &d.carriers));
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-    hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
+    else {
+      hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+    }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
@@ -482,6 +488,8 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   info->use_bit_vector = idx->g.use_bit_vector;
   info->device_bytes = idx->device_bytes;
   info->device = idx->device;
+  info->num_topology_keys = 0;
+  for (uint32_t v : idx->g.topo_val) info->num_topology_keys += v != 0;
   return VS_OK;
 }
 
@@ -546,8 +554,17 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
 }
 
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id, vs_result** out) {
-  (void)idx; (void)regions; (void)n; (void)sample_id; (void)out;
-  return fail(VS_ERR_UNSUPPORTED, "query type 4 is not built yet");
+  if (!idx || !out || (n && !regions)) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  if (sample_id >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_id, idx->g.num_samples);
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  int rc = run_var_in_ref(idx, regions, n, r, sample_id);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
 }
 
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out) {

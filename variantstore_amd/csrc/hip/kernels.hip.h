@@ -653,6 +653,118 @@ __global__ void __launch_bounds__(256) k_pack_headers(DevResult r, uint64_t* dst
   dst[4 * a + 3] = (region_base + r.r_region[a]) | ((uint64_t)r.r_car_count[a] << 32);
 }
 
+// ---------------------------------------------------------------------------
+// Query type 4: get_sample_var_in_ref (query.h:618-729) with its start search
+// get_prev_vertex_with_sample (query.h:57-113).  One thread per region walks the
+// sample's path literally (get_neighbor_vertex, variant_graph.h:1402-1451) over the
+// CSR + vertex table; EMIT=false counts, EMIT=true writes variant headers.  The
+// carriers of each reported vertex are expanded afterwards by k_fill_carriers.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v, uint32_t sid) {
+  if (im.use_bv) return (im.class_rows[(uint64_t)im.v_class[v] * im.wpc + (sid >> 6)] >> (sid & 63)) & 1;
+  if (sid == 0) return im.v_ridx[v] != 0;
+  const uint64_t b = im.v_car_begin[v];
+  for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
+    if (im.car_sid[b + i] == sid) return true;
+  return false;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  uint8_t fl = 0;
+  uint64_t nvar = 0, ncar = 0;
+  if (x < 1) fl = kRegionInvalid;
+  else {
+    bool empty = false;  // Index::is_empty, index.h:150-166
+    if (x > im.ref_length) empty = true;
+    else {
+      const uint32_t rx = rank1(im, x);
+      if (rx >= im.R) empty = true;
+      else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
+    }
+    if (empty) fl = kRegionEmpty;
+    else {
+      // ---- get_prev_vertex_with_sample ----
+      uint64_t rank = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;  // find(pos, rank)
+      uint64_t ref_pos = 1;
+      uint32_t start_v = 0;
+      while (true) {
+        const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
+        if (rank <= 1) { ref_pos = 1; start_v = v; break; }
+        bool found = false;
+        for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) {
+          const uint32_t n = im.col[e];
+          if (im.v_ridx[n]) ref_pos = im.v_ridx[n];
+          if (vertex_has_sample(im, n, sid)) { start_v = n; found = true; }
+          rank = rank ? rank - 1 : 0;  // the reference's unsigned counter would wrap here: clamped
+        }
+        if (found) break;
+      }
+      // ---- walk the sample's path ----
+      uint32_t cur = start_v;
+      uint32_t cur_ref_off = 0, cur_ref_len = 0;  // cur_ref: sequence of the last ref neighbour of the previous vertex
+      bool done = false;
+      const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
+      const uint64_t cb = EMIT ? r.car_base[q] : 0;
+      while (!done) {
+        if (ref_pos >= y) break;
+        uint64_t next_ref_pos = ref_pos + im.v_len[cur];
+        uint32_t next_ref_off = 0, next_ref_len = 0;
+        uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+        bool nxt_by_sample = false;
+        for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
+          const uint32_t n = im.col[e];
+          const uint32_t nr = im.v_ridx[n];
+          if (nr) { next_ref_pos = nr; next_ref_off = im.v_off[n]; next_ref_len = im.v_len[n]; }  // last ref neighbour wins
+          if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
+            if (sid != 0 && vertex_has_sample(im, n, sid)) { nxt = n; nxt_by_sample = true; }
+            else if (nr && min_idx > nr) { nxt = n; min_idx = nr; }
+          }
+        }
+        if (ref_pos >= x && vertex_has_sample(im, cur, sid)) {
+          uint64_t pos;
+          uint32_t ro, rl, ao, al;
+          bool ok = true;
+          if (ref_pos == next_ref_pos) {  // insertion
+            pos = ref_pos - 1; ro = 0; rl = 0; ao = im.v_off[cur]; al = im.v_len[cur];
+          } else if (im.v_ridx[cur]) {   // deletion: ref = sequence of find(ref_pos - 1)
+            const uint64_t p = ref_pos - 1;
+            uint32_t fv;
+            if (p < 1) { ok = false; fv = 0; }
+            else {
+              const uint64_t rf = (p >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, p) - 1;
+              fv = im.rp_vid[im.rank_to_slot[rf]];
+            }
+            pos = im.v_ridx[fv]; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
+          } else {                        // substitution
+            pos = ref_pos; ro = cur_ref_off; rl = cur_ref_len; ao = im.v_off[cur]; al = im.v_len[cur];
+          }
+          if (ok) {
+            const uint32_t c = im.v_ncar[cur];
+            if (EMIT) {
+              const uint64_t a = a0 + nvar;
+              r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
+              r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
+              r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+              r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+            }
+            nvar++; ncar += c;
+          }
+        }
+        cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
+        ref_pos = next_ref_pos;
+        if (nxt == 0) done = true;  // no neighbour: the path iterator is done
+        cur = nxt;
+      }
+    }
+  }
+  if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
+  else r.var_count[q] = nvar;
+}
+
 // Index::find batched (index.h:119-133)
 __global__ void __launch_bounds__(256) k_find(DevImage im, const uint64_t* pos, uint64_t n, uint32_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
