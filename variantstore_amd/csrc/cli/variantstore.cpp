@@ -150,7 +150,7 @@ int query_main(const Args& a) {
   vs_index_info inf;
   vs_index_get_info(idx, &inf);
   info("Graph stats:");
-  info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(inf.num_topology_keys + 1) +
+  info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(inf.num_topology_keys) +
        " #Edges: 0 Seq length: " + std::to_string(inf.seq_length));
 
   auto regions = read_regions(a.region);
