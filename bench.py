@@ -180,6 +180,14 @@ def main():
     achieved = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
     achieved_layout = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
     res.close()
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+    # (counters cannot be read from inside the run); the committed measurement is attached when it is for
+    # this workload, otherwise the field stays null.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(tpath) and nreg == w["regions"]:
+        with open(tpath) as tf:
+            traffic = json.load(tf).get("traffic_bytes_per_launch")
 
     # ---- p50 single-region latency (submit -> result resident), outside the timed region ----
     lat = []
@@ -217,7 +225,7 @@ def main():
                           "hbm_image_bytes": info.device_bytes, "build_s": round(t_build, 1)},
             },
             "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_launch": fill_bytes_survey, "avg_launch_ms": fill_ms / args.steps,
                          "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": fill_bytes_layout,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
