@@ -202,3 +202,23 @@ def test_type4_synthetic_midsize(tmp_path):
     regions = [(int(s), int(s) + 5000) for s in starts]
     for sample in ("S00001", "S00100", "S00200"):
         assert _compare_t4(vs, orc, regions, sample) == 400
+
+
+def test_wide_cohort_dense_variants(tmp_path):
+    """1500 samples with common alleles: variants with hundreds to > 1000 carriers drive the
+    wave-per-variant regimes of k_fill_carriers (medium and dense), checked text-exact."""
+    vs = VariantStore.synthetic(device=0, ref_length=400_000, num_variants=3000, num_samples=1500, seed=77,
+                                first_pos=200, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=4,
+                                af_exponent=3.5)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(8)
+    starts = rng.integers(1, 395_000, size=120)
+    regions = [(int(s), int(s) + 3000) for s in starts]
+    res = vs.get_var_in_ref(regions)
+    cc = res.view(False)["car_count"]
+    assert (cc > 640).sum() > 50 and ((cc > 32) & (cc <= 640)).sum() > 50 and (cc <= 32).sum() > 50
+    n = _compare_t6(vs, orc, regions)
+    assert n == len(regions)
+    assert _compare_t4(vs, orc, regions[:40], "S00750") == 40
