@@ -199,6 +199,26 @@ def main():
         r1.close()
     p50 = float(np.median(lat)) * 1e6 if lat else None
 
+    # ---- query type 4 on the same index (BASELINE.json configs[2] names types 4+6): 16 fixed samples,
+    #      one sub-batch each, outside the timed region of the headline metric ----
+    t4 = None
+    if os.environ.get("VS_BENCH_SKIP_T4") != "1":
+        names = [vs.sample_name(1 + (i * 157) % (info.num_samples - 1)) for i in range(16)]
+        per = max(1, nreg // 16)
+        r4 = vs.get_sample_var_in_ref(regions[:per], names[0])  # warm-up
+        r4.close()
+        torch.cuda.synchronize()
+        a4 = time.perf_counter()
+        nv4 = 0
+        for i, nm in enumerate(names):
+            r4 = vs.get_sample_var_in_ref(regions[i * per:(i + 1) * per], nm)
+            if i == 0:
+                nv4 = r4.totals()[1]
+            r4.close()
+        torch.cuda.synchronize()
+        t4 = {"queries_per_s": 16 * per / (time.perf_counter() - a4), "regions": 16 * per, "samples": 16,
+              "variants_per_region_first_sample": nv4 / per}
+
     if rank == 0:
         out = {
             "metric": "region-queries/sec (batch, query-type 6)",
@@ -231,6 +251,7 @@ def main():
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
                          "pipeline_ms": tot_ms / args.steps},
             "p50_latency_us": p50,
+            "type4": t4,
             "result_digest": f"{digest:016x}",
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -222,3 +222,20 @@ def test_wide_cohort_dense_variants(tmp_path):
     n = _compare_t6(vs, orc, regions)
     assert n == len(regions)
     assert _compare_t4(vs, orc, regions[:40], "S00750") == 40
+
+
+def test_cohort_wider_than_one_wave_of_row_words(tmp_path):
+    """4500 samples: class rows of 71 words (> 64) take the generic expansion path."""
+    vs = VariantStore.synthetic(device=0, ref_length=60_000, num_variants=400, num_samples=4500, seed=78,
+                                first_pos=200, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=4,
+                                af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(9)
+    starts = rng.integers(1, 57_000, size=40)
+    regions = [(int(s), int(s) + 2500) for s in starts]
+    cc = vs.get_var_in_ref(regions).view(False)["car_count"]
+    assert (cc > 32).sum() > 20 and cc.max() > 1000
+    assert _compare_t6(vs, orc, regions) == len(regions)
+    assert _compare_t4(vs, orc, regions[:10], "S02250") == 10
