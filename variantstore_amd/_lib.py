@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvariantstore_hip.so")
+LIB_PATH = os.environ.get("VS_ENGINE_LIB") or os.path.join(_HERE, "lib", "libvariantstore_hip.so")  # override: A/B builds
 
 
 class Region(C.Structure):

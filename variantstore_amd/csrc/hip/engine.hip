@@ -328,7 +328,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint64_t nchunks = (d.A + 63) / 64;
       uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
       static const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;
-      hipLaunchKernelGGL(k_fill_carriers, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
+      if (idx->d.wpc <= 63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
     }
     HIP_TRY(hipGetLastError());
   }

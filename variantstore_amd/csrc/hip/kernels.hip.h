@@ -464,6 +464,10 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 }
 
 // `ablate` is a profiling aid (bit0: skip sparse, bit1: skip medium, bit2: skip dense); 0 in production.
+// WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
+// fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
+// one wave of occupancy -- is compiled out.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -575,7 +579,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
       }
       uint32_t* out = carriers + cb_t;
-      if (!staged || wpc > 64) {
+      if (WIDE && (!staged || wpc > 64)) {
         // rows wider than one wave or more than 4096 staged genotypes: generic path
         expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, out, lane);
         word_cur = word_next;
