@@ -328,10 +328,14 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint64_t nchunks = (d.A + 63) / 64;
       uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
       static const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;
+      // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
+      uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
+      if (gt_words < 448) gt_words = 448;   // the medium path keeps 640 ids at word 256..
+      const size_t lds_bytes = 4 * (size_t)(gt_words + kRingWords) * 4;
       if (idx->d.wpc <= 63)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d, ablate);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
     }
     HIP_TRY(hipGetLastError());
   }

@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers_v1(DevImage im, DevResult
 //          is requested before the current one is expanded.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 32;
-constexpr uint32_t kLdsWordsPerWave = 1024 + 256;  // per wave: 4 KiB genotype bytes (one per carrier) + 1 KiB output ring
+constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
+// per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
 constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
 constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
 
@@ -468,7 +469,7 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
 // one wave of occupancy -- is compiled out.
 template <bool WIDE>
-__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate) {
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -477,7 +478,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
   uint32_t* __restrict__ carriers = r.carriers;
-  __shared__ uint32_t lds_blk[4 * kLdsWordsPerWave];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = gt_words + kRingWords;
 
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t a = (chunk << 6) + lane;
@@ -534,9 +536,9 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
     // Per-wave LDS block (4 KiB): one genotype BYTE per carrier (unpacked from the nibble
     // pool while staging, so the expansion loops read it with a single ds_read_u8);
     // the medium-density path also keeps its id list in the upper part of the block.
-    uint8_t* gt_lds = reinterpret_cast<uint8_t*>(&lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave]);
-    uint32_t* ids_lds = &lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave + kMidIdsAt];
-    uint32_t* ring = &lds_blk[(threadIdx.x >> 6) * kLdsWordsPerWave + 1024];
+    uint8_t* gt_lds = reinterpret_cast<uint8_t*>(&lds_blk[(threadIdx.x >> 6) * lds_words_per_wave]);
+    uint32_t* ids_lds = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + kMidIdsAt];
+    uint32_t* ring = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + gt_words];
     int t = __builtin_ctzll(dmask);
     uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
     uint64_t gt0_t = wave_bcast64(gt0, t);
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       const uint64_t cb_t = wave_bcast64(cb, t);
       const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
       const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
-      const bool staged = (uint64_t)nshift + cnt_t <= 4096;             // fits the 4 KiB block
+      const bool staged = (uint64_t)nshift + cnt_t <= gt_words * 4;     // fits the staging block
       // stage this variant's genotypes (fetched during the previous variant), one byte per carrier
       stage_unpacked(gt_lds + lane * 32, nq0);
       if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
@@ -613,31 +615,47 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         for (uint32_t pos = lane; pos < endpos; pos += 64)
           if (pos >= a0) gbase[pos] = ids_lds[pos - a0] | ((uint32_t)gt_lds[nshift + pos - a0] << 29);
       } else {
-        // ---- dense: bit per lane; carriers go through a 256-entry LDS ring and leave as
-        //      full-wave stores on 256-byte-aligned blocks of the arena (partial, unaligned
-        //      stores run at less than half the write bandwidth of aligned full ones) ----
-        uint32_t base = nshift;                    // staged genotype index of the word's first carrier
-        const uint32_t delta = a0 - nshift;        // arena block position = staged index + delta (mod 2^32)
-        uint32_t nfl = 0;                          // aligned blocks already written
-        uint32_t idv = lane;
-        for (uint32_t w = 0; w < wpc; ++w, idv += 64) {
-          const uint64_t word = wave_bcast64(mine, w);
-          const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
-          if (__builtin_amdgcn_inverse_ballot_w64(word)) {  // lane i is active iff bit i of the word is set
-            const uint32_t ni = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
-            ring[ni & 255u] = idv | ((uint32_t)gt_lds[ni] << 29);
+        // ---- dense: bit per lane, two row words per step.  The lanes whose bit is set (exec mask =
+        //      the word itself) rank themselves with v_mbcnt and drop id|gt into a 512-entry LDS ring
+        //      indexed by arena position; the ring leaves 1 KiB at a time as one 16-byte store per lane
+        //      on a 1 KiB-aligned arena block (aligned full stores run at twice the rate of partial ones,
+        //      tools/microbench/write_bw.hip) ----
+        const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
+        uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+        const uint32_t end1k = a1k + cnt_t;
+        const uint32_t gtoff = nshift - a1k;                // staged genotype index = arena position + gtoff
+        uint32_t bpos = a1k;                                // arena position of the step's first carrier
+        uint32_t nfl = 0;                                   // 256-entry blocks already written
+        for (uint32_t w = 0; w < wpc; w += 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const uint64_t word = (w + i < wpc) ? wave_bcast64(mine, w + i) : 0ULL;
+            if (__builtin_amdgcn_inverse_ballot_w64(word)) {
+              const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, bpos));
+              ring[pos & 511u] = ((w + i) * 64 + lane) | ((uint32_t)gt_lds[pos + gtoff] << 29);
+            }
+            bpos += __popcll(word);
           }
-          base += __popcll(word);
-          const uint32_t full = (base + delta) >> 6;   // complete aligned blocks so far
-          while (nfl < full) {
-            const uint32_t pos = nfl * 64 + lane;
-            if (pos >= a0) gbase[pos] = ring[(pos - delta) & 255u];
+          while (nfl < (bpos >> 8)) {                        // a complete 256-entry block is ready
+            const uint32_t p4 = nfl * 256 + lane * 4;
+            const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+            if (p4 >= a1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+            else if (p4 + 4 > a1k) {                         // the variant starts inside this lane's quad
+              const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (p4 + j >= a1k) g1k[p4 + j] = e[j];
+            }
             ++nfl;
           }
         }
-        if (nfl * 64 < endpos) {                      // tail block
-          const uint32_t pos = nfl * 64 + lane;
-          if (pos >= a0 && pos < endpos) gbase[pos] = ring[(pos - delta) & 255u];
+        for (uint32_t p4 = nfl * 256 + lane * 4; p4 < end1k; p4 += 256) {   // tail (at most 2 passes)
+          const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+          if (p4 >= a1k && p4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+          else {
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (p4 + j >= a1k && p4 + j < end1k) g1k[p4 + j] = e[j];
+          }
         }
       }
       word_cur = word_next;
