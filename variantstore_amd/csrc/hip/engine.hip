@@ -282,17 +282,26 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   std::vector<DevBuf> scratch;
-  if (n) {
-    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
-    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+  uint64_t totals[3] = {0, 0, 1};
+  const bool small = !t4 && n > 0 && n <= 512;   // latency path: one launch for bounds + scans
+  if (small) {
+    uint64_t* dtot = nullptr;
+    VS_TRY(ralloc(r, 3, &dtot));
+    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(totals, dtot, 24, hipMemcpyDeviceToHost, idx->stream));
+  } else {
+    if (n) {
+      if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
+      else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
+    HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
   }
-  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
-  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
-  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
-  uint64_t totals[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-  HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   d.A = totals[0];
   d.S = totals[1];
@@ -309,16 +318,16 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_class));
   VS_TRY(ralloc(r, d.A, &d.r_gt0));
   VS_TRY(ralloc(r, d.S, &d.carriers));
-  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  if (!small) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
     if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-      hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+      if (totals[2]) hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
     }
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  if (!small) HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (d.A) {
     static const int fill_variant = getenv("VS_FILL_V1") ? 1 : 2;
     if (fill_variant == 1) {
@@ -344,10 +353,13 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   release_bufs(idx, scratch);
   vs_timing& t = idx->timing;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
+  if (!small) {  // the latency path records only the end-to-end pair
+    HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  }
   t.fill_launches = d.A ? 1 : 0;
   return VS_OK;
 }

@@ -160,9 +160,7 @@ __global__ void __launch_bounds__(256) k_mark_dups(DevImage im) {
 // ---------------------------------------------------------------------------
 // Region bounds: one thread per region.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= r.Q) return;
+__device__ __forceinline__ void region_bounds(const DevImage& im, const DevResult& r, uint64_t q) {
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   uint8_t fl = 0;
   uint32_t g0 = 0, g1 = 0;
@@ -202,6 +200,28 @@ __global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r)
   r.q_g0[q] = g0;
   r.q_nvar[q] = g1 - g0;
   r.q_ncar[q] = im.s_carpre[g1] - im.s_carpre[g0];
+}
+
+__global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < r.Q) region_bounds(im, r, q);
+}
+
+// Small batches (latency path): bounds of every region and both offset scans in ONE single-block
+// launch.  totals = {slots, carriers, any region needing the literal dedup rule}.
+__global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResult r, uint64_t* totals) {
+  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t a = 0, c = 0, slow = 0;
+    for (uint64_t q = 0; q < r.Q; ++q) {
+      r.var_begin[q] = a; r.car_base[q] = c;
+      a += r.q_nvar[q]; c += r.q_ncar[q];
+      slow |= (r.q_flags[q] & kRegionSlow) ? 1 : 0;
+    }
+    r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
+    totals[0] = a; totals[1] = c; totals[2] = slow;
+  }
 }
 
 // ---------------------------------------------------------------------------
