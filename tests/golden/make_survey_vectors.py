@@ -56,6 +56,9 @@ vectors = {
         "aux_on_disk": [[3, 1], [8, 7, 6, 4], [10, 9], [12, 11], [14, 13], [16, 15], [18, 17]],
         "find": {"1": 0, "9": 1, "10": 2, "11": 5, "26": 9, "27": 11, "39": 13, "40": 14, "41": 15, "42": 16,
                  "55": 17, "56": 18},
+        # sample-coordinate index of every non-ref s_info entry, as listed in the same dump ("1:9:1|0" ...)
+        "carrier_index": {"3": [9], "6": [10], "7": [10], "8": [10], "10": [26], "12": [28], "14": [41], "16": [42],
+                          "18": [55]},
         "sampleid_map_x": "x 1001\nx 2\n1 1\nref 0\n"},
 }
 

@@ -76,3 +76,19 @@ def test_x_small_graph_dump(golden_dir, survey_vectors, tmp_path):
         assert vs.out_neighbors(int(v)) == out, v
     for pos, v in g["find"].items():
         assert orc.find(int(pos)) == v
+
+
+def test_x_small_sample_indexes(golden_dir, survey_vectors, tmp_path):
+    """fix_sample_indexes (variant_graph.h:1883-1997): per-carrier sample-coordinate indexes of the dump."""
+    from helpers import read_plain
+    g = survey_vectors["x_small_graph"]
+    vs, _ = _open(golden_dir, g["fasta"], g["vcf"], tmp_path)
+    plain = os.path.join(tmp_path, "idx.plain")
+    vs.export_plain(plain)
+    pg = read_plain(plain)
+    got = {}
+    for v in range(len(pg["off"])):
+        cs = [int(pg["car_index"][c]) for c in range(int(pg["car_begin"][v]), int(pg["car_begin"][v + 1]))]
+        if cs:
+            got[str(v)] = cs
+    assert got == g["carrier_index"]

@@ -226,7 +226,9 @@ class GraphBuilder {
   }
 
   // Flatten into the persisted form and build the position index.
-  void finish(HostGraph& g) {
+  // with_sample_indexes: run fix_sample_indexes (per-carrier sample-coordinate indexes, only read by
+  // query types 2/3/5; 4 bytes per carrier record)
+  void finish(HostGraph& g, bool with_sample_indexes = true) {
     g.chr = chr_;
     g.ref_length = ref_length_;
     g.num_samples = num_samples_;
@@ -253,6 +255,7 @@ class GraphBuilder {
     g.topo_inplace.resize(V, 0); g.topo_val.resize(V, 0);
     g.aux_lists.clear();
     for (auto& s : aux_) g.aux_lists.emplace_back(s.order());  // serialize iterates the sets (graph.h:199-203)
+    if (with_sample_indexes) fix_sample_indexes(g);
     build_index(g);
   }
 
@@ -413,6 +416,84 @@ class GraphBuilder {
   void split_vertex2(uint32_t vertex_id, uint64_t pos1, uint64_t pos2, uint32_t* n1, uint32_t* n2) {  // :1158-1167
     split_vertex(vertex_id, pos1, n1);
     split_vertex(*n1, pos2 - pos1 + 1, n2);
+  }
+
+  // ---- fix_sample_indexes, variant_graph.h:1883-1997 (the "optimized solution") ----
+  // One breadth-first pass over the whole graph in Graph::GraphIterator order (graph.h:394-459, with
+  // its "shared neighbour first" reordering) carrying a per-sample offset between sample and ref
+  // coordinates; uses the construct-time neighbour order, as the reference does.
+  void fix_sample_indexes(HostGraph& g) const {
+    const uint64_t V = off_.size();
+    g.car_index.assign(g.car_flags.size(), 0);
+    std::vector<int32_t> delta(num_samples_, 0);
+    std::vector<uint8_t> visited(V, 0);
+    std::vector<std::pair<uint32_t, uint64_t>> q;  // FIFO via head index
+    size_t head = 0;
+    std::vector<uint32_t> nb, nb2, ids, a, b;
+    auto process = [&](uint32_t cur) {
+      out_neighbors(cur, nb);
+      if (ref_index_[cur] != 0) {
+        const uint32_t ref_index = ref_index_[cur];
+        for (uint32_t n : nb) {
+          carrier_ids(n, ids);
+          for (size_t i = 0; i < ids.size(); ++i) {
+            uint32_t& idx = g.car_index[g.car_begin[n] + i];
+            if (idx == 0) {
+              const int32_t si = (int32_t)(ref_index + len_[cur] + (uint32_t)delta[ids[i]]);
+              if (si < 0) throw std::runtime_error("Sample index is less than 0");
+              idx = (uint32_t)si;
+            } else {
+              delta[ids[i]] = (int32_t)(idx - (ref_index + len_[cur]));
+            }
+          }
+        }
+      } else {
+        if (nb.size() > 1) throw std::runtime_error("Sample vertex has more than 1 neighbor");
+        for (uint32_t n : nb) {
+          if (ref_index_[n] == 0) throw std::runtime_error("Ref vertex not found as a neighbor from sample vertex");
+          carrier_ids(cur, ids);
+          for (size_t i = 0; i < ids.size(); ++i)
+            delta[ids[i]] = (int32_t)(g.car_index[g.car_begin[cur] + i] + len_[cur] - ref_index_[n]);
+        }
+      }
+    };
+    visited[0] = 1;
+    out_neighbors(0, nb);
+    for (uint32_t n : nb) q.emplace_back(n, 1);
+    process(0);
+    while (true) {
+      uint32_t cur = 0;
+      bool found = false;
+      while (head < q.size()) {
+        cur = q[head].first;
+        if (!visited[cur]) { visited[cur] = 1; found = true; break; }
+        ++head;
+      }
+      if (!found) break;
+      const uint64_t hop = q[head].second;
+      ++head;
+      std::vector<uint32_t> ordered;
+      out_neighbors(cur, nb2);
+      a = nb2;
+      std::sort(a.begin(), a.end());
+      for (uint32_t v : nb2) {
+        out_neighbors(v, b);
+        std::sort(b.begin(), b.end());
+        bool inter = false;
+        for (size_t i = 0, j = 0; i < a.size() && j < b.size();) {
+          if (a[i] == b[j]) { inter = true; break; }
+          if (a[i] < b[j]) ++i; else ++j;
+        }
+        if (inter) ordered.insert(ordered.begin(), v);
+        else ordered.push_back(v);
+      }
+      for (uint32_t v : ordered) q.emplace_back(v, hop + 1);
+      process(cur);
+      if (head > (1u << 20) && head * 2 > q.size()) {  // drop the consumed prefix
+        q.erase(q.begin(), q.begin() + head);
+        head = 0;
+      }
+    }
   }
 
   // ---- Index(const VariantGraph*) index.h:53-106 ----

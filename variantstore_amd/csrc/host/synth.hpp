@@ -11,6 +11,7 @@
 // Sample names are zero padded (S00001...) so name order equals column order.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -217,7 +218,9 @@ inline SynthStats construct_synthetic(const SynthParams& p, HostGraph& out, uint
   if (n_keys) *n_keys = b.num_keys();
   if (n_edges) *n_edges = b.num_edges();
   if (seq_len) *seq_len = b.seq_length();
-  b.finish(out);
+  // per-carrier sample-coordinate indexes cost 4 bytes per carrier record and are not read by the
+  // query types this engine runs; off unless asked for
+  b.finish(out, getenv("VS_SYNTH_SAMPLE_INDEXES") != nullptr);
   return st;
 }
 
