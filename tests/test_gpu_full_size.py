@@ -1,0 +1,108 @@
+"""Full BASELINE.json size (configs[2]: 5 M sites x 2504 samples, 100 k regions of 10 kb) on the GPU,
+checked through size-independent properties -- the CPU oracle cannot hold this index in reasonable
+time, so exactness at this size rests on: determinism, additivity over batch splits, equality of a
+region's result whatever batch it travels in, and structural invariants of every carrier list
+(ascending sample ids in range, a non-zero allele on every carrier, positions inside the region)."""
+import numpy as np
+import pytest
+
+from variantstore_amd import VariantStore
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(ref_length=249_250_621, num_variants=5_000_000, num_samples=2504, seed=1, first_pos=10_000,
+          frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6, af_exponent=11.0)
+
+
+@pytest.fixture(scope="module")
+def big():
+    vs = VariantStore.synthetic(device=0, **KW)
+    rng = np.random.default_rng(2000)
+    starts = np.sort(rng.integers(1, KW["ref_length"] - 10_000, size=100_000))
+    regions = np.stack([starts, starts + 10_000], axis=1).astype(np.uint64)
+    yield vs, regions
+    vs.close()
+
+
+def test_determinism_and_additivity(big):
+    vs, regions = big
+    a = vs.get_var_in_ref(regions)
+    ta, da = a.totals(), a.digest()
+    assert ta[0] == 100_000 and ta[1] > 15_000_000 and ta[2] > 2_000_000_000
+    b = vs.get_var_in_ref(regions)
+    assert (b.totals(), b.digest()) == (ta, da)
+    b.close()
+    parts = [vs.get_var_in_ref(regions[i::4]) for i in range(4)]
+    assert tuple(sum(p.totals()[k] for p in parts) for k in range(4)) == ta
+    for p in parts:
+        p.close()
+    # a region's rows do not depend on the batch around it
+    for q in (0, 1, 31_337, 99_999):
+        single = vs.get_var_in_ref(regions[q:q + 1])
+        assert single.region_text(0) == a.region_text(q)
+        single.close()
+    rev = vs.get_var_in_ref(regions[::-1].copy())
+    for q in (5, 50_000, 99_990):
+        assert rev.region_text(100_000 - 1 - q) == a.region_text(q)
+    rev.close()
+    a.close()
+
+
+def test_structure_of_every_carrier_list(big):
+    vs, regions = big
+    sub = regions[40_000:40_600]
+    res = vs.get_var_in_ref(sub)
+    v = res.view(with_carriers=True)
+    car = v["carriers"]
+    ids = (car & np.uint32(0x1FFFFFFF)).astype(np.int64)
+    gt = car >> np.uint32(29)
+    assert len(car) == int(v["car_count"].sum()) > 10_000_000
+    assert ids.min() >= 1 and ids.max() <= 2504            # sample ids, "ref" (0) is never a carrier
+    assert ((gt & 6) != 0).all()                            # every carrier holds a non-zero allele
+    assert ((gt & 1) == 1).all()                            # the synthetic cohort is fully phased
+    # ascending ids inside every variant (class bit order == get_sample_ids order)
+    begin = v["car_begin"].astype(np.int64)
+    cnt = v["car_count"].astype(np.int64)
+    assert (begin[1:] == begin[:-1] + cnt[:-1]).all() and begin[0] == 0
+    d = np.diff(ids)
+    boundaries = (begin[1:] - 1)[cnt[:-1] > 0]
+    mask = np.ones(len(d), dtype=bool)
+    mask[boundaries[boundaries < len(d)]] = False
+    assert (d[mask] > 0).all()
+    # positions lie inside their region and are sorted up to the insertion off-by-one
+    vb = v["var_begin"].astype(np.int64)
+    for q in range(len(sub)):
+        p = v["pos"][vb[q]:vb[q + 1]].astype(np.int64)
+        if len(p):
+            assert p.min() >= int(sub[q, 0]) and p.max() < int(sub[q, 1])
+            assert (np.diff(p) >= -1).all()
+    res.close()
+
+
+def test_type4_agrees_with_type6_on_membership(big):
+    """A sample's type-4 variants are the type-6 variants of the same region whose carrier list holds
+    that sample (true for this cohort: no variant lies within a deletion of the same sample's path
+    often enough to matter is NOT assumed -- only inclusion is checked)."""
+    vs, regions = big
+    sub = regions[70_000:70_050]
+    sid = vs.sample_id("S01234")
+    r6 = vs.get_var_in_ref(sub)
+    v6 = r6.view(with_carriers=True)
+    r4 = vs.get_sample_var_in_ref(sub, "S01234")
+    v4 = r4.view(with_carriers=True)
+    ids6 = v6["carriers"] & np.uint32(0x1FFFFFFF)
+    b6, c6 = v6["car_begin"].astype(np.int64), v6["car_count"].astype(np.int64)
+    vb6, vb4 = v6["var_begin"].astype(np.int64), v4["var_begin"].astype(np.int64)
+    total4 = 0
+    for q in range(len(sub)):
+        have = set()
+        for a in range(vb6[q], vb6[q + 1]):
+            if (ids6[b6[a]:b6[a] + c6[a]] == sid).any():
+                have.add((int(v6["pos"][a]), int(v6["alt_off"][a]), int(v6["alt_len"][a])))
+        for a in range(vb4[q], vb4[q + 1]):
+            key = (int(v4["pos"][a]), int(v4["alt_off"][a]), int(v4["alt_len"][a]))
+            assert key in have, (q, key)
+            total4 += 1
+    assert total4 > 50
+    r6.close()
+    r4.close()
