@@ -130,7 +130,7 @@ def main():
         res = vs.get_var_in_ref(regions)
         gathered = None
         if use_dist:
-            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank))
+            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True)
         return res, gathered
 
     def fence():
@@ -239,7 +239,7 @@ def main():
                             "query type 6 (get_var_in_ref), index + regions resident in HBM, results left in HBM",
                 "regions_per_gpu": nreg, "region_len": w["region_len"],
                 "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
-                "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists" if use_dist else ""),
+                "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,
                           "hbm_image_bytes": info.device_bytes, "build_s": round(t_build, 1)},

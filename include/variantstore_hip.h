@@ -152,6 +152,13 @@ int vs_result_digest(vs_result* r, uint64_t* digest);
  * device_dst == NULL only reports the record count. */
 int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records);
+/* Compact hit lists (query type 6): because every rank holds the same index, a region's variant list is
+ * its range of the position-ordered site table.  n_regions records of 4 x uint64 in DEVICE memory:
+ *   {region_base+q, first_site | region_flags<<32 | has_dropped<<40, variants reported, carriers}.
+ * (A region with has_dropped set lost entries to the reference's duplicate rule; its exact rows are in
+ * the full records of vs_result_pack_headers.)  device_dst == NULL only reports the record count. */
+int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
+                           uint64_t* n_records);
 void vs_result_free(vs_result* r);
 
 /* ---- timing of the last batch on this handle (HIP events on the engine's stream) ---- */

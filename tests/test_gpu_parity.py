@@ -239,3 +239,48 @@ def test_cohort_wider_than_one_wave_of_row_words(tmp_path):
     assert (cc > 32).sum() > 20 and cc.max() > 1000
     assert _compare_t6(vs, orc, regions) == len(regions)
     assert _compare_t4(vs, orc, regions[:10], "S02250") == 10
+
+
+def test_hit_list_records_for_the_collective(tmp_path):
+    """vs_result_pack_headers / vs_result_pack_regions write what the view holds (device -> torch tensor)."""
+    import torch
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 301, n_rows=300, ref_len=3000, p_near=0.7, p_multi=0.3)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(3)
+    regions = random_regions(rng, vs.info().ref_length, 200)
+    res = vs.get_var_in_ref(regions)
+    v = res.view(with_carriers=False)
+    n = res.num_header_records()
+    assert n == len(v["pos"])
+    buf = torch.zeros((n + 3, 4), dtype=torch.int64, device="cuda")
+    assert res.pack_headers_into(buf.data_ptr(), n + 3, region_base=1000) == n
+    rec = buf.cpu().numpy().view(np.uint64)[:n]
+    assert np.array_equal(rec[:, 0] & np.uint64((1 << 63) - 1), v["pos"])
+    assert np.array_equal((rec[:, 0] >> np.uint64(63)).astype(np.uint32), v["var_flags"] & 1)
+    assert np.array_equal(rec[:, 1], v["ref_off"].astype(np.uint64) | (v["ref_len"].astype(np.uint64) << np.uint64(32)))
+    assert np.array_equal(rec[:, 2], v["alt_off"].astype(np.uint64) | (v["alt_len"].astype(np.uint64) << np.uint64(32)))
+    assert np.array_equal(rec[:, 3] >> np.uint64(32), v["car_count"].astype(np.uint64))
+    vb = v["var_begin"].astype(np.int64)
+    reg_of_slot = np.repeat(np.arange(len(regions)), np.diff(vb))
+    assert np.array_equal(rec[:, 3] & np.uint64(0xFFFFFFFF), (reg_of_slot + 1000).astype(np.uint64))
+    # compact records: one per region
+    q = res.num_region_records()
+    assert q == len(regions)
+    rbuf = torch.zeros((q, 4), dtype=torch.int64, device="cuda")
+    assert res.pack_regions_into(rbuf.data_ptr(), q, region_base=7) == q
+    rr = rbuf.cpu().numpy().view(np.uint64)
+    assert np.array_equal(rr[:, 0], np.arange(q, dtype=np.uint64) + np.uint64(7))
+    assert np.array_equal(rr[:, 2], v["var_count"])
+    car_per_region = np.add.reduceat(np.concatenate([v["car_count"], [0]]).astype(np.uint64), np.minimum(vb[:-1], len(v["car_count"])))
+    car_per_region[np.diff(vb) == 0] = 0
+    assert np.array_equal(rr[:, 3], car_per_region)
+    assert np.array_equal((rr[:, 1] >> np.uint64(32)) & np.uint64(3), v["region_flags"].astype(np.uint64) & np.uint64(3))
+    has_dropped = ((rr[:, 1] >> np.uint64(40)) & np.uint64(1)).astype(bool)
+    assert np.array_equal(has_dropped, v["var_count"] != np.diff(vb).astype(np.uint64))
+    # the site range really is the region's variant list: consecutive regions with equal first sites
+    # and counts have equal rows
+    first = (rr[:, 1] & np.uint64(0xFFFFFFFF))
+    for a in range(q - 1):
+        for b in range(a + 1, min(q, a + 4)):
+            if first[a] == first[b] and rr[a, 2] == rr[b, 2] and not has_dropped[a] and not has_dropped[b] and rr[a, 2] > 0:
+                assert res.region_text(a) == res.region_text(b)

@@ -22,6 +22,12 @@ class FakeResult:
     def num_header_records(self):
         return self.recs.shape[0]
 
+    def num_region_records(self):
+        return self.recs.shape[0]
+
+    def pack_regions_into(self, ptr, cap, region_base):
+        return self.pack_headers_into(ptr, cap, region_base)
+
     def pack_headers_into(self, ptr, cap, region_base):
         assert cap >= self.recs.shape[0]
         r = self.recs.copy()
@@ -48,7 +54,7 @@ def _worker(rank, world, port, q):
     from variantstore_amd.parallel import allgather_hit_lists, shard_regions, unpack_records
     regions = np.stack([np.arange(1, 12), np.arange(1, 12) + 100], axis=1)
     mine, lo = shard_regions(regions, rank, world)
-    out, counts = allgather_hit_lists(FakeResult(_records(rank)), lo, torch.device("cpu"))
+    out, counts = allgather_hit_lists(FakeResult(_records(rank)), lo, torch.device("cpu"), compact=(rank >= 0 and world == 2))
     parts = unpack_records(out, counts)
     ok = [int(c) for c in counts] == [5 + 3 * r for r in range(world)]
     for r in range(world):

@@ -112,6 +112,18 @@ class QueryResult:
                                                 C.byref(n)), "vs_result_pack_headers")
         return int(n.value)
 
+    def num_region_records(self):
+        n = C.c_uint64()
+        _check(self._lib.vs_result_pack_regions(self._h, None, 0, 0, C.byref(n)), "vs_result_pack_regions")
+        return int(n.value)
+
+    def pack_regions_into(self, device_ptr, capacity_records, region_base=0):
+        """Compact hit lists: one 4 x uint64 record per region (site range of the replicated index)."""
+        n = C.c_uint64()
+        _check(self._lib.vs_result_pack_regions(self._h, C.c_void_p(device_ptr), capacity_records, region_base,
+                                                C.byref(n)), "vs_result_pack_regions")
+        return int(n.value)
+
     def region_text(self, q):
         """The `-o` file the reference writes for region q (query.h:38-50, 774-781)."""
         txt = C.c_char_p()

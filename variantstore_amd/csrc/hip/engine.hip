@@ -731,4 +731,22 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
   return VS_OK;
 }
 
+int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
+                           uint64_t* n_records) {
+  if (!r) return fail(VS_ERR_ARG, "null argument");
+  if (n_records) *n_records = r->d.Q;
+  if (!device_dst) return VS_OK;
+  if (capacity_records < r->d.Q) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
+                                             (unsigned long long)capacity_records, (unsigned long long)r->d.Q);
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  if (r->d.Q) {
+    hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((r->d.Q + 255) / 256)), dim3(256), 0, idx->stream, r->d,
+                       (uint64_t*)device_dst, region_base);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  return VS_OK;
+}
+
 }  // extern "C"

@@ -807,6 +807,20 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   else r.var_count[q] = nvar;
 }
 
+// Compact hit lists for a collective: the index (and so the site table) is replicated on every rank,
+// therefore a region's variant list is fully described by its site range.  4 x uint64 per region:
+//   {region_base + q, first site | region flags << 32 | has-dropped << 40, variants reported, carriers}
+__global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst, uint64_t region_base) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t fl = r.q_flags[q] & ~kRegionSlow;
+  const uint64_t dropped = r.var_count[q] != r.q_nvar[q] ? 1ULL : 0ULL;
+  dst[4 * q + 0] = region_base + q;
+  dst[4 * q + 1] = (uint64_t)r.q_g0[q] | (fl << 32) | (dropped << 40);
+  dst[4 * q + 2] = r.var_count[q];
+  dst[4 * q + 3] = r.car_base[q + 1] - r.car_base[q];
+}
+
 // Index::find batched (index.h:119-133)
 __global__ void __launch_bounds__(256) k_find(DevImage im, const uint64_t* pos, uint64_t n, uint32_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
