@@ -329,13 +329,9 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   if (!small) HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (d.A) {
-    static const int fill_variant = getenv("VS_FILL_V1") ? 1 : 2;
-    if (fill_variant == 1) {
-      uint64_t blocks = std::min<uint64_t>((d.A + 3) / 4, 16384);
-      hipLaunchKernelGGL(k_fill_carriers_v1, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, d);
-    } else {
+    {
       const uint64_t nchunks = (d.A + 63) / 64;
-      uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
+      const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
       static const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
       uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;

@@ -350,61 +350,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 }
 
 // ---------------------------------------------------------------------------
-// Carrier expansion: one wave per variant slot (grid-stride).
-// Bit-vector mode: lane w owns word w of the class row; an in-wave prefix sum
-// of the popcounts gives every word its output offset; each lane then peels its
-// set bits.  Explicit mode: a coalesced copy of the stored ids.
-// Output word = sample id | genotype bits << 29.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fill_carriers_v1(DevImage im, DevResult r) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t a = wave; a < r.A; a += nwaves) {
-    const uint32_t cnt = r.r_car_count[a];
-    if (cnt == 0) continue;
-    const uint32_t b = im.s_vid[r.r_site[a]];
-    uint32_t* out = r.carriers + r.r_car_begin[a];
-    const uint64_t gt0 = im.v_car_begin[b];
-    if (im.use_bv) {
-      const uint64_t* row = im.class_rows + (uint64_t)im.v_class[b] * im.wpc;
-      uint32_t base = 0;
-      for (uint32_t wb = 0; wb < im.wpc; wb += 64) {
-        const uint32_t w = wb + lane;
-        uint64_t word = w < im.wpc ? row[w] : 0ULL;
-        if (w == 0) word &= ~1ULL;  // bit 0 is "ref", never a carrier (query.h:278)
-        const uint32_t pc = __popcll(word);
-        uint32_t incl = pc;
-        for (int d = 1; d < 64; d <<= 1) {
-          uint32_t t = __shfl_up(incl, d, 64);
-          if (lane >= d) incl += t;
-        }
-        uint32_t k = base + incl - pc;
-        while (word) {
-          const uint32_t bit = __builtin_ctzll(word);
-          word &= word - 1;
-          if (k < cnt) {
-            const uint64_t c = gt0 + k;
-            const uint32_t nib = (im.gt_nibbles[c >> 1] >> ((c & 1) * 4)) & 7u;
-            out[k] = (w * 64 + bit) | (nib << 29);
-          }
-          ++k;
-        }
-        base += __shfl(incl, 63, 64);
-      }
-    } else {
-      for (uint32_t k = lane; k < cnt; k += 64) {
-        const uint64_t c = gt0 + k;
-        const uint32_t nib = (im.gt_nibbles[c >> 1] >> ((c & 1) * 4)) & 7u;
-        out[k] = im.car_sid[c] | (nib << 29);
-      }
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------
-// Carrier expansion v2.  One wave owns 64 consecutive variant slots; every lane
+// Carrier expansion (k_fill_carriers).  One wave owns 64 consecutive variant slots; every lane
 // first gathers the metadata of "its" slot (all 64 gathers in flight together),
 // then the wave works through the chunk in two regimes:
 //
