@@ -226,3 +226,20 @@ def test_vertex_blocks_parse_with_google_protobuf(seed, kw, tmp_path):
             assert (s.phase, s.gt_1, s.gt_2) == (bool(fl & 1), bool(fl & 2), bool(fl & 4))
             if not g["use_bit_vector"]:
                 assert list(s.sample_id) == [int(g["car_sid"][g["car_begin"][v] + i])]
+
+
+def test_multi_block_vertex_lists_and_resized_filter(tmp_path):
+    """> 200,000 vertices: several vertex_list_<k>.proto blocks (variant_graph.h:44 NUM_VERTEXES_IN_BLOCK),
+    read back in numeric (not lexical) order."""
+    vs = VariantStore.synthetic(device=-1, ref_length=6_000_000, num_variants=150_000, num_samples=30, seed=3,
+                                first_pos=100, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=4,
+                                af_exponent=2.0)
+    assert vs.info().num_vertices > 400_000
+    d = _save(vs, str(tmp_path / "ser"))
+    protos = sorted(f for f in os.listdir(d) if f.endswith(".proto"))
+    assert protos == ["vertex_list_0.proto", "vertex_list_1.proto", "vertex_list_2.proto"]
+    back = VariantStore.open(d, device=-1)
+    pa, pb = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    vs.export_plain(pa)
+    back.export_plain(pb)
+    assert open(pa, "rb").read() == open(pb, "rb").read()
