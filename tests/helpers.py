@@ -8,7 +8,7 @@ BASES = "ACGT"
 
 def write_random_cohort(dirpath, seed, ref_len=4000, n_rows=120, n_samples=6, sample_names=None,
                         p_ins=0.12, p_del=0.12, p_multi=0.08, p_mnp=0.05, p_near=0.3, carrier_p=0.3,
-                        unphased_p=0.1, missing_p=0.03, haploid_p=0.0, chrom="c1"):
+                        unphased_p=0.1, missing_p=0.03, haploid_p=0.0, chrom="c1", p_same=0.0, max_indel=4):
     """The "mix" recipe of SURVEY.md §4.5: SNPs, 1-4 bp insertions/deletions, two-ALT rows, MNPs, with a
     share of sites 1-3 bp from their predecessor.  Returns (fasta, vcf, names)."""
     rng = np.random.default_rng(seed)
@@ -18,8 +18,10 @@ def write_random_cohort(dirpath, seed, ref_len=4000, n_rows=120, n_samples=6, sa
     n_samples = len(sample_names)
     pos_list = []
     p = int(rng.integers(2, 20))
-    while len(pos_list) < n_rows and p < ref_len - 12:
+    while len(pos_list) < n_rows and p < ref_len - 12 - max_indel:
         pos_list.append(p)
+        if p_same and rng.random() < p_same:
+            continue  # another row at the very same position (repeated / split multi-allelic sites)
         if rng.random() < p_near:
             p += int(rng.integers(1, 4))
         else:
@@ -37,10 +39,10 @@ def write_random_cohort(dirpath, seed, ref_len=4000, n_rows=120, n_samples=6, sa
             t = rng.random()
             r0 = ref[p - 1]
             if t < p_ins:
-                k = int(rng.integers(1, 5))
+                k = int(rng.integers(1, max_indel + 1))
                 refa, alts = r0, [r0 + "".join(BASES[i] for i in rng.integers(0, 4, size=k))]
             elif t < p_ins + p_del:
-                k = int(rng.integers(1, 5))
+                k = int(rng.integers(1, max_indel + 1))
                 refa, alts = ref[p - 1:p + k], [r0]
             elif t < p_ins + p_del + p_mnp:
                 refa = ref[p - 1:p + 1]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign (GPU): many small cohorts of varied shape, every region compared with the
+CPU oracle as text, for query types 6 and 4.  Usage: python tools/stress_parity.py [n_cohorts] [seed0]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import random_regions, write_random_cohort  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from variantstore_amd import VariantStore  # noqa: E402
+
+n_cohorts = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+bad = hang = ub = checked = slow_regions = 0
+for c in range(n_cohorts):
+    seed = seed0 + c
+    rng = np.random.default_rng(seed)
+    kw = dict(ref_len=int(rng.integers(300, 6000)), n_rows=int(rng.integers(5, 400)),
+              n_samples=int(rng.choice([1, 2, 5, 9, 40, 70, 130])), p_ins=float(rng.uniform(0, 0.35)),
+              p_del=float(rng.uniform(0, 0.35)), p_multi=float(rng.uniform(0, 0.4)), p_mnp=float(rng.uniform(0, 0.15)),
+              p_near=float(rng.uniform(0, 0.9)), carrier_p=float(rng.choice([0.004, 0.05, 0.3, 0.7])),
+              unphased_p=float(rng.uniform(0, 0.3)), missing_p=float(rng.uniform(0, 0.1)),
+              p_same=float(rng.choice([0.0, 0.0, 0.2, 0.5])), max_indel=int(rng.choice([2, 4, 12, 40])))
+    if rng.random() < 0.3:
+        names = [f"n{int(x)}" for x in rng.permutation(kw["n_samples"])]
+        kw["sample_names"] = names
+    with tempfile.TemporaryDirectory() as td:
+        fasta, vcf, names = write_random_cohort(td, seed, **kw)
+        try:
+            vs = VariantStore.from_vcf(fasta, vcf, device=0)
+        except Exception as e:  # constructor refuses (e.g. mutation past the reference end)
+            print(f"cohort {seed}: construct refused: {e}")
+            continue
+        plain = os.path.join(td, "p.bin")
+        vs.export_plain(plain)
+        orc = Oracle(plain)
+        regions = random_regions(rng, vs.info().ref_length, 150, max_len=int(rng.choice([5, 60, 600, 5000])))
+        res = vs.get_var_in_ref(regions)
+        flags = res.view(False)
+        for q, (x, y) in enumerate(regions):
+            n, early, text = orc.get_var_in_ref(x, y)
+            if n < 0:
+                hang += 1
+                continue
+            checked += 1
+            if res.region_text(q) != text or bool(flags["region_flags"][q] & 1) != early:
+                bad += 1
+                print(f"MISMATCH t6 cohort {seed} region {x}:{y}\n--- gpu\n{res.region_text(q)}--- oracle\n{text}")
+        slow_regions += int((flags["var_count"] != np.diff(flags["var_begin"].astype(np.int64))).sum())
+        sample = names[int(rng.integers(0, len(names)))]
+        r4 = vs.get_sample_var_in_ref(regions[:60], sample)
+        for q, (x, y) in enumerate(regions[:60]):
+            n, early, text = orc.get_sample_var_in_ref(x, y, sample)
+            if n < 0:
+                hang += 1
+                continue
+            checked += 1
+            if r4.region_text(q) != text:
+                bad += 1
+                print(f"MISMATCH t4 cohort {seed} sample {sample} region {x}:{y}\n--- gpu\n{r4.region_text(q)}--- oracle\n{text}")
+        ub += orc.ub_events()
+        res.close(); r4.close(); vs.close()
+print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
+      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions}")
+sys.exit(1 if bad else 0)
