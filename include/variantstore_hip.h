@@ -106,6 +106,9 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
 /* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
                                vs_result** out);
+/* type 4 with one sample id per region (a batch mixing samples, e.g. the cohort round-robin of the bench) */
+int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids,
+                                vs_result** out);
 /* batched Index::find (index.h:119-133): vertex id of the ref node covering each position */
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out);
 

@@ -190,6 +190,20 @@ def test_random_cohorts_type4_match_oracle(seed, kw, tmp_path):
         assert _compare_t4(vs, orc, regions, sample) > 0
 
 
+def test_type4_mixed_samples_in_one_batch(tmp_path):
+    """vs_query_samples_var_in_ref: one sample id per region."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 207, n_samples=9, p_near=0.5, p_multi=0.2)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(207)
+    regions = random_regions(rng, vs.info().ref_length, 120)
+    per = [names[i % len(names)] for i in range(len(regions))]
+    res = vs.get_sample_var_in_ref(regions, per)
+    for q, (x, y) in enumerate(regions):
+        n, early, text = orc.get_sample_var_in_ref(x, y, per[q])
+        if n >= 0:
+            assert res.region_text(q) == text, (q, per[q])
+
+
 def test_type4_synthetic_midsize(tmp_path):
     vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21,
                                 first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6,

@@ -249,8 +249,16 @@ class VariantStore:
 
     def get_sample_var_in_ref(self, regions, sample) -> QueryResult:
         """Query type 4 for one sample over a batch of regions (query.h:618-729)."""
-        sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
         arr, ptr, n = _regions_array(regions)
         h = C.c_void_p()
+        if isinstance(sample, (list, tuple, np.ndarray)):  # one sample per region
+            sids = np.ascontiguousarray([self.sample_id(s) if isinstance(s, str) else int(s) for s in sample],
+                                        dtype=np.uint32)
+            if sids.shape[0] != n:
+                raise ValueError("one sample per region expected")
+            _check(self._lib.vs_query_samples_var_in_ref(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                         C.byref(h)), "vs_query_samples_var_in_ref")
+            return QueryResult(self, h)
+        sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
         _check(self._lib.vs_query_sample_var_in_ref(self._h, ptr, n, sid, C.byref(h)), "vs_query_sample_var_in_ref")
         return QueryResult(self, h)

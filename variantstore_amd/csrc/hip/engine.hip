@@ -264,8 +264,10 @@ static int ralloc(vs_result* r, size_t n, T** p) {
 }
 
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk)
-static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone) {
-  const bool t4 = sample_id != kNone;
+static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
+                          const uint32_t* sample_ids = nullptr) {
+  const bool t4 = sample_id != kNone || sample_ids != nullptr;
+  uint32_t* dsids = nullptr;
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -280,6 +282,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
   if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
+  if (sample_ids && n) {
+    VS_TRY(ralloc(r, n, &dsids));
+    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
+  }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   std::vector<DevBuf> scratch;
   uint64_t totals[3] = {0, 0, 1};
@@ -292,7 +298,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipMemcpyAsync(totals, dtot, 24, hipMemcpyDeviceToHost, idx->stream));
   } else {
     if (n) {
-      if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
+      if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
       else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
       HIP_TRY(hipGetLastError());
     }
@@ -320,7 +326,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.S, &d.carriers));
   if (!small) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id);
+    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       if (totals[2]) hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
@@ -577,6 +583,22 @@ int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t
   r->idx = idx;
   idx->live_results++;
   int rc = run_var_in_ref(idx, regions, n, r, sample_id);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids,
+                                vs_result** out) {
+  if (!idx || !out || (n && (!regions || !sample_ids))) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  for (uint64_t i = 0; i < n; ++i)
+    if (sample_ids[i] >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_ids[i], idx->g.num_samples);
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  int rc = run_var_in_ref(idx, regions, n, r, kNone, sample_ids);
   if (rc != VS_OK) { vs_result_free(r); return rc; }
   *out = r;
   return VS_OK;

@@ -658,9 +658,10 @@ __device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v
 }
 
 template <bool EMIT>
-__global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid) {
+__global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
+  const uint32_t sid = sid_per_region ? sid_per_region[q] : sid_all;
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   uint8_t fl = 0;
   uint64_t nvar = 0, ncar = 0;
