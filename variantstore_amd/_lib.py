@@ -94,6 +94,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP engine has not been built "
             "(run `python -m variantstore_amd.build`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If this library were loaded
+    # first it would bring in the system copy and a later `import torch` would see "No HIP GPUs" (and
+    # corrupt the heap).  Importing torch first, when it is installed, makes both share torch's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
