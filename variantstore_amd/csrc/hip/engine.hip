@@ -61,6 +61,7 @@ struct vs_index {
   vs_timing timing{};
   vs_construct_stats cstats{};
   uint64_t live_results = 0;
+  uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path
 };
 
 struct vs_result {
@@ -165,6 +166,7 @@ static int build_device_image(vs_index* idx) {
   HIP_TRY(hipSetDevice(idx->device));
   HIP_TRY(hipStreamCreate(&idx->stream));
   for (auto& e : idx->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipHostMalloc((void**)&idx->pinned, 16384, hipHostMallocDefault));
   d.ref_length = im.ref_length;
   d.nbits = (uint64_t)im.bits.size() * 64;
   d.num_samples = im.num_samples; d.wpc = im.wpc; d.use_bv = im.use_bit_vector;
@@ -288,26 +290,17 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   std::vector<DevBuf> scratch;
-  uint64_t totals[3] = {0, 0, 1};
-  const bool small = !t4 && n > 0 && n <= 512;   // latency path: one launch for bounds + scans
-  if (small) {
-    uint64_t* dtot = nullptr;
-    VS_TRY(ralloc(r, 3, &dtot));
-    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot);
+  uint64_t totals[2] = {0, 0};
+  if (n) {
+    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(totals, dtot, 24, hipMemcpyDeviceToHost, idx->stream));
-  } else {
-    if (n) {
-      if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
-      else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
-      HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
-    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
-    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
-    HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
   }
+  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
+  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
+  HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   d.A = totals[0];
   d.S = totals[1];
@@ -324,16 +317,16 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_class));
   VS_TRY(ralloc(r, d.A, &d.r_gt0));
   VS_TRY(ralloc(r, d.S, &d.carriers));
-  if (!small) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
     if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-      if (totals[2]) hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+      hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
     }
     HIP_TRY(hipGetLastError());
   }
-  if (!small) HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (d.A) {
     {
       const uint64_t nchunks = (d.A + 63) / 64;
@@ -355,13 +348,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   release_bufs(idx, scratch);
   vs_timing& t = idx->timing;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
-  t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
-  if (!small) {  // the latency path records only the end-to-end pair
-    HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
-  }
+  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
   t.fill_launches = d.A ? 1 : 0;
   return VS_OK;
 }
@@ -396,6 +386,69 @@ static int fetch_headers(vs_result* r) {
   return VS_OK;
 }
 
+// Latency path for small type-6 batches: regions are read from mapped host memory, result buffers are
+// taken speculatively (pooled, so free after the first call), the sizes are decided on the device and
+// all four kernels are queued back to back -- one host synchronisation per call.  Returns 1 when the
+// speculative buffers were too small (the caller then takes the general path).
+static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
+  DevResult& d = r->d;
+  d.Q = n;
+  const uint64_t capA = std::max<uint64_t>(4096, 1024 * n);
+  const uint64_t capS = std::min<uint64_t>(std::max<uint64_t>(1u << 20, 131072 * n), 32u << 20);
+  memcpy(idx->pinned + 8, regions, n * 16);
+  d.regions = idx->pinned + 8;
+  VS_TRY(ralloc(r, n, &d.q_flags));
+  VS_TRY(ralloc(r, n, &d.q_g0));
+  VS_TRY(ralloc(r, n, &d.q_nvar));
+  VS_TRY(ralloc(r, n, &d.q_ncar));
+  VS_TRY(ralloc(r, n + 1, &d.var_begin));
+  VS_TRY(ralloc(r, n + 1, &d.car_base));
+  VS_TRY(ralloc(r, n, &d.var_count));
+  uint64_t* dtot = nullptr;
+  VS_TRY(ralloc(r, 4, &dtot));
+  d.dyn_totals = dtot;
+  VS_TRY(ralloc(r, capA, &d.r_pos));
+  VS_TRY(ralloc(r, capA, &d.r_ref_off));
+  VS_TRY(ralloc(r, capA, &d.r_ref_len));
+  VS_TRY(ralloc(r, capA, &d.r_alt_off));
+  VS_TRY(ralloc(r, capA, &d.r_alt_len));
+  VS_TRY(ralloc(r, capA, &d.r_flags));
+  VS_TRY(ralloc(r, capA, &d.r_car_count));
+  VS_TRY(ralloc(r, capA, &d.r_site));
+  VS_TRY(ralloc(r, capA, &d.r_region));
+  VS_TRY(ralloc(r, capA, &d.r_car_begin));
+  VS_TRY(ralloc(r, capA, &d.r_class));
+  VS_TRY(ralloc(r, capA, &d.r_gt0));
+  VS_TRY(ralloc(r, capS, &d.carriers));
+  d.A = capA; d.S = capS;
+  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
+  hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+  hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+  {
+    const uint64_t nchunks = (capA + 63) / 64;
+    const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 2048);
+    uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
+    if (gt_words < 448) gt_words = 448;
+    const size_t lds_bytes = 4 * (size_t)(gt_words + kRingWords) * 4;
+    if (idx->d.wpc <= 63)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  if (idx->pinned[3]) return 1;  // overflow: nothing was written, retry with exact sizes
+  d.A = idx->pinned[0];
+  d.S = idx->pinned[1];
+  vs_timing& t = idx->timing;
+  t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
+  t.fill_launches = 1;
+  return VS_OK;
+}
+
 extern "C" {
 
 const char* vs_strerror(int code) {
@@ -422,6 +475,7 @@ void vs_index_close(vs_index* idx) {
     for (auto p : idx->image_allocs) (void)hipFree(p);
     for (auto& b : idx->pool) (void)hipFree(b.p);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
+    if (idx->pinned) (void)hipHostFree(idx->pinned);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
   }
   delete idx;
@@ -568,7 +622,15 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  int rc = run_var_in_ref(idx, regions, n, r);
+  int rc = 1;
+  if (n > 0 && n <= 512) {
+    rc = run_small_type6(idx, regions, n, r);
+    if (rc == 1) {  // speculative buffers too small
+      release_bufs(idx, r->bufs);
+      r->d = DevResult{};
+    }
+  }
+  if (rc == 1) rc = run_var_in_ref(idx, regions, n, r);
   if (rc != VS_OK) { vs_result_free(r); return rc; }
   *out = r;
   return VS_OK;

@@ -77,6 +77,8 @@ struct DevResult {
   uint64_t* r_car_begin;
   uint64_t* r_gt0;
   uint32_t* carriers;
+  // latency path: sizes are decided on the device ({slots, carriers, any-slow, overflow}); NULL otherwise
+  const uint64_t* dyn_totals;
 };
 
 // ones in bit positions [0, p): number of ref-node start indexes <= p
@@ -209,7 +211,8 @@ __global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r)
 
 // Small batches (latency path): bounds of every region and both offset scans in ONE single-block
 // launch.  totals = {slots, carriers, any region needing the literal dedup rule}.
-__global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResult r, uint64_t* totals) {
+__global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResult r, uint64_t* totals,
+                                                           uint64_t* host_totals, uint64_t cap_slots, uint64_t cap_carriers) {
   for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -220,7 +223,9 @@ __global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResul
       slow |= (r.q_flags[q] & kRegionSlow) ? 1 : 0;
     }
     r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
-    totals[0] = a; totals[1] = c; totals[2] = slow;
+    const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
+    totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
+    if (host_totals) { host_totals[0] = a; host_totals[1] = c; host_totals[2] = slow; host_totals[3] = over; }
   }
 }
 
@@ -297,6 +302,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const T* in, uint64_t
 __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
+  if (r.dyn_totals && r.dyn_totals[3]) return;  // speculative buffers too small: the host retries
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
   const uint32_t g0 = r.q_g0[q];
@@ -324,6 +330,7 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
+  if (r.dyn_totals && r.dyn_totals[3]) return;
   const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
   uint64_t kept = 0, back = 0;
   for (uint64_t j = 0; j < n; ++j) {
@@ -439,7 +446,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint64_t nchunks = (r.A + 63) >> 6;
+  const uint64_t A = r.dyn_totals ? (r.dyn_totals[3] ? 0 : r.dyn_totals[0]) : r.A;
+  const uint64_t nchunks = (A + 63) >> 6;
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
     const uint64_t a = (chunk << 6) + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
-    if (a < r.A) {
+    if (a < A) {
       cnt = r.r_car_count[a];
       cls = r.r_class[a];
       gt0 = r.r_gt0[a];
