@@ -298,3 +298,27 @@ def test_hit_list_records_for_the_collective(tmp_path):
         for b in range(a + 1, min(q, a + 4)):
             if first[a] == first[b] and rr[a, 2] == rr[b, 2] and not has_dropped[a] and not has_dropped[b] and rr[a, 2] > 0:
                 assert res.region_text(a) == res.region_text(b)
+
+
+def test_small_batches_that_outgrow_the_speculative_buffers(tmp_path):
+    """Batches of <= 512 regions take the single-sync latency path with result buffers sized by guess;
+    regions holding more variants (> 4096) or more carriers (> 2^20) than the guess must fall back to
+    the exact-size path and give the same text."""
+    vs = VariantStore.synthetic(device=0, ref_length=600_000, num_variants=9000, num_samples=1200, seed=91,
+                                first_pos=200, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=4,
+                                af_exponent=2.5)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    whole = [(1, 599_000)]
+    res = vs.get_var_in_ref(whole)
+    nv, ncar = int(res.view(False)["var_begin"][1]), int(res.totals()[2])
+    assert nv > 4096 and ncar > (1 << 20), (nv, ncar)
+    assert _compare_t6(vs, orc, whole) == 1
+    # within the variant guess but not the carrier guess, and the other way round
+    assert _compare_t6(vs, orc, [(1, 250_000)]) == 1
+    assert _compare_t6(vs, orc, [(1, 599_000), (300_000, 301_000), (5, 200)]) == 3
+    # and right after a fallback the latency path still answers small regions
+    assert _compare_t6(vs, orc, [(300_000, 301_000)]) == 1
+    batch = [(int(s), int(s) + 700) for s in np.random.default_rng(3).integers(1, 598_000, size=512)]
+    assert _compare_t6(vs, orc, batch) == 512
