@@ -217,6 +217,35 @@ def main():
         t4 = {"queries_per_s": 3 * nreg / (time.perf_counter() - a4), "regions_per_batch": nreg, "samples": 16,
               "variants_per_region": nv4 / nreg}
 
+    # ---- point queries (types 1 and 7) on the same index, outside the timed region:
+    #      1M random positions; type 7 asks for an A>C substitution everywhere (nearly always "no such variant",
+    #      which costs the same walk) ----
+    t17 = None
+    if os.environ.get("VS_BENCH_SKIP_T4") != "1":
+        npos = 1_000_000
+        prng = np.random.default_rng(17)
+        positions = prng.integers(1, w["ref_length"], size=npos, dtype=np.uint64)
+        r1 = vs.closest_var(positions)
+        nv1 = r1.totals()[1]
+        r1.close()
+        torch.cuda.synchronize()
+        a1 = time.perf_counter()
+        for _k in range(3):
+            r1 = vs.closest_var(positions)
+            r1.close()
+        torch.cuda.synchronize()
+        t1_qps = 3 * npos / (time.perf_counter() - a1)
+        refs7, alts7 = ["A"] * npos, ["C"] * npos
+        r7 = vs.samples_has_var(positions, refs7, alts7)
+        r7.close()
+        torch.cuda.synchronize()
+        r7 = vs.samples_has_var(positions, refs7, alts7)
+        ms7 = vs.last_timing().ms_total   # device pipeline; the host side here is a million Python strings
+        nf7 = int((r7.view(False)["region_flags"] & 4 == 0).sum())
+        r7.close()
+        t17 = {"type1_queries_per_s": t1_qps, "type1_variants_per_query": nv1 / npos,
+               "type7_queries_per_s_device": npos / (ms7 * 1e-3), "type7_found": nf7, "positions_per_batch": npos}
+
     if rank == 0:
         out = {
             "metric": "region-queries/sec (batch, query-type 6)",
@@ -250,6 +279,7 @@ def main():
                          "pipeline_ms": tot_ms / args.steps},
             "p50_latency_us": p50,
             "type4": t4,
+            "point_queries": t17,
             "result_digest": f"{digest:016x}",
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -109,12 +109,26 @@ int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t
 /* type 4 with one sample id per region (a batch mixing samples, e.g. the cohort round-robin of the bench) */
 int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids,
                                 vs_result** out);
+/* Query type 1, closest_var (include/query.h:441-483; called from src/commands.cc:151-155): the variants of the
+ * site nearest to each position, found exactly as the reference does (one next_variant_in_ref call forwards, one
+ * mirrored call backwards, or the one-position-at-a-time step back when nothing lies ahead).  Each position gives one
+ * "region" of the result; VS_REGION_NOT_FOUND marks a call for which the reference returns false (it then writes
+ * no output file and vs_result_format_region gives an empty text). */
+int vs_query_closest_var(vs_index* idx, const uint64_t* positions, uint64_t n, vs_result** out);
+/* Query type 7, samples_has_var (include/query.h:792-823; src/commands.cc:181-189): the carriers of the variant
+ * (positions[i], refs[i], alts[i]) among the variants ONE next_variant_in_ref(positions[i]) call reports.
+ * refs/alts are NUL-terminated strings compared byte for byte with the index's sequences.  A region of the result
+ * holds one variant when found (vs_result_format_region then gives the reference's output line: `name gt` pairs
+ * with no separator, then a newline) and carries VS_REGION_NOT_FOUND otherwise ("There is no such variant!"). */
+int vs_query_samples_has_var(vs_index* idx, const uint64_t* positions, const char* const* refs, const char* const* alts,
+                             uint64_t n, vs_result** out);
 /* batched Index::find (index.h:119-133): vertex id of the ref node covering each position */
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out);
 
 /* Result of one batch.  Arrays live in HBM until a view is requested. */
 enum { VS_REGION_EMPTY = 1,   /* Index::is_empty early-out fired (query.h:745-756 prints the other label) */
-       VS_REGION_INVALID = 2  /* pos_x < 1: the reference aborts (index.h:151-154) */ };
+       VS_REGION_INVALID = 2, /* pos_x < 1: the reference aborts (index.h:151-154) */
+       VS_REGION_NOT_FOUND = 4 /* types 1 and 7: closest_var returned false / "There is no such variant!" */ };
 enum { VS_VAR_DROPPED = 1 };  /* suppressed by the reference's "already seen" rule, query.h:397-414 */
 #define VS_CARRIER_ID(c) ((c) & 0x1FFFFFFFu)
 #define VS_CARRIER_GT(c) ((c) >> 29)         /* bit0 phase ('|'), bit1 gt_1, bit2 gt_2 */

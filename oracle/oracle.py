@@ -37,6 +37,12 @@ def _load():
         lib.vso_get_var_in_ref.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
         lib.vso_get_sample_var_in_ref.restype = C.c_long
         lib.vso_get_sample_var_in_ref.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_int)]
+        lib.vso_closest_var.restype = C.c_long
+        lib.vso_closest_var.argtypes = [C.c_void_p, C.c_uint64]
+        lib.vso_samples_has_var.restype = C.c_int
+        lib.vso_samples_has_var.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p]
+        lib.vso_raw_text.restype = C.c_void_p
+        lib.vso_raw_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.vso_last_text.restype = C.c_void_p
         lib.vso_last_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.vso_ub_events.restype = C.c_uint64
@@ -84,6 +90,19 @@ class Oracle:
         e = C.c_int()
         n = self._lib.vso_get_sample_var_in_ref(self._h, x, y, sample.encode(), C.byref(e))
         return n, bool(e.value), (self.last_text() if text else None)
+
+    def closest_var(self, pos):
+        """Query type 1: (n_variants, text); n == -1 (text None) when the reference returns false."""
+        n = self._lib.vso_closest_var(self._h, pos)
+        return n, (self.last_text() if n >= 0 else None)
+
+    def samples_has_var(self, pos, ref, alt):
+        """Query type 7: the line written to the output file, or None ("There is no such variant!")."""
+        if not self._lib.vso_samples_has_var(self._h, pos, ref.encode("latin-1"), alt.encode("latin-1")):
+            return None
+        n = C.c_uint64()
+        p = self._lib.vso_raw_text(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode("latin-1")
 
     def last_text(self):
         n = C.c_uint64()

@@ -20,6 +20,7 @@
 //   get_samples, next_variant_in_ref, get_var_in_ref       include/query.h:268-436, 736-784
 //   get_prev_vertex_with_sample, get_sample_var_in_ref     include/query.h:57-113, 618-729
 //   print_header / print_var                               include/query.h:38-50
+//   closest_var (type 1), samples_has_var (type 7)         include/query.h:441-483, 792-823
 //
 // Input: the "plain dump" of an index (HostGraph::write_plain) -- the decoded
 // content of the index directory.  Neighbour sets are rebuilt here with the
@@ -562,6 +563,56 @@ struct Oracle {
     return (long)last_vars.size();
   }
 
+  // Type 1.  returns -1 when the reference returns false (nothing is written to the output file)
+  long closest_var(const uint64_t pos) {  // query.h:441-483
+    std::vector<Variant> vars, next_var;
+    uint64_t next_pos;
+    last_empty = false;
+    if (next_variant_in_ref(pos, next_var, next_pos)) {
+      uint64_t next_var_pos = next_var[0].var_pos;
+      std::vector<Variant> prev_var;
+      int cur_pos = (int)(pos - (next_var_pos - pos));
+      if (cur_pos > 0) {
+        next_variant_in_ref(cur_pos, prev_var, next_pos);
+        if (prev_var.empty()) {  // prev_var[0] on an empty vector in the reference; defined: keep next_var
+          ub_events++;
+          vars = next_var;
+        } else {
+          uint64_t prev_var_pos = prev_var[0].var_pos;
+          if (prev_var_pos != next_var_pos) vars = prev_var;
+          else vars = next_var;
+        }
+      } else vars = next_var;
+    } else {
+      int cur_pos = (int)(pos - 1);
+      while (cur_pos > 0 && !next_variant_in_ref(cur_pos, next_var, next_pos)) {
+        if (cur_pos == 1) { last_vars.clear(); return -1; }
+        cur_pos--;
+      }
+      vars = next_var;
+    }
+    last_vars.swap(vars);
+    return (long)last_vars.size();
+  }
+
+  // Type 7.  returns 1 and leaves the output line in last_text, or 0 ("There is no such variant!")
+  int samples_has_var(const uint64_t pos, const std::string& ref, const std::string& alt) {  // query.h:792-823
+    std::vector<Variant> vars;
+    uint64_t next_pos;
+    next_variant_in_ref(pos, vars, next_pos);
+    last_text.clear();
+    for (auto var : vars) {
+      if (var.ref == ref && var.var_pos == pos && var.alt == alt) {
+        for (auto i = var.samples.begin(); i != var.samples.end(); ++i) { last_text += i->first; last_text += ' '; last_text += i->second; }
+        last_text += "\n";
+        last_vars.assign(1, var);
+        return 1;
+      }
+    }
+    last_vars.clear();
+    return 0;
+  }
+
   void format_last() {
     last_text.clear();
     print_header(last_text);
@@ -662,6 +713,17 @@ long vso_get_sample_var_in_ref(void* h, uint64_t x, uint64_t y, const char* samp
   long n = o->get_sample_var_in_ref(x, y, sample);
   if (empty_out) *empty_out = o->last_empty;
   return n;
+}
+// type 1.  Number of variants, or -1 when closest_var returns false (no output file is written then).
+long vso_closest_var(void* h, uint64_t pos) { return ((Oracle*)h)->closest_var(pos); }
+// type 7.  1 = found (vso_raw_text holds the line written to the output file), 0 = "There is no such variant!"
+int vso_samples_has_var(void* h, uint64_t pos, const char* ref, const char* alt) {
+  return ((Oracle*)h)->samples_has_var(pos, ref, alt);
+}
+const char* vso_raw_text(void* h, uint64_t* len) {
+  Oracle* o = (Oracle*)h;
+  if (len) *len = o->last_text.size();
+  return o->last_text.c_str();
 }
 // text of the last query in the `-o` file format (header + one row per variant)
 const char* vso_last_text(void* h, uint64_t* len) {

@@ -83,3 +83,39 @@ def test_query_batch_sorted_last_region_in_outfile_and_type4(golden_dir, survey_
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Number of variants get_sample_var_in_ref: 8" in _msgs(out.stdout)
     assert open(ofile).read() == survey_vectors["G1_t4"]["text"]
+
+
+@pytest.mark.gpu
+def test_query_types_1_and_7(golden_dir, tmp_path):
+    """`-t 1` (closest_var) and `-t 7` (samples_has_var) on the 3-sample G4 index of SURVEY.md §4.3."""
+    d = str(tmp_path / "ser")
+    os.makedirs(d)
+    out = subprocess.run([CLI, "construct", "-r", os.path.join(golden_dir, "x.small.fa"), "-v",
+                          os.path.join(golden_dir, "g4.vcf"), "-p", d], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ofile = str(tmp_path / "o.txt")
+    # the survey's run of the reference: `-t 7 -r 9 -b G -a A` -> "[error] There is no such variant!"
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "7", "-r", "9", "-b", "G", "-a", "A", "-m", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    assert "7. Get samples have given variant. 0" in msgs
+    assert "Looking for variant POS: 9, REF: G, ALT: A" in msgs
+    assert "There is no such variant!" in msgs
+    assert not os.path.exists(ofile)
+    # regions are sorted, the -a/-b lists are not (commands.cc:91,185): 20 pairs with the FIRST listed sequences
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "7", "-r", "54,20", "-b", "T,", "-a", "G,AG", "-m", "1", "-o", ofile,
+                          "-v"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    assert "Looking for variant POS: 20, REF: T, ALT: G" in msgs and "Looking for variant POS: 54, REF: , ALT: AG" in msgs
+    assert "There is no such variant!" not in msgs
+    assert open(ofile).read() == "S2 0|1\n"          # the last region's line stays in the file
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "1", "-r", "8,80", "-m", "1", "-o", ofile, "-v", "--batch-out",
+                          str(tmp_path / "b.txt")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    assert "1. return closest mutation in ref coordinate. 0" in msgs and "1. return closest mutation in ref coordinate. 1" in msgs
+    assert re.match(r"Query2: Total Time Elapsed: \d+\.\d{6}seconds", msgs[-1])
+    assert open(ofile).read() == "Pos\tRef\tAlt\tSamples\n54\t\tAG\tS2(0|1) \n"
+    assert "#region 0 8\nPos\tRef\tAlt\tSamples\n9\tG\tA\tS2(1/1) S10(0|1) S1(1|0) \n" in open(str(tmp_path / "b.txt")).read()

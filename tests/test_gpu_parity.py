@@ -322,3 +322,83 @@ def test_small_batches_that_outgrow_the_speculative_buffers(tmp_path):
     assert _compare_t6(vs, orc, [(300_000, 301_000)]) == 1
     batch = [(int(s), int(s) + 700) for s in np.random.default_rng(3).integers(1, 598_000, size=512)]
     assert _compare_t6(vs, orc, batch) == 512
+
+
+def _parse_rows(text):
+    rows = []
+    for line in text.split("\n")[1:-1]:
+        pos, ref, alt, _ = line.split("\t")
+        rows.append((int(pos), ref, alt))
+    return rows
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (301, dict()),
+    (302, dict(p_same=0.25, p_near=0.6)),
+    (303, dict(n_samples=70, carrier_p=0.2, ref_len=3000, n_rows=90)),
+    (304, dict(n_samples=40, carrier_p=0.004, ref_len=2500, n_rows=60)),   # explicit sample ids
+])
+def test_type1_closest_var_matches_oracle(seed, kw, tmp_path):
+    """Query type 1 at EVERY position of the reference (and past its end), text-exact, including the
+    calls the reference answers with `false` (no file written)."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = kw.get("ref_len", 4000)
+    # the last two exercise the reference's `int cur_pos` truncation (a position like 2^31 - 1 is left out: the
+    # reference -- and the literal oracle -- would step back two billion positions one call at a time)
+    positions = list(range(0, L + 40)) + [2 ** 31 + 5, 2 ** 32 + 7]
+    res = vs.closest_var(positions)
+    flags = res.view(False)["region_flags"]
+    for q, p in enumerate(positions):
+        n, text = orc.closest_var(p)
+        if n < 0:
+            assert flags[q] & 4 and res.region_text(q) == "", p
+        else:
+            assert not (flags[q] & 4) and res.region_text(q) == text, p
+    res.close()
+
+
+def test_type1_on_an_index_without_variants_ahead(golden_dir, tmp_path):
+    vs, orc = _open_gpu(os.path.join(golden_dir, "x.small.fa"), os.path.join(golden_dir, "g4.vcf"), tmp_path)
+    positions = list(range(0, 120))
+    res = vs.closest_var(positions)
+    for q, p in enumerate(positions):
+        n, text = orc.closest_var(p)
+        assert n >= 0 and res.region_text(q) == text, p
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (311, dict()),
+    (312, dict(p_same=0.25, p_near=0.6)),
+    (313, dict(n_samples=70, carrier_p=0.2, ref_len=3000, n_rows=90)),
+])
+def test_type7_samples_has_var_matches_oracle(seed, kw, tmp_path):
+    """Query type 7 for every variant type 6 reports (at its own position and the neighbouring ones), for
+    wrong REF/ALT strings, and for positions with nothing to find."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = kw.get("ref_len", 4000)
+    rows = _parse_rows(orc.get_var_in_ref(1, L)[2])
+    assert len(rows) > 50
+    qs = []
+    for pos, ref, alt in rows:
+        for d in (-2, -1, 0, 1):
+            if pos + d >= 0:
+                qs.append((pos + d, ref, alt))
+        qs.append((pos, ref + "A", alt))
+        qs.append((pos, ref, alt + "C"))
+        qs.append((pos, alt, ref))
+        qs.append((pos, "", ""))
+    qs += [(L + 50, "A", "C"), (0, "A", "C"), (1, "", "")]
+    res = vs.samples_has_var([q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs])
+    flags = res.view(False)["region_flags"]
+    found = 0
+    for q, (pos, ref, alt) in enumerate(qs):
+        want = orc.samples_has_var(pos, ref, alt)
+        if want is None:
+            assert flags[q] & 4 and res.region_text(q) == "", qs[q]
+        else:
+            found += 1
+            assert not (flags[q] & 4) and res.region_text(q) == want, qs[q]
+    assert found > 20
+    res.close()

@@ -92,3 +92,29 @@ def test_x_small_sample_indexes(golden_dir, survey_vectors, tmp_path):
         if cs:
             got[str(v)] = cs
     assert got == g["carrier_index"]
+
+
+def test_type7_observation_of_the_survey(golden_dir, tmp_path):
+    """SURVEY.md §4.3 (run of the reference on the G4 index): `-t 7 -r 9 -b G -a A` logs
+    "There is no such variant!" -- type 7 only finds variants hanging off a node that starts at pos."""
+    _, orc = _open(golden_dir, "x.small.fa", "g4.vcf", tmp_path)
+    assert orc.samples_has_var(9, "G", "A") is None
+    # the same variant is reported by type 6 at var_pos 9, so no position makes type 7 return it
+    assert all(orc.samples_has_var(p, "G", "A") is None for p in range(1, 90))
+    # what it does find: an insertion whose anchor node ends at pos, and a substitution behind a zero-length
+    # dummy ref node (quirk 3 of §4.3); the output line has no separator between the `name gt` pairs
+    assert orc.samples_has_var(54, "", "AG") == "S2 0|1\n"
+    assert orc.samples_has_var(20, "T", "G") == "S2 0|1S10 1|0\n"
+    assert orc.samples_has_var(39, "T", "") is None
+    assert orc.ub_events() == 0
+
+
+def test_type1_closest_var_on_g4(golden_dir, tmp_path):
+    """closest_var (query.h:441-483) restated: mirrored second call, and the step back past the last variant."""
+    _, orc = _open(golden_dir, "x.small.fa", "g4.vcf", tmp_path)
+    n, text = orc.closest_var(8)
+    assert n == 1 and text.split("\n")[1].startswith("9\tG\tA\t")
+    n, text = orc.closest_var(80)       # nothing ahead: walks back to the last site
+    assert n == 1 and text.split("\n")[1].startswith("54\t\tAG\t")
+    n, text = orc.closest_var(1000)     # beyond the reference
+    assert n == 1 and text.split("\n")[1].startswith("54\t\tAG\t")

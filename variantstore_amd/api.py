@@ -262,3 +262,26 @@ class VariantStore:
         sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
         _check(self._lib.vs_query_sample_var_in_ref(self._h, ptr, n, sid, C.byref(h)), "vs_query_sample_var_in_ref")
         return QueryResult(self, h)
+
+    def closest_var(self, positions) -> QueryResult:
+        """Query type 1 (query.h:441-483) for a batch of positions: one result "region" per position;
+        `region_flags & 4` marks the calls for which the reference returns false."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(self._lib.vs_query_closest_var(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint64)), pos.shape[0],
+                                              C.byref(h)), "vs_query_closest_var")
+        return QueryResult(self, h)
+
+    def samples_has_var(self, positions, refs, alts) -> QueryResult:
+        """Query type 7 (query.h:792-823) for a batch of (pos, ref, alt): region_text(q) is the reference's
+        output line, `region_flags & 4` means "There is no such variant!"."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        n = pos.shape[0]
+        if len(refs) != n or len(alts) != n:
+            raise ValueError("one ref and one alt per position expected")
+        r = (C.c_char_p * max(n, 1))(*[x.encode("latin-1") for x in refs])
+        a = (C.c_char_p * max(n, 1))(*[x.encode("latin-1") for x in alts])
+        h = C.c_void_p()
+        _check(self._lib.vs_query_samples_has_var(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint64)), r, a, n,
+                                                  C.byref(h)), "vs_query_samples_has_var")
+        return QueryResult(self, h)

@@ -3,8 +3,8 @@
 // Same sub-commands, flags, log lines and output files as the reference driver
 // (reference src/variantstore.cc:81-156 clipp grammar, src/commands.cc:33-60 construct_main,
 // :64-93 read_regions, :114-215 query_main, src/util.cc:67-80 print_time_elapsed; log lines in
-// spdlog's default pattern "[Y-m-d H:M:S.ms] [level] msg").  Query types 6 and 4 run on the GPU
-// through include/variantstore_hip.h; the other types are not part of this engine.
+// spdlog's default pattern "[Y-m-d H:M:S.ms] [level] msg").  Query types 6, 4, 1 and 7 run on the
+// GPU through include/variantstore_hip.h; types 2, 3 and 5 are not part of this engine.
 //
 // Extensions for batches that do not fit a command line:
 //   -r @FILE            one "<start>:<end>" (or "<start>") per line instead of a comma list
@@ -140,6 +140,84 @@ int construct_main(const Args& a) {
   return EXIT_SUCCESS;
 }
 
+// read_sequences, commands.cc:96-111
+std::vector<std::string> read_sequences(std::string s) {
+  std::vector<std::string> seqs;
+  auto pos = s.find(',');
+  while (true) {
+    seqs.push_back(s.substr(0, pos));
+    if (pos == std::string::npos) break;
+    s = s.substr(pos + 1);
+    pos = s.find(',');
+  }
+  return seqs;
+}
+
+// Query types 1 (closest_var) and 7 (samples_has_var): commands.cc:151-155, 181-189.
+int point_query_main(const Args& a, vs_index* idx, const std::vector<vs_region>& batch) {
+  struct timeval start, end;
+  gettimeofday(&start, nullptr);
+  std::vector<uint64_t> positions;
+  for (auto& b : batch) positions.push_back(b.x);
+  std::vector<std::string> refs, alts;
+  std::vector<const char*> refp, altp;
+  vs_result* res = nullptr;
+  int rc;
+  if (a.type == 7) {
+    alts = read_sequences(a.alt);
+    refs = read_sequences(a.refseq);
+    // the reference indexes refs[i]/alts[i] with the position of the region in the SORTED list and does not
+    // check the lengths (commands.cc:185); a shorter list is out of bounds there and refused here
+    if (refs.size() < batch.size() || alts.size() < batch.size()) {
+      error("-a/-b must list one sequence per region");
+      vs_index_close(idx);
+      return EXIT_FAILURE;
+    }
+    for (size_t i = 0; i < batch.size(); ++i) { refp.push_back(refs[i].c_str()); altp.push_back(alts[i].c_str()); }
+    rc = vs_query_samples_has_var(idx, positions.data(), refp.data(), altp.data(), positions.size(), &res);
+  } else {
+    rc = vs_query_closest_var(idx, positions.data(), positions.size(), &res);
+  }
+  if (rc != VS_OK) die(rc, "query");
+  vs_result_view v;
+  rc = vs_result_get_view(res, 0, &v);
+  if (rc != VS_OK) die(rc, "result");
+  gettimeofday(&end, nullptr);
+  std::ofstream batch_out;
+  if (!a.batch_out.empty()) batch_out.open(a.batch_out);
+  uint32_t query_num = 0;
+  for (uint64_t i = 0; i < v.n_regions; ++i) {
+    const bool found = !(v.region_flags[i] & VS_REGION_NOT_FOUND);
+    if (a.type == 1) info("1. return closest mutation in ref coordinate. " + std::to_string(i));
+    else {
+      info("7. Get samples have given variant. " + std::to_string(i));
+      info("Looking for variant POS: " + std::to_string(positions[i]) + ", REF: " + refs[i] + ", ALT: " + alts[i]);
+      if (!found) error("There is no such variant!");
+    }
+    const char* text = nullptr; uint64_t len = 0;
+    if (found && (batch_out.is_open() || a.verbose)) {
+      rc = vs_result_format_region(res, i, &text, &len);
+      if (rc != VS_OK) die(rc, "result");
+    }
+    if (batch_out.is_open()) {
+      batch_out << "#region " << i << " " << positions[i] << (found ? "" : " not-found") << "\n";
+      if (found) batch_out.write(text, len);
+    }
+    if (a.verbose && found) {  // rewritten by every call that finds something: the last one stays
+      std::ofstream out;
+      out.open(a.outfile);
+      out.write(text, len);
+    }
+    query_num += 1;
+    if (query_num == 10 || query_num == 100 || query_num == 1000)
+      print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+  }
+  print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+  vs_result_free(res);
+  vs_index_close(idx);
+  return EXIT_SUCCESS;
+}
+
 int query_main(const Args& a) {
   info("Loading Index ...");
   info("Loading variant graph ...");
@@ -156,15 +234,16 @@ int query_main(const Args& a) {
   auto regions = read_regions(a.region);
   struct timeval start, end;
   gettimeofday(&start, nullptr);
-  if (a.type != 6 && a.type != 4) {
+  if (a.type != 6 && a.type != 4 && a.type != 1 && a.type != 7) {
     for (size_t i = 0; i < regions.size(); ++i) error("Unsupported query type");
-    error("query types other than 4 and 6 are not part of the GPU engine");
+    error("query types 2, 3 and 5 are not part of the GPU engine");
     vs_index_close(idx);
     return EXIT_FAILURE;
   }
   std::vector<vs_region> batch;
   for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
   vs_result* res = nullptr;
+  if (a.type == 1 || a.type == 7) return point_query_main(a, idx, batch);
   if (a.type == 6) rc = vs_query_var_in_ref(idx, batch.data(), batch.size(), &res);
   else {
     uint32_t sid = 0;

@@ -77,6 +77,7 @@ struct vs_result {
   bool have_totals = false;
   std::string text;
   std::vector<uint32_t> slice_carriers;
+  int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line)
 };
 
 // ------------------------------------------------------------------ helpers
@@ -265,9 +266,16 @@ static int ralloc(vs_result* r, size_t n, T** p) {
   return VS_OK;
 }
 
-// sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk)
+// Strings of a type-7 batch (ref, alt per query) as one byte pool + [2n+1] offsets.
+struct PointStrings {
+  const std::vector<uint8_t>* chars;
+  const std::vector<uint64_t>* off;
+};
+
+// sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
+// point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
-                          const uint32_t* sample_ids = nullptr) {
+                          const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
   uint32_t* dsids = nullptr;
   DevResult& d = r->d;
@@ -293,6 +301,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   uint64_t totals[2] = {0, 0};
   if (n) {
     if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
   }
@@ -323,6 +332,17 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+      if (strings) {
+        uint8_t* dchars = nullptr;
+        uint64_t* doff = nullptr;
+        VS_TRY(ralloc(r, strings->chars->size() + 8, &dchars));
+        VS_TRY(ralloc(r, strings->off->size(), &doff));
+        if (!strings->chars->empty())
+          HIP_TRY(hipMemcpyAsync(dchars, strings->chars->data(), strings->chars->size(), hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(hipMemcpyAsync(doff, strings->off->data(), strings->off->size() * 8, hipMemcpyHostToDevice, idx->stream));
+        hipLaunchKernelGGL(k_has_var_filter, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d,
+                           (const uint8_t*)dchars, (const uint64_t*)doff);
+      }
     }
     HIP_TRY(hipGetLastError());
   }
@@ -666,6 +686,44 @@ int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_
   return VS_OK;
 }
 
+static int run_point_batch(vs_index* idx, const uint64_t* positions, uint64_t n, uint32_t mode, const PointStrings* strings,
+                           vs_result** out) {
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  HIP_TRY(hipSetDevice(idx->device));
+  std::vector<vs_region> regions(n);
+  for (uint64_t i = 0; i < n; ++i) regions[i] = vs_region{positions[i], 0};
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  r->kind = mode == 7 ? 7 : 0;
+  idx->live_results++;
+  int rc = run_var_in_ref(idx, regions.data(), n, r, kNone, nullptr, mode, strings);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_closest_var(vs_index* idx, const uint64_t* positions, uint64_t n, vs_result** out) {
+  if (!idx || !out || (n && !positions)) return fail(VS_ERR_ARG, "null argument");
+  return run_point_batch(idx, positions, n, 1, nullptr, out);
+}
+
+int vs_query_samples_has_var(vs_index* idx, const uint64_t* positions, const char* const* refs, const char* const* alts,
+                             uint64_t n, vs_result** out) {
+  if (!idx || !out || (n && (!positions || !refs || !alts))) return fail(VS_ERR_ARG, "null argument");
+  std::vector<uint8_t> chars;
+  std::vector<uint64_t> off(2 * n + 1, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (!refs[i] || !alts[i]) return fail(VS_ERR_ARG, "null ref/alt string at query %llu", (unsigned long long)i);
+    off[2 * i] = chars.size();
+    chars.insert(chars.end(), (const uint8_t*)refs[i], (const uint8_t*)refs[i] + strlen(refs[i]));
+    off[2 * i + 1] = chars.size();
+    chars.insert(chars.end(), (const uint8_t*)alts[i], (const uint8_t*)alts[i] + strlen(alts[i]));
+  }
+  off[2 * n] = chars.size();
+  PointStrings ps{&chars, &off};
+  return run_point_batch(idx, positions, n, 7, &ps, out);
+}
+
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out) {
   if (!idx || (n && (!pos || !vertex_out))) return fail(VS_ERR_ARG, "null argument");
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
@@ -748,6 +806,29 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   }
   std::string& out = r->text;
   out.clear();
+  if (r->kind == 7) {  // samples_has_var's output line, query.h:811-816: `name gt` pairs with nothing between them
+    for (uint64_t a = a0; a < a1; ++a) {
+      if (r->h_vflags[a] & kVarDropped) continue;
+      const uint32_t* c = car + (r->h_car_begin[a] - c0);
+      for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
+        const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
+        out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
+        out += ' ';
+        out += (gt & GT_1) ? '1' : '0';
+        out += (gt & GT_PHASE) ? '|' : '/';
+        out += (gt & GT_2) ? '1' : '0';
+      }
+      out += '\n';
+    }
+    *text = out.c_str();
+    if (len) *len = out.size();
+    return VS_OK;
+  }
+  if (r->h_flags[q] & VS_REGION_NOT_FOUND) {  // closest_var returned false: the reference writes no file
+    *text = out.c_str();
+    if (len) *len = 0;
+    return VS_OK;
+  }
   out += "Pos\tRef\tAlt\tSamples\n";  // print_header, query.h:38-41
   for (uint64_t a = a0; a < a1; ++a) {
     if (r->h_vflags[a] & kVarDropped) continue;

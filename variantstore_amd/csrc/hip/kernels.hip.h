@@ -21,6 +21,10 @@
 //                       (query.h:268-285, variant_graph.h:875-942): expansion of
 //                       a class bit row + genotype bits into carrier lists.
 //                       This is the dominant kernel.
+// k_point_bounds        one next_variant_in_ref call from a position (query.h:297-436)
+//                       as used by closest_var (query.h:441-483, type 1) and
+//                       samples_has_var (query.h:792-823, type 7)
+// k_has_var_filter      the (pos, ref, alt) match of samples_has_var (query.h:802-803)
 // k_find                Index::find batched
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,7 +35,7 @@ namespace vsamd {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSiteAlwaysDrop = 2;  // branch the reference would emit with an uninitialised var_pos
 constexpr uint32_t kVarDropped = 1;
-constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionSlow = 128;
+constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionNotFound = 4, kRegionSlow = 128;
 
 struct DevImage {
   uint64_t ref_length, nbits;
@@ -774,6 +778,122 @@ __global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst
   dst[4 * q + 1] = (uint64_t)r.q_g0[q] | (fl << 32) | (dropped << 40);
   dst[4 * q + 2] = r.var_count[q];
   dst[4 * q + 3] = r.car_base[q + 1] - r.car_base[q];
+}
+
+// ---------------------------------------------------------------------------
+// Point queries (types 1 and 7).  A single next_variant_in_ref(pos) call with an empty `vars`
+// walks the ref path from find(pos) and stops at the first node with a reportable branch, so its
+// answer is the branch list of ONE ref-path slot: the first slot >= slot(find(pos)) whose sites
+// carry anybody (always-dropped sites have s_ncar == 0, reportable ones >= 1).  s_carpre over
+// rp_cand_prefix is monotone in the slot, so that slot is found by bisection.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slot_of_find(const DevImage& im, uint64_t pos) {  // Index::find, index.h:119-133
+  uint64_t rf;
+  if (pos >= im.ref_length) rf = im.R - 1;
+  else { const uint32_t k = rank1(im, pos); rf = k == 0 ? 0 : k - 1; }
+  return im.rank_to_slot[rf];
+}
+
+__device__ __forceinline__ uint32_t next_valid_slot(const DevImage& im, uint32_t s0) {
+  const uint32_t P = (uint32_t)im.P;
+  if (s0 >= P) return P;
+  const uint64_t base = im.s_carpre[im.rp_cand_prefix[s0]];
+  if (im.s_carpre[im.G] == base) return P;
+  uint32_t lo = s0, hi = P - 1;
+  while (lo < hi) {
+    const uint32_t m = lo + ((hi - lo) >> 1);
+    if (im.s_carpre[im.rp_cand_prefix[m + 1]] > base) hi = m; else lo = m + 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t first_reported_pos(const DevImage& im, uint32_t s) {  // vars[0].var_pos of the call
+  uint32_t g = im.rp_cand_prefix[s];
+  while (im.s_ncar[g] == 0) ++g;
+  return im.s_pos[g];
+}
+
+// mode 1: closest_var, mode 7: samples_has_var.  regions[2q] = pos.
+__global__ void __launch_bounds__(256) k_point_bounds(DevImage im, DevResult r, uint32_t mode) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t pos = r.regions[2 * q];
+  const uint32_t P = (uint32_t)im.P;
+  uint8_t fl = 0;
+  uint32_t chosen = P;
+  const uint32_t s = next_valid_slot(im, slot_of_find(im, pos));
+  if (mode == 7) {
+    chosen = s;
+    if (s == P) fl = kRegionNotFound;
+  } else if (s < P) {  // query.h:451-465
+    const uint64_t next_var_pos = first_reported_pos(im, s);
+    const int cur_pos = (int)(uint32_t)(pos - (next_var_pos - pos));
+    chosen = s;
+    if (cur_pos > 0) {
+      const uint32_t s2 = next_valid_slot(im, slot_of_find(im, (uint64_t)cur_pos));
+      // s2 == P would be prev_var[0] of an empty vector in the reference; next_var is kept then
+      if (s2 < P && first_reported_pos(im, s2) != next_var_pos) chosen = s2;
+    }
+  } else {             // query.h:466-473: step back one position at a time until a call finds something
+    const int cur_pos = (int)(uint32_t)(pos - 1);
+    if (cur_pos > 0) {
+      const uint32_t s2 = next_valid_slot(im, slot_of_find(im, (uint64_t)cur_pos));
+      if (s2 < P) chosen = s2;
+      else if (im.s_carpre[im.G] == 0) fl = kRegionNotFound;  // reaches cur_pos == 1: returns false
+      else {  // the last slot with a reportable branch
+        const uint64_t total = im.s_carpre[im.G];
+        uint32_t lo = 0, hi = P - 1;
+        while (lo < hi) {
+          const uint32_t m = lo + ((hi - lo) >> 1);
+          if (im.s_carpre[im.rp_cand_prefix[m + 1]] >= total) hi = m; else lo = m + 1;
+        }
+        chosen = lo;
+      }
+    }  // else: the loop is not entered, vars stays empty and the call returns true
+  }
+  uint32_t g0 = 0, g1 = 0;
+  if (chosen < P) {
+    g0 = im.rp_cand_prefix[chosen]; g1 = im.rp_cand_prefix[chosen + 1];
+    uint32_t lo = 0, hi = im.n_sus;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (im.sus_g[m] < g0) lo = m + 1; else hi = m; }
+    for (uint32_t k = lo; k < im.n_sus && im.sus_g[k] < g1; ++k) {
+      const uint32_t pv = im.sus_prev[k];
+      if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
+    }
+  }
+  r.q_flags[q] = fl;
+  r.q_g0[q] = g0;
+  r.q_nvar[q] = g1 - g0;
+  r.q_ncar[q] = im.s_carpre[g1] - im.s_carpre[g0];
+}
+
+// samples_has_var: keep the first reported variant whose (ref, var_pos, alt) equals the query's
+// (query.h:802-803); everything else of the slot is dropped.  One thread per query; strings are the
+// caller's bytes, compared with the decoded sequence characters (get_sequence, variant_graph.h:1261-1268).
+__global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r, const uint8_t* chars, const uint64_t* str_off) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t pos = r.regions[2 * q];
+  const uint8_t* ref = chars + str_off[2 * q];
+  const uint64_t ref_len = str_off[2 * q + 1] - str_off[2 * q];
+  const uint8_t* alt = chars + str_off[2 * q + 1];
+  const uint64_t alt_len = str_off[2 * q + 2] - str_off[2 * q + 1];
+  const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
+  bool found = false;
+  for (uint64_t j = 0; j < n; ++j) {
+    const uint64_t a = a0 + j;
+    if (r.r_flags[a] & kVarDropped) continue;
+    bool match = !found && r.r_pos[a] == pos && r.r_ref_len[a] == ref_len && r.r_alt_len[a] == alt_len;
+    if (match) {
+      const char dec[8] = {'A', 'C', 'T', 'G', 'N', 5, 5, 5};  // map_int, util.cc:32-41
+      for (uint64_t i = 0; match && i < ref_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_ref_off[a] + i] & 7] == ref[i];
+      for (uint64_t i = 0; match && i < alt_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_alt_off[a] + i] & 7] == alt[i];
+    }
+    if (match) found = true;
+    else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
+  }
+  r.var_count[q] = found ? 1 : 0;
+  if (!found) r.q_flags[q] |= kRegionNotFound;
 }
 
 // Index::find batched (index.h:119-133)
