@@ -122,13 +122,30 @@ int vs_query_closest_var(vs_index* idx, const uint64_t* positions, uint64_t n, v
  * with no separator, then a newline) and carries VS_REGION_NOT_FOUND otherwise ("There is no such variant!"). */
 int vs_query_samples_has_var(vs_index* idx, const uint64_t* positions, const char* const* refs, const char* const* alts,
                              uint64_t n, vs_result** out);
+/* Query types 2 and 3, query_sample_from_ref / query_sample_from_sample (include/query.h:118-190, :196-261;
+ * src/commands.cc:156-165): the sequence of sample sample_ids[i] over regions[i] = [x, y) in reference coordinates
+ * (sample_coordinates == 0) or in the sample's own coordinates (!= 0).  The result is a SEQUENCE result: read it with
+ * vs_result_get_sequences or vs_result_format_region (sequence + '\n', the reference's output file).  Regions on
+ * which the reference dies of an uncaught std::out_of_range carry VS_REGION_INVALID, regions on which its backward
+ * search never ends carry VS_REGION_ENDLESS; both give an empty sequence.  Needs an index with sample coordinates
+ * (every index built from a VCF or loaded from disk has them). */
+int vs_query_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int sample_coordinates,
+                        vs_result** out);
+/* Query type 5, get_sample_var_in_sample (include/query.h:490-612; src/commands.cc:171-175): the variants on the path
+ * of sample_ids[i] over regions[i] in the SAMPLE's coordinates; an ordinary variant-table result.  var_pos follows the
+ * reference: the sample-coordinate index for substitutions and deletions, the reference index for insertions. */
+int vs_query_sample_var_in_sample(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, vs_result** out);
+/* host view of a sequence result: region i is chars[seq_begin[i] .. seq_begin[i+1]) */
+int vs_result_get_sequences(vs_result* r, uint64_t* n_regions, const uint8_t** region_flags, const uint64_t** seq_begin,
+                            const char** chars);
 /* batched Index::find (index.h:119-133): vertex id of the ref node covering each position */
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out);
 
 /* Result of one batch.  Arrays live in HBM until a view is requested. */
 enum { VS_REGION_EMPTY = 1,   /* Index::is_empty early-out fired (query.h:745-756 prints the other label) */
        VS_REGION_INVALID = 2, /* pos_x < 1: the reference aborts (index.h:151-154) */
-       VS_REGION_NOT_FOUND = 4 /* types 1 and 7: closest_var returned false / "There is no such variant!" */ };
+       VS_REGION_NOT_FOUND = 4, /* types 1 and 7: closest_var returned false / "There is no such variant!" */
+       VS_REGION_ENDLESS = 8   /* types 3 and 5: the reference's backward search (query.h:213-218) never terminates */ };
 enum { VS_VAR_DROPPED = 1 };  /* suppressed by the reference's "already seen" rule, query.h:397-414 */
 #define VS_CARRIER_ID(c) ((c) & 0x1FFFFFFFu)
 #define VS_CARRIER_GT(c) ((c) >> 29)         /* bit0 phase ('|'), bit1 gt_1, bit2 gt_2 */

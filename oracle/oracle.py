@@ -41,6 +41,11 @@ def _load():
         lib.vso_closest_var.argtypes = [C.c_void_p, C.c_uint64]
         lib.vso_samples_has_var.restype = C.c_int
         lib.vso_samples_has_var.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p]
+        for fn in (lib.vso_query_sample_from_ref, lib.vso_query_sample_from_sample, lib.vso_get_sample_var_in_sample):
+            fn.restype = C.c_long
+            fn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
+        lib.vso_last_seq.restype = C.c_void_p
+        lib.vso_last_seq.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.vso_raw_text.restype = C.c_void_p
         lib.vso_raw_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.vso_last_text.restype = C.c_void_p
@@ -103,6 +108,27 @@ class Oracle:
         n = C.c_uint64()
         p = self._lib.vso_raw_text(self._h, C.byref(n))
         return C.string_at(p, n.value).decode("latin-1")
+
+    def _last_seq(self):
+        n = C.c_uint64()
+        p = self._lib.vso_last_seq(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode("latin-1")
+
+    def query_sample_from_ref(self, x, y, sample):
+        """Query type 2: (code, sequence).  code >= 0 is the length; -1 the reference does not terminate,
+        -2 unknown sample, -3 the reference dies of an uncaught std::out_of_range."""
+        n = self._lib.vso_query_sample_from_ref(self._h, x, y, sample.encode())
+        return n, (self._last_seq() if n >= 0 else None)
+
+    def query_sample_from_sample(self, x, y, sample):
+        """Query type 3, same return convention as query_sample_from_ref."""
+        n = self._lib.vso_query_sample_from_sample(self._h, x, y, sample.encode())
+        return n, (self._last_seq() if n >= 0 else None)
+
+    def get_sample_var_in_sample(self, x, y, sample):
+        """Query type 5: (n_variants, text); n == -1 non-terminating, -2 unknown sample."""
+        n = self._lib.vso_get_sample_var_in_sample(self._h, x, y, sample.encode())
+        return n, (self.last_text() if n >= 0 else None)
 
     def last_text(self):
         n = C.c_uint64()

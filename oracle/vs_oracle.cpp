@@ -21,6 +21,8 @@
 //   get_prev_vertex_with_sample, get_sample_var_in_ref     include/query.h:57-113, 618-729
 //   print_header / print_var                               include/query.h:38-50
 //   closest_var (type 1), samples_has_var (type 7)         include/query.h:441-483, 792-823
+//   query_sample_from_ref (2), query_sample_from_sample (3) include/query.h:118-261
+//   get_sample_var_in_sample (5)                           include/query.h:490-612
 //
 // Input: the "plain dump" of an index (HostGraph::write_plain) -- the decoded
 // content of the index directory.  Neighbour sets are rebuilt here with the
@@ -39,6 +41,7 @@
 #include <cstdio>
 #include <cstring>
 #include <queue>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -613,6 +616,173 @@ struct Oracle {
     return 0;
   }
 
+  // ---- types 2 and 3: a sample's sequence over [pos_x, pos_y) in ref / sample coordinates ----
+  // Return codes shared by the three sample-coordinate queries:
+  //   >= 0 ok; -1 the reference does not terminate; -2 unknown sample (the reference aborts);
+  //   -3 std::out_of_range from substr (uncaught in the reference: terminate)
+  std::string last_seq;
+
+  // the four-way window logic shared by query.h:160-177 and :236-247; returns true when the walk stops
+  static bool window_step(std::string& seq, bool& record_seq, const std::string& temp, uint64_t cur, uint64_t next,
+                          uint64_t pos_x, uint64_t pos_y) {
+    if (record_seq == true && next < pos_y) {
+      seq += temp;
+    } else if (record_seq == true && next >= pos_y) {
+      seq += temp.substr(0, pos_y - cur);
+      return true;
+    } else if (next >= pos_x && next < pos_y) {
+      record_seq = true;
+      seq += temp.substr(pos_x - cur);
+    } else if (next >= pos_x && next >= pos_y) {
+      seq = temp.substr(pos_x - cur, pos_y - pos_x);
+      return true;
+    }
+    return false;
+  }
+
+  long query_sample_from_ref(const uint64_t pos_x, const uint64_t pos_y, const std::string& sample_id) {  // :118-190
+    last_seq.clear();
+    if (sampleid_map.find(sample_id) == sampleid_map.end()) return -2;
+    std::string seq = "";
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t closest_v = get_prev_vertex_with_sample(pos_x, sample_id, ref_pos, sample_pos);
+    PathIterator it(this, closest_v, sample_id);
+    bool record_seq = false;
+    std::string temp;
+    try {
+      while (!it.done()) {
+        temp.assign(get_sequence(*(*it)));
+        uint64_t l = (*it)->length;
+        uint64_t next_ref_pos = ref_pos + l;
+        VGIterator bfs_it(this, (*it)->vertex_id, 1);
+        ++bfs_it;
+        while (!bfs_it.done()) {
+          uint32_t v = (*bfs_it)->vertex_id;
+          SampleInfo sample;
+          if (get_sample_from_vertex_if_exists(v, REF, sample)) { next_ref_pos = sample.index; break; }
+          ++bfs_it;
+        }
+        if (window_step(seq, record_seq, temp, ref_pos, next_ref_pos, pos_x, pos_y)) break;
+        ++it;
+        ref_pos = next_ref_pos;
+      }
+    } catch (const std::out_of_range&) { return -3; }
+    last_seq.swap(seq);
+    return (long)last_seq.size();
+  }
+
+  // the backward search of query.h:213-218 and :507-512; false when it would not terminate
+  bool rewind_to_sample_pos(const uint64_t pos_x, const std::string& sample_id, uint32_t& closest_v, uint64_t& ref_pos,
+                            uint64_t& sample_pos) {
+    closest_v = get_prev_vertex_with_sample(pos_x, sample_id, ref_pos, sample_pos);
+    size_t guard = 0;
+    while (sample_pos >= pos_x && closest_v > 0) {
+      uint64_t pos = ref_pos;
+      const uint64_t before_ref = ref_pos, before_sample = sample_pos;
+      const uint32_t before_v = closest_v;
+      closest_v = get_prev_vertex_with_sample(pos, sample_id, ref_pos, sample_pos);
+      // the search is a pure function of `pos`: an unchanged state repeats forever in the reference
+      if (ref_pos == before_ref && sample_pos == before_sample && closest_v == before_v) { ub_events++; return false; }
+      if (++guard > 4 * vertices.size() + 64) { ub_events++; return false; }
+    }
+    return true;
+  }
+
+  long query_sample_from_sample(const uint64_t pos_x, const uint64_t pos_y, const std::string& sample_id) {  // :196-261
+    last_seq.clear();
+    if (sampleid_map.find(sample_id) == sampleid_map.end()) return -2;
+    std::string seq = "";
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t closest_v = 0;
+    if (!rewind_to_sample_pos(pos_x, sample_id, closest_v, ref_pos, sample_pos)) return -1;
+    PathIterator it(this, closest_v, sample_id);
+    bool record_seq = false;
+    std::string temp;
+    try {
+      while (!it.done()) {
+        temp.assign(get_sequence(*(*it)));
+        uint64_t l = (*it)->length;
+        uint64_t next_sample_pos = sample_pos + l;
+        if (window_step(seq, record_seq, temp, sample_pos, next_sample_pos, pos_x, pos_y)) break;
+        ++it;
+        sample_pos = next_sample_pos;
+      }
+    } catch (const std::out_of_range&) { return -3; }
+    last_seq.swap(seq);
+    return (long)last_seq.size();
+  }
+
+  // ---- type 5: a sample's variants over [pos_x, pos_y) in the sample's own coordinates ----
+  long get_sample_var_in_sample(const uint64_t pos_x, const uint64_t pos_y, const std::string& sample_id) {  // :490-612
+    std::vector<Variant> vars;
+    last_empty = false;
+    if (sampleid_map.find(sample_id) == sampleid_map.end()) { last_vars.swap(vars); return -2; }
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t closest_v = 0;
+    if (!rewind_to_sample_pos(pos_x, sample_id, closest_v, ref_pos, sample_pos)) { last_vars.swap(vars); return -1; }
+    closest_v = find(ref_pos);
+    SampleInfo sample;
+    uint64_t seq_len = 0;
+    if (get_sample_from_vertex_if_exists(closest_v, REF, sample)) {
+      seq_len = ref_pos - sample.index;
+      ref_pos = sample.index;
+    } else ub_events++;  // "reference node is expected to be found!"
+    sample_pos = sample_pos - seq_len;
+    PathIterator it(this, closest_v, sample_id);
+    std::string cur_ref;
+    const size_t cap = 4 * vertices.size() + 64;
+    size_t steps = 0;
+    while (!it.done()) {
+      if (sample_pos >= pos_y) break;
+      if (++steps > cap) { ub_events++; last_vars.swap(vars); return -1; }
+      uint32_t cur_v = (*it)->vertex_id;
+      Variant var;
+      uint64_t l = (*it)->length;
+      uint64_t next_ref_pos = ref_pos + l;
+      uint64_t next_sample_pos = sample_pos + l;
+      std::string next_ref;
+      VGIterator bfs_it(this, (*it)->vertex_id, 1);
+      ++bfs_it;
+      while (!bfs_it.done()) {
+        uint32_t v = (*bfs_it)->vertex_id;
+        if (get_sample_from_vertex_if_exists(v, REF, sample)) {
+          next_ref_pos = sample.index;
+          next_ref = get_sequence(*(*bfs_it));
+        }
+        ++bfs_it;
+      }
+      if (sample_pos > pos_x && get_sample_from_vertex_if_exists(cur_v, sample_id, sample)) {
+        std::string alt;
+        if (ref_pos == next_ref_pos) {  // insertion
+          cur_ref = "";
+          alt = get_sequence(*(*it));
+          var.var_pos = ref_pos;
+        } else if (get_sample_from_vertex_if_exists(cur_v, REF, sample)) {  // deletion
+          alt = "";
+          get_sample_from_vertex_if_exists(cur_v, sample_id, sample);
+          var.var_pos = sample.index;
+          uint32_t v = find(ref_pos - 1);
+          cur_ref = get_sequence(get_vertex(v));
+        } else {  // substitution
+          alt = get_sequence(*(*it));
+          get_sample_from_vertex_if_exists(cur_v, sample_id, sample);
+          var.var_pos = sample.index;
+        }
+        var.pos_valid = true;
+        var.alt.assign(alt);
+        var.ref = cur_ref;
+        get_samples((*it), var.samples);
+        vars.push_back(var);
+      }
+      cur_ref = next_ref;
+      ref_pos = next_ref_pos;
+      sample_pos = next_sample_pos;
+      ++it;
+    }
+    last_vars.swap(vars);
+    return (long)last_vars.size();
+  }
+
   void format_last() {
     last_text.clear();
     print_header(last_text);
@@ -719,6 +889,23 @@ long vso_closest_var(void* h, uint64_t pos) { return ((Oracle*)h)->closest_var(p
 // type 7.  1 = found (vso_raw_text holds the line written to the output file), 0 = "There is no such variant!"
 int vso_samples_has_var(void* h, uint64_t pos, const char* ref, const char* alt) {
   return ((Oracle*)h)->samples_has_var(pos, ref, alt);
+}
+// types 2 / 3: length of the sequence (vso_last_seq holds it; the output file is the sequence + '\n'),
+// or -1 non-terminating, -2 unknown sample, -3 the reference dies of an uncaught std::out_of_range
+long vso_query_sample_from_ref(void* h, uint64_t x, uint64_t y, const char* sample) {
+  return ((Oracle*)h)->query_sample_from_ref(x, y, sample);
+}
+long vso_query_sample_from_sample(void* h, uint64_t x, uint64_t y, const char* sample) {
+  return ((Oracle*)h)->query_sample_from_sample(x, y, sample);
+}
+const char* vso_last_seq(void* h, uint64_t* len) {
+  Oracle* o = (Oracle*)h;
+  if (len) *len = o->last_seq.size();
+  return o->last_seq.c_str();
+}
+// type 5: number of variants (vso_last_text formats them), -1 / -2 as above
+long vso_get_sample_var_in_sample(void* h, uint64_t x, uint64_t y, const char* sample) {
+  return ((Oracle*)h)->get_sample_var_in_sample(x, y, sample);
 }
 const char* vso_raw_text(void* h, uint64_t* len) {
   Oracle* o = (Oracle*)h;

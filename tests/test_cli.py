@@ -119,3 +119,36 @@ def test_query_types_1_and_7(golden_dir, tmp_path):
     assert re.match(r"Query2: Total Time Elapsed: \d+\.\d{6}seconds", msgs[-1])
     assert open(ofile).read() == "Pos\tRef\tAlt\tSamples\n54\t\tAG\tS2(0|1) \n"
     assert "#region 0 8\nPos\tRef\tAlt\tSamples\n9\tG\tA\tS2(1/1) S10(0|1) S1(1|0) \n" in open(str(tmp_path / "b.txt")).read()
+
+
+@pytest.mark.gpu
+def test_query_types_2_3_5(golden_dir, tmp_path):
+    """`-t 2`, `-t 3` (sample sequences) and `-t 5` (variants in the sample's coordinates) on the G4 index;
+    expected strings are the CPU oracle's (tests/test_gpu_parity.py checks those at scale)."""
+    d = str(tmp_path / "ser")
+    os.makedirs(d)
+    out = subprocess.run([CLI, "construct", "-r", os.path.join(golden_dir, "x.small.fa"), "-v",
+                          os.path.join(golden_dir, "g4.vcf"), "-p", d], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ofile = str(tmp_path / "o.txt")
+    ref = "CAAATAAGGCTTGGAAATTTTCTGGAGTTCTATTATATTCCAACTCTCTGGTTCCTGGTGCTATGTGTAACTAGTAATGG"
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "2", "-r", "1:80", "-s", "S2", "-m", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "2. Get sample's sequence in ref coordinate. 0" in _msgs(out.stdout)
+    # S2 over ref [1,80): G>A at 9, T>C at 20, AG inserted after 54
+    want = ref[:8] + "A" + ref[9:19] + "C" + ref[20:54] + "AG" + ref[54:79]
+    assert open(ofile).read() == want + "\n"
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "3", "-r", "1:80", "-s", "S2", "-m", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "3. Get sample's sequence in sample's coordinate. 0" in _msgs(out.stdout)
+    assert open(ofile).read() == want[:79] + "\n"        # 79 bases of the SAMPLE's sequence
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "5", "-r", "1:80", "-s", "S10", "-m", "1", "-o", ofile, "-v"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    assert "5. Get sample's variants in sample coordinate. 0" in msgs
+    assert "Number of variants get_sample_var_in_sample: 3" in msgs
+    assert open(ofile).read() == ("Pos\tRef\tAlt\tSamples\n9\tG\tA\tS2(1/1) S10(0|1) S1(1|0) \n"
+                                  "20\t\tC\tS2(0|1) S10(1|0) \n39\tT\t\tS10(0|1) S1(1|0) \n")

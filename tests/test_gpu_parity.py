@@ -402,3 +402,90 @@ def test_type7_samples_has_var_matches_oracle(seed, kw, tmp_path):
             assert not (flags[q] & 4) and res.region_text(q) == want, qs[q]
     assert found > 20
     res.close()
+
+
+# ---- sample-coordinate queries (types 2, 3, 5): SURVEY.md §8(f) rank 3 ----
+SC_COHORTS = [
+    (401, dict()),
+    (402, dict(p_same=0.2, p_near=0.6, p_multi=0.2)),
+    (403, dict(n_samples=70, carrier_p=0.2, ref_len=3000, n_rows=90)),
+    (404, dict(n_samples=40, carrier_p=0.004, ref_len=2500, n_rows=60)),   # explicit sample ids
+    (405, dict(sample_names=["S2", "S10", "S1", "x", "A9"], p_ins=0.25, p_del=0.25)),  # column order != name order
+]
+
+
+def _sc_regions(rng, L):
+    regions = random_regions(rng, L, 60, max_len=400)
+    regions += [(0, 10), (0, 0), (1, 1), (3, 2), (L - 3, L + 30)]
+    regions += [(x, x + 1) for x in range(1, 40)]
+    return regions
+
+
+@pytest.mark.parametrize("seed,kw", SC_COHORTS)
+@pytest.mark.parametrize("coords", [0, 1])
+def test_types_2_and_3_sample_sequences_match_oracle(seed, kw, coords, tmp_path):
+    """query_sample_from_ref / query_sample_from_sample: the sequence string of every sample (and of "ref")
+    over random and edge-shaped regions; inputs on which the reference throws or never returns are flagged."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = vs.info().ref_length
+    rng = np.random.default_rng(seed)
+    regions = _sc_regions(rng, L)
+    samples = ["ref"] + [names[i] for i in rng.choice(len(names), size=min(4, len(names)), replace=False)]
+    ok = 0
+    for smp in samples:
+        res = vs.query_sample_seq(regions, smp, sample_coordinates=bool(coords))
+        flags, seqs = res.sequences()
+        for q, (x, y) in enumerate(regions):
+            n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, smp)
+            if n == -1:
+                assert flags[q] & 8, (smp, x, y)
+            elif n == -3:
+                assert flags[q] & 2, (smp, x, y)
+            else:
+                assert not flags[q] and seqs[q] == seq, (smp, x, y)
+                assert res.region_text(q) == seq + "\n"
+                ok += 1
+        res.close()
+    assert ok > 200
+
+
+@pytest.mark.parametrize("seed,kw", SC_COHORTS)
+def test_type5_sample_variants_in_sample_coordinates_match_oracle(seed, kw, tmp_path):
+    fasta, vcf, names = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = vs.info().ref_length
+    rng = np.random.default_rng(seed + 1)
+    regions = _sc_regions(rng, L)
+    samples = ["ref"] + [names[i] for i in rng.choice(len(names), size=min(4, len(names)), replace=False)]
+    ok = nvar = 0
+    for smp in samples:
+        res = vs.get_sample_var_in_sample(regions, smp)
+        view = res.view(False)
+        for q, (x, y) in enumerate(regions):
+            n, text = orc.get_sample_var_in_sample(x, y, smp)
+            if n == -1:
+                assert view["region_flags"][q] & 8, (smp, x, y)
+                continue
+            assert not view["region_flags"][q] and res.region_text(q) == text, (smp, x, y)
+            assert int(view["var_count"][q]) == n
+            ok += 1
+            nvar += n
+        res.close()
+    assert ok > 200 and nvar > 100
+
+
+def test_sample_sequence_batch_with_one_sample_per_region(tmp_path):
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 410, n_samples=9, p_near=0.5)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(410)
+    regions = random_regions(rng, vs.info().ref_length, 150, max_len=800)
+    per = [names[i % len(names)] for i in range(len(regions))]
+    for coords in (False, True):
+        res = vs.query_sample_seq(regions, per, sample_coordinates=coords)
+        flags, seqs = res.sequences()
+        for q, (x, y) in enumerate(regions):
+            n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, per[q])
+            if n >= 0:
+                assert seqs[q] == seq, (q, per[q], coords)
+        assert res.totals()[3] == sum(len(s) for s in seqs)

@@ -71,6 +71,20 @@ class QueryResult:
         _check(self._lib.vs_result_totals(self._h, *[C.byref(x) for x in v]), "vs_result_totals")
         return tuple(int(x.value) for x in v)
 
+    def sequences(self):
+        """(region_flags, list of str) of a sequence result (query types 2 and 3)."""
+        n = C.c_uint64()
+        fl = C.POINTER(C.c_uint8)()
+        beg = C.POINTER(C.c_uint64)()
+        chars = C.c_char_p()
+        _check(self._lib.vs_result_get_sequences(self._h, C.byref(n), C.byref(fl), C.byref(beg), C.byref(chars)),
+               "vs_result_get_sequences")
+        q = int(n.value)
+        flags = np.ctypeslib.as_array(fl, shape=(q,)).copy() if q else np.zeros(0, np.uint8)
+        b = np.ctypeslib.as_array(beg, shape=(q + 1,)).copy() if q else np.zeros(1, np.uint64)
+        raw = C.string_at(C.cast(chars, C.c_void_p).value, int(b[q])) if q else b""
+        return flags, [raw[int(b[i]):int(b[i + 1])].decode("latin-1") for i in range(q)]
+
     def digest(self):
         d = C.c_uint64()
         _check(self._lib.vs_result_digest(self._h, C.byref(d)), "vs_result_digest")
@@ -284,4 +298,32 @@ class VariantStore:
         h = C.c_void_p()
         _check(self._lib.vs_query_samples_has_var(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint64)), r, a, n,
                                                   C.byref(h)), "vs_query_samples_has_var")
+        return QueryResult(self, h)
+
+    def _sample_ids(self, sample, n):
+        if isinstance(sample, (list, tuple, np.ndarray)):
+            sids = np.ascontiguousarray([self.sample_id(x) if isinstance(x, str) else int(x) for x in sample], dtype=np.uint32)
+            if sids.shape[0] != n:
+                raise ValueError("one sample per region expected")
+            return sids
+        sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
+        return np.full(max(n, 1), sid, dtype=np.uint32)
+
+    def query_sample_seq(self, regions, sample, sample_coordinates=False) -> QueryResult:
+        """Query type 2 (query_sample_from_ref, query.h:118-190) or, with sample_coordinates, type 3
+        (query_sample_from_sample, query.h:196-261).  `sample` is one name/id or one per region."""
+        arr, ptr, n = _regions_array(regions)
+        sids = self._sample_ids(sample, n)
+        h = C.c_void_p()
+        _check(self._lib.vs_query_sample_seq(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             1 if sample_coordinates else 0, C.byref(h)), "vs_query_sample_seq")
+        return QueryResult(self, h)
+
+    def get_sample_var_in_sample(self, regions, sample) -> QueryResult:
+        """Query type 5 (query.h:490-612)."""
+        arr, ptr, n = _regions_array(regions)
+        sids = self._sample_ids(sample, n)
+        h = C.c_void_p()
+        _check(self._lib.vs_query_sample_var_in_sample(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                       C.byref(h)), "vs_query_sample_var_in_sample")
         return QueryResult(self, h)

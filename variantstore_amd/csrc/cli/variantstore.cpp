@@ -3,8 +3,8 @@
 // Same sub-commands, flags, log lines and output files as the reference driver
 // (reference src/variantstore.cc:81-156 clipp grammar, src/commands.cc:33-60 construct_main,
 // :64-93 read_regions, :114-215 query_main, src/util.cc:67-80 print_time_elapsed; log lines in
-// spdlog's default pattern "[Y-m-d H:M:S.ms] [level] msg").  Query types 6, 4, 1 and 7 run on the
-// GPU through include/variantstore_hip.h; types 2, 3 and 5 are not part of this engine.
+// spdlog's default pattern "[Y-m-d H:M:S.ms] [level] msg").  All seven query types run on the GPU
+// through include/variantstore_hip.h.
 //
 // Extensions for batches that do not fit a command line:
 //   -r @FILE            one "<start>:<end>" (or "<start>") per line instead of a comma list
@@ -153,6 +153,59 @@ std::vector<std::string> read_sequences(std::string s) {
   return seqs;
 }
 
+// Query types 2 (query_sample_from_ref) and 3 (query_sample_from_sample): commands.cc:156-165.
+int sequence_query_main(const Args& a, vs_index* idx, const std::vector<vs_region>& batch) {
+  struct timeval start, end;
+  gettimeofday(&start, nullptr);
+  uint32_t sid = 0;
+  if (vs_index_sample_id(idx, a.sample.c_str(), &sid) != VS_OK) { error("Sample not found"); abort(); }  // variant_graph.h:2010-2013
+  std::vector<uint32_t> sids(batch.size(), sid);
+  vs_result* res = nullptr;
+  int rc = vs_query_sample_seq(idx, batch.data(), batch.size(), sids.data(), a.type == 3 ? 1 : 0, &res);
+  if (rc != VS_OK) die(rc, "query");
+  uint64_t nq = 0;
+  const uint8_t* flags = nullptr;
+  rc = vs_result_get_sequences(res, &nq, &flags, nullptr, nullptr);
+  if (rc != VS_OK) die(rc, "result");
+  gettimeofday(&end, nullptr);
+  std::ofstream batch_out;
+  if (!a.batch_out.empty()) batch_out.open(a.batch_out);
+  uint32_t query_num = 0;
+  for (uint64_t i = 0; i < nq; ++i) {
+    if (a.type == 2) info("2. Get sample's sequence in ref coordinate. " + std::to_string(i));
+    else info("3. Get sample's sequence in sample's coordinate. " + std::to_string(i));
+    if (flags[i] & VS_REGION_INVALID) {  // an uncaught exception of std::string::substr in the reference
+      std::cerr << "terminate called after throwing an instance of 'std::out_of_range'\n";
+      abort();
+    }
+    if (flags[i] & VS_REGION_ENDLESS) {
+      error("the reference's backward search does not terminate on region " + std::to_string(batch[i].x) + ":" + std::to_string(batch[i].y));
+      return EXIT_FAILURE;
+    }
+    const char* text = nullptr; uint64_t len = 0;
+    if (batch_out.is_open() || a.verbose) {
+      rc = vs_result_format_region(res, i, &text, &len);
+      if (rc != VS_OK) die(rc, "result");
+    }
+    if (batch_out.is_open()) {
+      batch_out << "#region " << i << " " << batch[i].x << ":" << batch[i].y << "\n";
+      batch_out.write(text, len);
+    }
+    if (a.verbose && i + 1 == nq) {
+      std::ofstream out;
+      out.open(a.outfile);
+      out.write(text, len);
+    }
+    query_num += 1;
+    if (query_num == 10 || query_num == 100 || query_num == 1000)
+      print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+  }
+  print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+  vs_result_free(res);
+  vs_index_close(idx);
+  return EXIT_SUCCESS;
+}
+
 // Query types 1 (closest_var) and 7 (samples_has_var): commands.cc:151-155, 181-189.
 int point_query_main(const Args& a, vs_index* idx, const std::vector<vs_region>& batch) {
   struct timeval start, end;
@@ -234,22 +287,26 @@ int query_main(const Args& a) {
   auto regions = read_regions(a.region);
   struct timeval start, end;
   gettimeofday(&start, nullptr);
-  if (a.type != 6 && a.type != 4 && a.type != 1 && a.type != 7) {
-    for (size_t i = 0; i < regions.size(); ++i) error("Unsupported query type");
-    error("query types 2, 3 and 5 are not part of the GPU engine");
+  if (a.type < 1 || a.type > 7) {
+    for (size_t i = 0; i < regions.size(); ++i) error("Unsupported query type");  // commands.cc:191
     vs_index_close(idx);
-    return EXIT_FAILURE;
+    return EXIT_SUCCESS;
   }
   std::vector<vs_region> batch;
   for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
   vs_result* res = nullptr;
   if (a.type == 1 || a.type == 7) return point_query_main(a, idx, batch);
+  if (a.type == 2 || a.type == 3) return sequence_query_main(a, idx, batch);
   if (a.type == 6) rc = vs_query_var_in_ref(idx, batch.data(), batch.size(), &res);
   else {
     uint32_t sid = 0;
     rc = vs_index_sample_id(idx, a.sample.c_str(), &sid);
-    if (rc != VS_OK) { error("Sample not found: " + a.sample); die(rc, "query"); }
-    rc = vs_query_sample_var_in_ref(idx, batch.data(), batch.size(), sid, &res);
+    if (rc != VS_OK) { error("Sample not found"); abort(); }  // variant_graph.h:2010-2013
+    if (a.type == 4) rc = vs_query_sample_var_in_ref(idx, batch.data(), batch.size(), sid, &res);
+    else {
+      std::vector<uint32_t> sids(batch.size(), sid);
+      rc = vs_query_sample_var_in_sample(idx, batch.data(), batch.size(), sids.data(), &res);
+    }
   }
   if (rc != VS_OK) die(rc, "query");
   vs_result_view v;
@@ -262,13 +319,19 @@ int query_main(const Args& a) {
   uint32_t query_num = 0;
   for (uint64_t i = 0; i < v.n_regions; ++i) {
     if (a.type == 6) info("6. Get variants in ref coordinate. " + std::to_string(i));
+    else if (a.type == 5) info("5. Get sample's variants in sample coordinate. " + std::to_string(i));
     else info("4. Get sample's variants in ref coordinate. " + std::to_string(i));
+    if (v.region_flags[i] & VS_REGION_ENDLESS) {
+      error("the reference's backward search does not terminate on region " + std::to_string(batch[i].x) + ":" + std::to_string(batch[i].y));
+      return EXIT_FAILURE;
+    }
     if (v.region_flags[i] & VS_REGION_INVALID) {  // index.h:151-154
       error("Can't find node corresponding to pos " + std::to_string(batch[i].x));
       abort();
     }
     // query.h:746 prints the type-4 label on the early-out of type 6 as well
     const char* label = (a.type == 6 && !(v.region_flags[i] & VS_REGION_EMPTY)) ? "get_var_in_ref" : "get_sample_var_in_ref";
+    if (a.type == 5) label = "get_sample_var_in_sample";  // query.h:599
     std::cout << "Number of variants " << label << ": " << v.var_count[i] << '\n';
     if (batch_out.is_open()) {
       const char* text; uint64_t len;

@@ -77,8 +77,17 @@ struct vs_result {
   bool have_totals = false;
   std::string text;
   std::vector<uint32_t> slice_carriers;
-  int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line)
+  int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line); 2 / 3: sequences
+  // sequence results (query types 2 and 3)
+  DevSeqResult sq{};
+  uint64_t seq_bytes = 0;
+  bool have_seq = false;
+  std::vector<uint64_t> h_byte_begin;
+  std::vector<uint8_t> h_chars;
 };
+
+#define VS_NOT_SEQ(r) \
+  if ((r)->kind == 2 || (r)->kind == 3) return fail(VS_ERR_ARG, "a sequence result (query types 2/3) has no variant table; use vs_result_get_sequences")
 
 // ------------------------------------------------------------------ helpers
 static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf>* owner) {
@@ -193,6 +202,8 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.cls_list_ids, &d.cls_list_ids));
   VS_TRY(upload_image(idx, im.gt_nibbles, &d.gt_nibbles));
   VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
+  VS_TRY(upload_image(idx, im.car_index, &d.car_index));
+  d.has_car_index = im.car_index.empty() ? 0u : 1u;
   VS_TRY(upload_image(idx, im.seq_codes, &d.seq_codes));
   const uint64_t G = d.G;
   VS_TRY(alloc_image(idx, G, &d.s_pos));
@@ -275,7 +286,8 @@ struct PointStrings {
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
-                          const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr) {
+                          const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
+                          int walk_mode = 4) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
   uint32_t* dsids = nullptr;
   DevResult& d = r->d;
@@ -300,7 +312,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   std::vector<DevBuf> scratch;
   uint64_t totals[2] = {0, 0};
   if (n) {
-    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
     else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
@@ -328,7 +341,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.S, &d.carriers));
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
@@ -403,6 +417,73 @@ static int fetch_headers(vs_result* r) {
   HIP_TRY(hipStreamSynchronize(idx->stream));
   for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
   r->have_headers = true;
+  return VS_OK;
+}
+
+// Query types 2 and 3: count pieces and bytes per region, scan, emit the piece list, decode it.
+static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r) {
+  DevSeqResult& q = r->sq;
+  q.Q = n;
+  r->d.Q = n;
+  uint64_t* dreg = nullptr;
+  uint32_t* dsids = nullptr;
+  VS_TRY(ralloc(r, 2 * n, &dreg));
+  VS_TRY(ralloc(r, n, &dsids));
+  q.regions = dreg; q.sids = dsids;
+  VS_TRY(ralloc(r, n, &q.q_flags));
+  VS_TRY(ralloc(r, n, &q.q_nseg));
+  VS_TRY(ralloc(r, n, &q.q_nbytes));
+  VS_TRY(ralloc(r, n + 1, &q.seg_begin));
+  VS_TRY(ralloc(r, n + 1, &q.byte_begin));
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
+    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
+  }
+  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  if (n) {
+    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, false>), grid, block, 0, idx->stream, idx->d, q);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, false>), grid, block, 0, idx->stream, idx->d, q);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<DevBuf> scratch;
+  uint64_t totals[2] = {0, 0};
+  VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
+  VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
+  HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  VS_TRY(ralloc(r, totals[0], &q.seg_src));
+  VS_TRY(ralloc(r, totals[0], &q.seg_len));
+  VS_TRY(ralloc(r, totals[0], &q.seg_dst));
+  VS_TRY(ralloc(r, totals[1], &q.chars));
+  r->seq_bytes = totals[1];
+  if (n) {
+    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, true>), grid, block, 0, idx->stream, idx->d, q);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, true>), grid, block, 0, idx->stream, idx->d, q);
+    hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, q);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  release_bufs(idx, scratch);
+  vs_timing& t = idx->timing;
+  t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
+  t.fill_launches = 0;
+  return VS_OK;
+}
+
+static int fetch_sequences(vs_result* r) {
+  if (r->have_seq) return VS_OK;
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(fetch(idx, r->h_flags, (const uint8_t*)r->sq.q_flags, r->sq.Q));
+  VS_TRY(fetch(idx, r->h_byte_begin, (const uint64_t*)r->sq.byte_begin, r->sq.Q + 1));
+  VS_TRY(fetch(idx, r->h_chars, (const uint8_t*)r->sq.chars, r->seq_bytes));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  r->h_chars.push_back(0);
+  r->have_seq = true;
   return VS_OK;
 }
 
@@ -724,6 +805,56 @@ int vs_query_samples_has_var(vs_index* idx, const uint64_t* positions, const cha
   return run_point_batch(idx, positions, n, 7, &ps, out);
 }
 
+static int check_sample_batch(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, vs_result** out,
+                              bool need_index) {
+  if (!idx || !out || (n && (!regions || !sample_ids))) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  for (uint64_t i = 0; i < n; ++i)
+    if (sample_ids[i] >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_ids[i], idx->g.num_samples);
+  if (need_index && !idx->d.has_car_index)
+    return fail(VS_ERR_ARG, "this index holds no sample coordinates (built without them); query types 2, 3 and 5 need them");
+  return VS_OK;
+}
+
+int vs_query_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int sample_coordinates,
+                        vs_result** out) {
+  VS_TRY(check_sample_batch(idx, regions, n, sample_ids, out, true));
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  r->kind = sample_coordinates ? 3 : 2;
+  idx->live_results++;
+  int rc = run_sample_seq(idx, regions, n, sample_ids, r->kind, r);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_sample_var_in_sample(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, vs_result** out) {
+  VS_TRY(check_sample_batch(idx, regions, n, sample_ids, out, true));
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  static const uint32_t none = 0;
+  int rc = run_var_in_ref(idx, regions, n, r, kNone, n ? sample_ids : &none, 0, nullptr, 5);
+  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  *out = r;
+  return VS_OK;
+}
+
+int vs_result_get_sequences(vs_result* r, uint64_t* n_regions, const uint8_t** region_flags, const uint64_t** seq_begin,
+                            const char** chars) {
+  if (!r) return fail(VS_ERR_ARG, "null argument");
+  if (r->kind != 2 && r->kind != 3) return fail(VS_ERR_ARG, "not a sequence result");
+  VS_TRY(fetch_sequences(r));
+  if (n_regions) *n_regions = r->sq.Q;
+  if (region_flags) *region_flags = r->h_flags.data();
+  if (seq_begin) *seq_begin = r->h_byte_begin.data();
+  if (chars) *chars = (const char*)r->h_chars.data();
+  return VS_OK;
+}
+
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out) {
   if (!idx || (n && (!pos || !vertex_out))) return fail(VS_ERR_ARG, "null argument");
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
@@ -744,6 +875,7 @@ int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vert
 
 // ---------------------------------------------------------------- result access
 int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
+  if (r) { VS_NOT_SEQ(r); }
   if (!r || !view) return fail(VS_ERR_ARG, "null argument");
   VS_TRY(fetch_headers(r));
   if (with_carriers && !r->have_carriers) {
@@ -771,6 +903,13 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
 int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers, uint64_t* n_bases) {
   vs_result* r = const_cast<vs_result*>(cr);
   if (!r) return fail(VS_ERR_ARG, "null argument");
+  if (r->kind == 2 || r->kind == 3) {  // sequences: only regions and bases
+    if (n_regions) *n_regions = r->sq.Q;
+    if (n_variants) *n_variants = 0;
+    if (n_carriers) *n_carriers = 0;
+    if (n_bases) *n_bases = r->seq_bytes;
+    return VS_OK;
+  }
   VS_TRY(fetch_headers(r));
   if (!r->have_totals) {
     uint64_t nv = 0, nc = 0, nb = 0;
@@ -789,6 +928,18 @@ int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_varia
 
 int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len) {
   if (!r || !text) return fail(VS_ERR_ARG, "null argument");
+  if (r->kind == 2 || r->kind == 3) {  // `out << seq << std::endl`, query.h:182-187 / :252-257
+    VS_TRY(fetch_sequences(r));
+    if (q >= r->sq.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
+    r->text.clear();
+    if (!(r->h_flags[q] & (VS_REGION_INVALID | VS_REGION_ENDLESS))) {
+      r->text.assign((const char*)r->h_chars.data() + r->h_byte_begin[q], r->h_byte_begin[q + 1] - r->h_byte_begin[q]);
+      r->text += '\n';
+    }
+    *text = r->text.c_str();
+    if (len) *len = r->text.size();
+    return VS_OK;
+  }
   VS_TRY(fetch_headers(r));
   if (q >= r->d.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
   vs_index* idx = r->idx;
@@ -857,6 +1008,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
 
 int vs_result_digest(vs_result* r, uint64_t* digest) {
   if (!r || !digest) return fail(VS_ERR_ARG, "null argument");
+  VS_NOT_SEQ(r);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
   std::vector<DevBuf> bufs;
@@ -877,6 +1029,7 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
 int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
+  VS_NOT_SEQ(r);
   if (n_records) *n_records = r->d.A;
   if (!device_dst) return VS_OK;  // size query
   if (capacity_records < r->d.A) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
@@ -895,6 +1048,7 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
 int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
+  VS_NOT_SEQ(r);
   if (n_records) *n_records = r->d.Q;
   if (!device_dst) return VS_OK;
   if (capacity_records < r->d.Q) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",

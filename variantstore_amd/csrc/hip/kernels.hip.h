@@ -25,6 +25,10 @@
 //                       as used by closest_var (query.h:441-483, type 1) and
 //                       samples_has_var (query.h:792-823, type 7)
 // k_has_var_filter      the (pos, ref, alt) match of samples_has_var (query.h:802-803)
+// k_sample_walk_sc      get_sample_var_in_sample (query.h:490-612, type 5)
+// k_sample_seq          query_sample_from_ref / query_sample_from_sample
+//                       (query.h:118-261, types 2 and 3): the walk emits (offset, length)
+//                       pieces of the sequence pool; k_copy_segments decodes them
 // k_find                Index::find batched
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,7 +39,7 @@ namespace vsamd {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSiteAlwaysDrop = 2;  // branch the reference would emit with an uninitialised var_pos
 constexpr uint32_t kVarDropped = 1;
-constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionNotFound = 4, kRegionSlow = 128;
+constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionNotFound = 4, kRegionEndless = 8, kRegionSlow = 128;
 
 struct DevImage {
   uint64_t ref_length, nbits;
@@ -56,6 +60,7 @@ struct DevImage {
   const uint32_t* cls_list_ids;
   const uint8_t* gt_nibbles;
   const uint32_t* car_sid;
+  const uint32_t* car_index;  // sample-coordinate index per carrier record (types 2/3/5); valid when has_car_index
   const uint8_t* seq_codes;
   // site table (one entry per branch of a ref-path node, ref-path order)
   uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev, *s_class;
@@ -63,7 +68,7 @@ struct DevImage {
   uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
-  uint32_t n_sus, pad2_;
+  uint32_t n_sus, has_car_index;
 };
 
 struct DevResult {
@@ -894,6 +899,282 @@ __global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r,
   }
   r.var_count[q] = found ? 1 : 0;
   if (!found) r.q_flags[q] |= kRegionNotFound;
+}
+
+// ---------------------------------------------------------------------------
+// Sample-coordinate queries (types 2, 3 and 5).  They need the per-carrier `index` of
+// sample_info (variantgraphvertex.proto:12) -- DevImage::car_index.
+// ---------------------------------------------------------------------------
+
+// get_sample_from_vertex_if_exists(v, sample, out) -> out.index (variant_graph.h:1296-1339).  The s_info
+// entry of a sample is found by its position in the class's ascending id list (bit-vector mode) or by a
+// linear search (explicit ids); the carrier pool holds the non-ref entries in s_info order.
+__device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {
+  if (sid == 0) {
+    if (!im.v_ridx[v]) return false;
+    index = im.v_ridx[v];
+    return true;
+  }
+  const uint64_t b = im.v_car_begin[v];
+  if (im.use_bv) {
+    const uint64_t* row = im.class_rows + (uint64_t)im.v_class[v] * im.wpc;
+    const uint32_t w = sid >> 6, bit = sid & 63;
+    const uint64_t word = row[w];
+    if (!((word >> bit) & 1)) return false;
+    uint32_t rank = __popcll(word & ((1ULL << bit) - 1));
+    for (uint32_t i = 0; i < w; ++i) rank += __popcll(row[i]);
+    rank -= (uint32_t)(row[0] & 1);  // the ref entry is not part of the pool
+    index = im.car_index[b + rank];
+    return true;
+  }
+  for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
+    if (im.car_sid[b + i] == sid) { index = im.car_index[b + i]; return true; }
+  return false;
+}
+
+// get_neighbor_vertex (variant_graph.h:1402-1451): first out-neighbour holding the sample, else the ref
+// neighbour with the smallest ref index; 0 = none (the path iterator is done)
+__device__ __forceinline__ uint32_t next_on_path(const DevImage& im, uint32_t cur, uint32_t sid) {
+  uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+  for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
+    const uint32_t n = im.col[e];
+    if (sid != 0 && vertex_has_sample(im, n, sid)) return n;
+    const uint32_t nr = im.v_ridx[n];
+    if (nr && min_idx > nr) { nxt = n; min_idx = nr; }
+  }
+  return nxt;
+}
+
+// get_prev_vertex_with_sample (query.h:57-113) including the sample-coordinate output
+__device__ __forceinline__ uint32_t prev_vertex_with_sample(const DevImage& im, uint64_t pos, uint32_t sid, uint64_t& ref_pos,
+                                                            uint64_t& sample_pos) {
+  uint64_t rank;  // find(pos, rank), index.h:135-148 (rank is left unset for pos == 0 there: defined as 0)
+  if (pos >= im.ref_length) rank = im.R - 1;
+  else { const uint32_t k = rank1(im, pos); rank = k == 0 ? 0 : k - 1; }
+  uint32_t v_find = 0;
+  while (true) {
+    const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
+    if (rank <= 1) { ref_pos = 1; v_find = v; sample_pos = im.v_ridx[v]; break; }
+    bool found = false;
+    for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) {
+      const uint32_t n = im.col[e];
+      if (im.v_ridx[n]) ref_pos = im.v_ridx[n];
+      uint32_t idx;
+      if (sample_entry(im, n, sid, idx)) { v_find = n; found = true; sample_pos = idx; }
+      rank = rank ? rank - 1 : 0;  // unsigned wrap in the reference: clamped
+    }
+    if (found) break;
+  }
+  return v_find;
+}
+
+// the backward search of query.h:213-218 / :507-512; false when the reference would loop forever
+__device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_t x, uint32_t sid, uint32_t& closest_v,
+                                                     uint64_t& ref_pos, uint64_t& sample_pos) {
+  closest_v = prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  uint64_t guard = 0;
+  while (sample_pos >= x && closest_v > 0) {
+    const uint64_t pos = ref_pos, before_ref = ref_pos, before_sample = sample_pos;
+    const uint32_t before_v = closest_v;
+    closest_v = prev_vertex_with_sample(im, pos, sid, ref_pos, sample_pos);
+    if (ref_pos == before_ref && sample_pos == before_sample && closest_v == before_v) return false;
+    if (++guard > 4 * im.V + 64) return false;
+  }
+  return true;
+}
+
+// Query type 5.  One thread per region; EMIT=false counts, EMIT=true writes the variant headers.
+template <bool EMIT>
+__global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint32_t sid = sid_per_region[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  uint8_t fl = 0;
+  uint64_t nvar = 0, ncar = 0;
+  uint64_t ref_pos = 0, sample_pos = 0;
+  uint32_t closest_v = 0;
+  if (!rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
+  else {
+    closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
+    if (im.v_ridx[closest_v]) {
+      const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
+      ref_pos = im.v_ridx[closest_v];
+      sample_pos -= seq_len;
+    }
+    uint32_t cur = closest_v;
+    uint32_t cur_ref_off = 0, cur_ref_len = 0;
+    bool done = false;
+    const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
+    const uint64_t cb = EMIT ? r.car_base[q] : 0;
+    while (!done) {
+      if (sample_pos >= y) break;
+      const uint32_t l = im.v_len[cur];
+      uint64_t next_ref_pos = ref_pos + l;
+      uint32_t next_ref_off = 0, next_ref_len = 0;
+      for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
+        const uint32_t n = im.col[e];
+        if (im.v_ridx[n]) { next_ref_pos = im.v_ridx[n]; next_ref_off = im.v_off[n]; next_ref_len = im.v_len[n]; }
+      }
+      uint32_t sidx = 0;
+      if (sample_pos > x && sample_entry(im, cur, sid, sidx)) {
+        uint64_t pos;
+        uint32_t ro, rl, ao, al;
+        if (ref_pos == next_ref_pos) {        // insertion
+          pos = ref_pos; ro = 0; rl = 0; ao = im.v_off[cur]; al = l;
+        } else if (im.v_ridx[cur]) {          // deletion: ref = sequence of find(ref_pos - 1)
+          const uint32_t fv = im.rp_vid[slot_of_find(im, ref_pos - 1)];
+          pos = sidx; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
+        } else {                              // substitution
+          pos = sidx; ro = cur_ref_off; rl = cur_ref_len; ao = im.v_off[cur]; al = l;
+        }
+        const uint32_t c = im.v_ncar[cur];
+        if (EMIT) {
+          const uint64_t a = a0 + nvar;
+          r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
+          r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
+          r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+          r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+        }
+        nvar++; ncar += c;
+        // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
+      }
+      cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
+      ref_pos = next_ref_pos;
+      sample_pos += l;
+      const uint32_t nxt = next_on_path(im, cur, sid);
+      if (nxt == 0) done = true;
+      cur = nxt;
+    }
+  }
+  if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
+  else r.var_count[q] = nvar;
+}
+
+// Query types 2 and 3: the sequence of a sample over [x, y).  The walk produces the list of (pool offset,
+// length) pieces; seg_begin / byte_begin are the exclusive scans of the counting pass.
+struct DevSeqResult {
+  uint64_t Q;
+  const uint64_t* regions;
+  const uint32_t* sids;
+  uint8_t* q_flags;
+  uint64_t *q_nseg, *q_nbytes;      // [Q] counting pass
+  uint64_t *seg_begin, *byte_begin; // [Q+1]
+  uint32_t *seg_src, *seg_len;      // [nseg]
+  uint64_t* seg_dst;                // [nseg] byte offset in chars
+  uint8_t* chars;
+};
+
+struct SeqSink {
+  uint64_t nseg, nbytes;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void seq_append(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint32_t off,
+                                           uint64_t len) {
+  if (len == 0) return;
+  if (EMIT) {
+    r.seg_src[seg0 + s.nseg] = off; r.seg_len[seg0 + s.nseg] = (uint32_t)len; r.seg_dst[seg0 + s.nseg] = byte0 + s.nbytes;
+  }
+  s.nseg++; s.nbytes += len;
+}
+
+// the window logic of query.h:160-177 / :236-247 on (off, l) instead of a std::string.
+// Returns 0 continue, 1 stop, 2 std::out_of_range (uncaught in the reference).
+template <bool EMIT>
+__device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, bool& record,
+                                          uint32_t off, uint64_t l, uint64_t cur, uint64_t next, uint64_t x, uint64_t y) {
+  if (record && next < y) {
+    seq_append<EMIT>(r, s, seg0, byte0, off, l);
+  } else if (record && next >= y) {
+    const uint64_t n = y - cur;  // substr(0, n): n may have wrapped, it is clipped to the string
+    seq_append<EMIT>(r, s, seg0, byte0, off, n < l ? n : l);
+    return 1;
+  } else if (next >= x && next < y) {
+    record = true;
+    const uint64_t p = x - cur;
+    if (p > l) return 2;
+    seq_append<EMIT>(r, s, seg0, byte0, off + (uint32_t)p, l - p);
+  } else if (next >= x && next >= y) {
+    const uint64_t p = x - cur;
+    if (p > l) return 2;
+    const uint64_t n = y - x;
+    seq_append<EMIT>(r, s, seg0, byte0, off + (uint32_t)p, n < l - p ? n : l - p);
+    return 1;
+  }
+  return 0;
+}
+
+template <int MODE, bool EMIT>
+__global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  if (EMIT && r.q_flags[q]) return;
+  const uint32_t sid = r.sids[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t seg0 = EMIT ? r.seg_begin[q] : 0, byte0 = EMIT ? r.byte_begin[q] : 0;
+  SeqSink s{0, 0};
+  uint8_t fl = 0;
+  uint64_t ref_pos = 0, sample_pos = 0;
+  uint32_t cur = 0;
+  bool ok = true;
+  if (MODE == 2) cur = prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  else ok = rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
+  if (!ok) fl = kRegionEndless;
+  else {
+    bool record = false, done = false;
+    while (!done) {
+      const uint32_t off = im.v_off[cur];
+      const uint64_t l = im.v_len[cur];
+      int st;
+      if (MODE == 2) {
+        uint64_t next_ref_pos = ref_pos + l;
+        for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
+          const uint32_t nr = im.v_ridx[im.col[e]];
+          if (nr) { next_ref_pos = nr; break; }  // the FIRST ref neighbour here (query.h:150-153)
+        }
+        st = seq_window<EMIT>(r, s, seg0, byte0, record, off, l, ref_pos, next_ref_pos, x, y);
+        ref_pos = next_ref_pos;
+      } else {
+        const uint64_t next_sample_pos = sample_pos + l;
+        st = seq_window<EMIT>(r, s, seg0, byte0, record, off, l, sample_pos, next_sample_pos, x, y);
+        sample_pos = next_sample_pos;
+      }
+      if (st == 2) { fl = kRegionInvalid; break; }
+      if (st == 1) break;
+      const uint32_t nxt = next_on_path(im, cur, sid);
+      if (nxt == 0) done = true;
+      cur = nxt;
+    }
+  }
+  if (!EMIT) {
+    r.q_flags[q] = fl;
+    r.q_nseg[q] = fl ? 0 : s.nseg;
+    r.q_nbytes[q] = fl ? 0 : s.nbytes;
+  }
+}
+
+// Decode the pieces into characters: one wave per region, 64 piece descriptors at a time.
+__global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t s0 = r.seg_begin[q], s1 = r.seg_begin[q + 1];
+  for (uint64_t base = s0; base < s1; base += 64) {
+    const uint64_t mine = base + lane;
+    uint32_t src = 0, len = 0;
+    uint64_t dst = 0;
+    if (mine < s1) { src = r.seg_src[mine]; len = r.seg_len[mine]; dst = r.seg_dst[mine]; }
+    const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t ksrc = __builtin_amdgcn_readlane(src, k), klen = __builtin_amdgcn_readlane(len, k);
+      const uint64_t kdst = wave_bcast64(dst, k);
+      for (uint32_t i = lane; i < klen; i += 64) {
+        const uint32_t c = im.seq_codes[ksrc + i] & 7;
+        r.chars[kdst + i] = (uint8_t)(0x0505054E47544341ULL >> (8 * c));  // "ACTGN" then char 5 (map_int, util.cc:32-41)
+      }
+    }
+  }
 }
 
 // Index::find batched (index.h:119-133)

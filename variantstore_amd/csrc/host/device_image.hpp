@@ -65,6 +65,7 @@ struct HostImage {
   std::vector<uint32_t> cls_list_ids;    // ascending sample ids (ref excluded), padded
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
+  std::vector<uint32_t> car_index;   // sample-coordinate index per carrier record (query types 2/3/5); may be empty
   std::vector<uint8_t> seq_codes;    // DNA_MAP codes, one per base
 };
 
@@ -269,6 +270,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   for (uint64_t c = 0; c < g.car_flags.size(); ++c)
     im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
   im.car_sid = g.car_sid;
+  im.car_index = g.car_index;
   im.seq_codes = g.seq;
 }
 
