@@ -70,6 +70,9 @@ typedef struct {
   double frac_multi;         /* fraction of SNP sites with a second ALT        */
   uint32_t max_indel;        /* indel length 1..max_indel                      */
   double af_exponent;        /* AF = min(0.5, 10^(-af_exponent * U))           */
+  uint32_t sample_coordinates; /* != 0: also compute the per-carrier sample-coordinate indexes (the reference's
+                                * "Fixing sample indexes" pass, variant_graph.h:1919-1997) that query types 2, 3 and 5
+                                * read; 4 bytes per carrier record                                                      */
 } vs_synth_params;
 int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats* stats, vs_index** out);
 
@@ -78,6 +81,8 @@ int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats*
 int vs_index_open(const char* prefix, int device, vs_index** out);
 /* Write the index directory (VariantGraph::serialize + Index::serialize). */
 int vs_index_save(const vs_index* idx, const char* prefix);
+/* Releases the handle.  If results of this handle are still alive the release is deferred to the vs_result_free of
+ * the last one (their arrays live in the handle's HBM pool); the handle must not be used for new calls meanwhile. */
 void vs_index_close(vs_index* idx);
 
 typedef struct {

@@ -489,3 +489,57 @@ def test_sample_sequence_batch_with_one_sample_per_region(tmp_path):
             if n >= 0:
                 assert seqs[q] == seq, (q, per[q], coords)
         assert res.totals()[3] == sum(len(s) for s in seqs)
+
+
+def test_sample_coordinate_queries_synthetic_midsize(tmp_path):
+    """20k variants x 200 samples (bit-vector classes), 300 regions of 5 kb, three samples: types 2, 3 and 5."""
+    vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=23,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6,
+                                af_exponent=3.0, sample_coordinates=True)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(6)
+    starts = rng.integers(1, 1_990_000, size=300)
+    regions = [(int(s), int(s) + 5000) for s in starts]
+    for smp in ("S00001", "S00100", "S00200"):
+        for coords in (False, True):
+            res = vs.query_sample_seq(regions, smp, sample_coordinates=coords)
+            flags, seqs = res.sequences()
+            good = 0
+            for q, (x, y) in enumerate(regions):
+                n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, smp)
+                if n == -3:   # pos_x inside a segment this sample deletes: substr throws in the reference
+                    assert flags[q] & 2, (smp, coords, x, y)
+                    continue
+                if n == -1:   # sample_pos of the start vertex >= pos_x: the reference's backward search repeats itself
+                    assert flags[q] & 8, (smp, coords, x, y)
+                    continue
+                assert n >= 0 and not flags[q] and seqs[q] == seq, (smp, coords, x, y)
+                good += 1
+            assert good > 270
+            res.close()
+        res = vs.get_sample_var_in_sample(regions, smp)
+        rflags = res.view(False)["region_flags"]
+        nv = 0
+        for q, (x, y) in enumerate(regions):
+            n, text = orc.get_sample_var_in_sample(x, y, smp)
+            if n == -1:
+                assert rflags[q] & 8, (smp, x, y)
+                continue
+            assert n >= 0 and res.region_text(q) == text, (smp, x, y)
+            nv += n
+        assert nv > 300
+        res.close()
+    # the sample "ref" read in reference coordinates is the reference itself: pieces concatenate
+    res = vs.query_sample_seq([(1000, 9000), (1000, 5000), (5000, 9000)], "ref")
+    _, seqs = res.sequences()
+    assert len(seqs[0]) == 8000 and seqs[0] == seqs[1] + seqs[2]
+
+
+def test_sample_coordinate_queries_need_the_indexes(tmp_path):
+    vs = VariantStore.synthetic(device=0, ref_length=100_000, num_variants=500, num_samples=50, seed=3)
+    with pytest.raises(Exception, match="sample coordinates"):
+        vs.query_sample_seq([(100, 200)], "S00001")
+    with pytest.raises(Exception, match="sample coordinates"):
+        vs.get_sample_var_in_sample([(100, 200)], "S00001")

@@ -61,6 +61,7 @@ struct vs_index {
   vs_timing timing{};
   vs_construct_stats cstats{};
   uint64_t live_results = 0;
+  bool close_pending = false;  // vs_index_close was called while results were alive
   uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path
 };
 
@@ -570,6 +571,10 @@ const char* vs_last_error(void) { return g_last_error.c_str(); }
 
 void vs_index_close(vs_index* idx) {
   if (!idx) return;
+  if (idx->live_results > 0) {  // results still hold buffers of this handle: the last vs_result_free closes it
+    idx->close_pending = true;
+    return;
+  }
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
@@ -609,6 +614,7 @@ int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats*
     sp.ref_length = p->ref_length; sp.num_variants = p->num_variants; sp.num_samples = p->num_samples;
     sp.seed = p->seed; sp.first_pos = p->first_pos; sp.frac_ins = p->frac_ins; sp.frac_del = p->frac_del;
     sp.frac_multi = p->frac_multi; sp.max_indel = p->max_indel ? p->max_indel : 1; sp.af_exponent = p->af_exponent;
+    sp.sample_coordinates = p->sample_coordinates != 0;
     uint64_t nk = 0, ne = 0, sl = 0;
     SynthStats st = construct_synthetic(sp, idx->g, &nk, &ne, &sl);
     idx->cstats = vs_construct_stats{st.num_vars, st.num_mutations, st.num_mutations_samples, nk, ne, sl,
@@ -712,6 +718,7 @@ void vs_result_free(vs_result* r) {
     (void)hipSetDevice(r->idx->device);
     release_bufs(r->idx, r->bufs);
     r->idx->live_results--;
+    if (r->idx->close_pending && r->idx->live_results == 0) vs_index_close(r->idx);
   }
   delete r;
 }

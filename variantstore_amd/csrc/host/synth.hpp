@@ -29,6 +29,7 @@ struct SynthParams {
   double frac_ins = 0.0, frac_del = 0.0, frac_multi = 0.0;
   uint32_t max_indel = 6;
   double af_exponent = 3.0;
+  bool sample_coordinates = false;
 };
 
 struct SplitMix64 {
@@ -218,9 +219,9 @@ inline SynthStats construct_synthetic(const SynthParams& p, HostGraph& out, uint
   if (n_keys) *n_keys = b.num_keys();
   if (n_edges) *n_edges = b.num_edges();
   if (seq_len) *seq_len = b.seq_length();
-  // per-carrier sample-coordinate indexes cost 4 bytes per carrier record and are not read by the
-  // query types this engine runs; off unless asked for
-  b.finish(out, getenv("VS_SYNTH_SAMPLE_INDEXES") != nullptr);
+  // per-carrier sample-coordinate indexes cost 4 bytes per carrier record and are read only by query
+  // types 2, 3 and 5; off unless asked for
+  b.finish(out, p.sample_coordinates || getenv("VS_SYNTH_SAMPLE_INDEXES") != nullptr);
   return st;
 }
 
