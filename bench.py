@@ -246,6 +246,42 @@ def main():
         t17 = {"type1_queries_per_s": t1_qps, "type1_variants_per_query": nv1 / npos,
                "type7_queries_per_s_device": npos / (ms7 * 1e-3), "type7_found": nf7, "positions_per_batch": npos}
 
+    # ---- sample-coordinate queries (types 2, 3 and 5), outside the timed region, on a
+    #      1/12.5-length cohort of the same shape built WITH sample coordinates (4 B per carrier record) ----
+    tsc = None
+    if os.environ.get("VS_BENCH_SKIP_T4") != "1" and rank == 0:
+        kw = synth_kwargs(w)
+        kw["ref_length"] = max(200_000, w["ref_length"] * 2 // 25)
+        kw["num_variants"] = max(1000, w["num_variants"] * 2 // 25)
+        kw["first_pos"] = min(w["first_pos"], kw["ref_length"] // 10)
+        vsc = VariantStore.synthetic(device=local_rank, sample_coordinates=True, **kw)
+        nsc = 20_000
+        srng = np.random.default_rng(23)
+        st = srng.integers(max(1, kw["first_pos"]), kw["ref_length"] - w["region_len"], size=nsc, dtype=np.int64)
+        sreg = np.stack([st, st + w["region_len"]], axis=1).astype(np.uint64)
+        ns = vsc.info().num_samples
+        sper = np.array([1 + ((i % 16) * 157) % (ns - 1) for i in range(nsc)], dtype=np.uint32)
+        tsc = {"regions_per_batch": nsc, "samples": 16, "index_sites": int(vsc.info().num_sites)}
+        for name, call in (("type2", lambda: vsc.query_sample_seq(sreg, sper, sample_coordinates=False)),
+                           ("type3", lambda: vsc.query_sample_seq(sreg, sper, sample_coordinates=True)),
+                           ("type5", lambda: vsc.get_sample_var_in_sample(sreg, sper))):
+            rr = call()
+            rr.close()
+            torch.cuda.synchronize()
+            b0 = time.perf_counter()
+            for _k in range(3):
+                rr = call()
+                tot = rr.totals()
+                rr.close()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - b0) / 3
+            tsc[name + "_queries_per_s"] = nsc / dt
+            if name != "type5":
+                tsc[name + "_bases_per_s"] = tot[3] / dt
+            else:
+                tsc["type5_variants_per_region"] = tot[1] / nsc
+        vsc.close()
+
     if rank == 0:
         out = {
             "metric": "region-queries/sec (batch, query-type 6)",
@@ -280,6 +316,7 @@ def main():
             "p50_latency_us": p50,
             "type4": t4,
             "point_queries": t17,
+            "sample_coordinate_queries": tsc,
             "result_digest": f"{digest:016x}",
         }
         if world == 1 and not args.no_cpu_baseline:
