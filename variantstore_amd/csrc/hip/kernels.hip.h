@@ -484,31 +484,45 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       continue;
     }
 
-    // ---------------- sparse: lane per variant ----------------
-    // ids come from the class's decoded id list (built once at load), genotypes from
-    // three unaligned 64-bit windows of the nibble pool; the loop is loads-then-stores.
-    if (cnt > 0 && cnt <= kSparseMax && !(ablate & 1)) {
-      const uint8_t* gp = gtp + (gt0 >> 1);
-      const uint32_t odd = (uint32_t)(gt0 & 1);
-      const uint64_t n0 = load_u64_unaligned(gp);
-      const uint32_t* __restrict__ ids = im.cls_list_ids + im.cls_list_begin[cls];
-      uint32_t* out = carriers + cb;
-      uint4 q = load_u128_unaligned(ids);
-      uint64_t n1 = 0, n2 = 0;
-      if (cnt + odd > 16) { n1 = load_u64_unaligned(gp + 8); n2 = load_u64_unaligned(gp + 16); }
-      for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-        const uint4 cur = q;
-        if (k0 + 4 < cnt) q = load_u128_unaligned(ids + k0 + 4);
-        const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
+    // ---------------- sparse: lane per CARRIER ----------------
+    // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
+    // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
+    // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
+    // the class's decoded id list (built once at load), genotype nibble from the pool.  Two or three
+    // full-width passes replace up to eight lane-per-variant iterations whose loads and stores ran with a
+    // handful of active lanes -- the cost of those was per instruction, not per byte.
+    {
+      uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
+      const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
+      const uint32_t c = sp ? cnt : 0u;
+      uint32_t incl = c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t k = k0 + i;
-          if (k < cnt) {
-            const uint32_t ni = k + odd;
-            const uint64_t win = ni < 16 ? n0 : (ni < 32 ? n1 : n2);
-            const uint32_t nib = (uint32_t)(win >> ((ni & 15) * 4)) & 7u;
-            out[k] = v[i] | (nib << 29);
-          }
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+      }
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      if (total) {
+        // per-variant parameters go through LDS (not lane shuffles: in the last pass the owning lane may be idle)
+        uint32_t* s_idb = s_off + 64;
+        uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+        uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+        s_off[lane] = incl - c;
+        s_idb[lane] = sp ? im.cls_list_begin[cls] : 0u;
+        s_gt0[lane] = gt0;
+        s_cb[lane] = cb;
+        for (uint32_t e = lane; e < total; e += 64) {
+          uint32_t L = 0;
+#pragma unroll
+          for (uint32_t step = 32; step; step >>= 1)
+            if (s_off[L + step] <= e) L += step;
+          const uint32_t k = e - s_off[L];
+          const uint32_t idb_L = s_idb[L];
+          const uint64_t gt0_L = s_gt0[L];
+          const uint64_t cb_L = s_cb[L];
+          const uint64_t g = gt0_L + k;
+          const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
+          carriers[cb_L + k] = im.cls_list_ids[idb_L + k] | (nib << 29);
         }
       }
     }
