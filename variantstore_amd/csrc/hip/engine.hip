@@ -370,7 +370,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
       uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
       if (gt_words < 448) gt_words = 448;   // the medium path keeps 640 ids at word 256..
-      const size_t lds_bytes = 4 * (size_t)(gt_words + kRingWords) * 4;
+      const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
       if (idx->d.wpc <= 63)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else
@@ -532,7 +532,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 2048);
     uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
     if (gt_words < 448) gt_words = 448;
-    const size_t lds_bytes = 4 * (size_t)(gt_words + kRingWords) * 4;
+    const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
     if (idx->d.wpc <= 63)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
     else

@@ -387,6 +387,18 @@ constexpr uint32_t kSparseMax = 32;
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
 // per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
 constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
+// Slice path (cohorts of at most 4032 samples): per-wave LDS = row staging + raw genotype nibbles + 16-bit id list
+constexpr uint32_t kRowWords = 132;          // 65 x uint64 (the row and one zero word behind it), padded
+__host__ __device__ inline uint32_t slice_gt_words(uint32_t n_samples) {
+  uint32_t b = (n_samples + 32) / 2 + 32;   // nibbles of one variant, first one anywhere in a 16-byte group, + the bias
+  b = (b + 15) & ~15u;
+  if (b < 1024 + 16) b = 1024 + 16;         // the first 1 KiB is written by all lanes
+  return b / 4;
+}
+__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) { return ((256 + n_samples + 8 + 7) & ~7u) / 2; }
+__host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
+  return kRowWords + slice_gt_words(n_samples) + slice_ids_words(n_samples);
+}
 constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
 
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
@@ -462,7 +474,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
   uint32_t* __restrict__ carriers = r.carriers;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
-  const uint32_t lds_words_per_wave = gt_words + kRingWords;
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
 
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t a = (chunk << 6) + lane;
@@ -560,9 +572,15 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
       const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
       const bool staged = (uint64_t)nshift + cnt_t <= gt_words * 4;     // fits the staging block
-      // stage this variant's genotypes (fetched during the previous variant), one byte per carrier
-      stage_unpacked(gt_lds + lane * 32, nq0);
-      if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
+      // stage this variant's genotypes (fetched during the previous variant)
+      if (WIDE) {   // one byte per carrier
+        stage_unpacked(gt_lds + lane * 32, nq0);
+        if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
+      } else {      // raw nibbles, behind the row staging area
+        uint8_t* nib_st = gt_lds + kRowWords * 4 + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
+        *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
+        if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
+      }
       // request the next variant's row and nibbles before expanding this one
       uint64_t word_next = 0;
       nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0};
@@ -591,7 +609,64 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       const uint32_t endpos = a0 + cnt_t;
       if ((ablate & 2) && cnt_t <= kMidMax) { word_cur = word_next; continue; }
       if ((ablate & 4) && cnt_t > kMidMax) { word_cur = word_next; continue; }
-      if (cnt_t <= kMidMax) {
+      if (!WIDE) {
+        // ---- slice path: every lane owns wpc consecutive bits of the row (64 x wpc bits = the whole row), peels
+        //      them into a 16-bit id list in LDS at its prefix-sum position, then the list leaves in 1 KiB-aligned
+        //      blocks, one 16-byte store per lane, genotypes merged from the raw nibble stream on the way out.
+        //      Compared with the bit-per-lane ring (kept below for wide cohorts) this needs ~2.5x fewer
+        //      instructions per carrier and no scalar work per row word. ----
+        uint64_t* rowq = reinterpret_cast<uint64_t*>(gt_lds);                     // [65]
+        const uint8_t* nib_lds = gt_lds + kRowWords * 4;
+        uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + (kRowWords + slice_gt_words(im.num_samples)) * 4);
+        rowq[lane] = mine;
+        if (lane == 0) rowq[64] = 0;
+        const uint32_t b0s = wpc * lane, wi = b0s >> 6, sh = b0s & 63;
+        const uint64_t ra = rowq[wi], rb = rowq[wi + 1];
+        uint64_t slice = sh ? ((ra >> sh) | (rb << (64 - sh))) : ra;
+        slice &= (1ULL << wpc) - 1;
+        uint32_t lo = (uint32_t)slice, hi = (uint32_t)(slice >> 32);
+        const uint32_t pc = __popc(lo) + __popc(hi);
+        uint32_t incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = __shfl_up(incl, d, 64);
+          if (lane >= (uint32_t)d) incl += up;
+        }
+        const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
+        uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+        const uint32_t end1k = a1k + cnt_t;
+        uint32_t j = a1k + incl - pc;                       // list index of this lane's first carrier
+        while (lo) {
+          ids16[j++] = (uint16_t)(b0s + __builtin_ctz(lo));
+          lo &= lo - 1;
+        }
+        while (hi) {
+          ids16[j++] = (uint16_t)(b0s + 32 + __builtin_ctz(hi));
+          hi &= hi - 1;
+        }
+        // copy-out: lane q of a pass owns list entries 4q..4q+3; their nibbles are 16 consecutive bits of the
+        // stream.  nibble index = list index + D; the staging is biased by 32 nibbles so that the first, partly
+        // valid quad (entries before a1k are not the variant's) still addresses forwards.
+        const uint32_t D = nshift + 32 - a1k;
+        for (uint32_t q4 = lane * 4; q4 < end1k; q4 += 256) {
+          if (q4 + 4 <= a1k) continue;
+          const uint2 iw = *reinterpret_cast<const uint2*>(ids16 + q4);
+          const uint32_t n0 = q4 + D;
+          const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
+          const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
+          uint4 v;
+          v.x = (iw.x & 0xFFFFu) | (n << 29);
+          v.y = (iw.x >> 16) | ((n << 25) & 0xE0000000u);
+          v.z = (iw.y & 0xFFFFu) | ((n << 21) & 0xE0000000u);
+          v.w = (iw.y >> 16) | ((n << 17) & 0xE0000000u);
+          if (q4 >= a1k && q4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + q4) = v;
+          else {
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (q4 + i >= a1k && q4 + i < end1k) g1k[q4 + i] = e[i];
+          }
+        }
+      } else if (cnt_t <= kMidMax) {
         // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
         const uint32_t pc = __popcll(mine);
         uint32_t incl = pc;
