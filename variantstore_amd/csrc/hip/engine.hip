@@ -339,7 +339,12 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_car_begin));
   VS_TRY(ralloc(r, d.A, &d.r_class));
   VS_TRY(ralloc(r, d.A, &d.r_gt0));
-  VS_TRY(ralloc(r, d.S, &d.carriers));
+  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  {
+    uint8_t* arena = nullptr;
+    VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
+    d.carriers = arena;
+  }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
@@ -395,6 +400,27 @@ template <typename T>
 static int fetch(vs_index* idx, std::vector<T>& h, const T* dptr, size_t n) {
   h.resize(n);
   if (n) HIP_TRY(hipMemcpyAsync(h.data(), dptr, n * sizeof(T), hipMemcpyDeviceToHost, idx->stream));
+  return VS_OK;
+}
+
+// carriers [first, first + n) of the arena as 32-bit words (id | gt << 29), whatever the arena's width
+static int fetch_carriers(vs_result* r, uint64_t first, uint64_t n, std::vector<uint32_t>& out) {
+  vs_index* idx = r->idx;
+  out.resize(n);
+  if (n == 0) return VS_OK;
+  if (r->d.car_width == 4) {
+    HIP_TRY(hipMemcpyAsync(out.data(), (const uint32_t*)r->d.carriers + first, n * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    return VS_OK;
+  }
+  // 16-bit arena: copy into the upper half of the output buffer, widen in place from the front
+  uint16_t* narrow = reinterpret_cast<uint16_t*>(out.data()) + n;
+  HIP_TRY(hipMemcpyAsync(narrow, (const uint16_t*)r->d.carriers + first, n * 2, hipMemcpyDeviceToHost, idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t c = narrow[i];
+    out[i] = (c & 0x1FFFu) | ((c >> 13) << 29);
+  }
   return VS_OK;
 }
 
@@ -521,7 +547,12 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   VS_TRY(ralloc(r, capA, &d.r_car_begin));
   VS_TRY(ralloc(r, capA, &d.r_class));
   VS_TRY(ralloc(r, capA, &d.r_gt0));
-  VS_TRY(ralloc(r, capS, &d.carriers));
+  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  {
+    uint8_t* arena = nullptr;
+    VS_TRY(ralloc(r, capS * d.car_width + 16, &arena));
+    d.carriers = arena;
+  }
   d.A = capA; d.S = capS;
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
@@ -886,7 +917,7 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
   if (!r || !view) return fail(VS_ERR_ARG, "null argument");
   VS_TRY(fetch_headers(r));
   if (with_carriers && !r->have_carriers) {
-    VS_TRY(fetch(r->idx, r->h_carriers, (const uint32_t*)r->d.carriers, r->d.S));
+    VS_TRY(fetch_carriers(r, 0, r->d.S, r->h_carriers));
     HIP_TRY(hipStreamSynchronize(r->idx->stream));
     r->have_carriers = true;
   }
@@ -955,11 +986,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   const uint32_t* car = nullptr;
   if (r->have_carriers) car = r->h_carriers.data() + c0;
   else {
-    r->slice_carriers.resize(c1 - c0);
-    if (c1 > c0) {
-      HIP_TRY(hipMemcpyAsync(r->slice_carriers.data(), r->d.carriers + c0, (c1 - c0) * 4, hipMemcpyDeviceToHost, idx->stream));
-      HIP_TRY(hipStreamSynchronize(idx->stream));
-    }
+    VS_TRY(fetch_carriers(r, c0, c1 - c0, r->slice_carriers));
     car = r->slice_carriers.data();
   }
   std::string& out = r->text;

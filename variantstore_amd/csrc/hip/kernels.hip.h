@@ -33,6 +33,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vsamd {
 
@@ -85,7 +86,8 @@ struct DevResult {
   uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_site, *r_region, *r_class;
   uint64_t* r_car_begin;
   uint64_t* r_gt0;
-  uint32_t* carriers;
+  void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
+  uint32_t car_width, pad3_; // bytes per carrier word in the arena: 2 or 4
   // latency path: sizes are decided on the device ({slots, carriers, any-slow, overflow}); NULL otherwise
   const uint64_t* dyn_totals;
 };
@@ -384,6 +386,10 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 //          is requested before the current one is expanded.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 32;
+#ifndef VS_FILL_CHUNK
+#define VS_FILL_CHUNK 64
+#endif
+constexpr uint32_t kFillChunk = VS_FILL_CHUNK;   // variant slots per wave task (<= 64)
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
 // per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
 constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
@@ -395,7 +401,7 @@ __host__ __device__ inline uint32_t slice_gt_words(uint32_t n_samples) {
   if (b < 1024 + 16) b = 1024 + 16;         // the first 1 KiB is written by all lanes
   return b / 4;
 }
-__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) { return ((256 + n_samples + 8 + 7) & ~7u) / 2; }
+__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) { return ((512 + n_samples + 8 + 7) & ~7u) / 2; }
 __host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
   return kRowWords + slice_gt_words(n_samples) + slice_ids_words(n_samples);
 }
@@ -468,19 +474,22 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   const uint64_t A = r.dyn_totals ? (r.dyn_totals[3] ? 0 : r.dyn_totals[0]) : r.A;
-  const uint64_t nchunks = (A + 63) >> 6;
+  const uint64_t nchunks = (A + kFillChunk - 1) / kFillChunk;
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
-  uint32_t* __restrict__ carriers = r.carriers;
+  // carrier word in the arena: 16 bits when every sample id fits 13 bits (the non-WIDE instantiation), else 32
+  using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
+  constexpr uint32_t kGtShift = WIDE ? 29 : 13;
+  CT* __restrict__ carriers = reinterpret_cast<CT*>(r.carriers);
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
 
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const uint64_t a = (chunk << 6) + lane;
+    const uint64_t a = chunk * kFillChunk + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
-    if (a < A) {
+    if (a < A && lane < kFillChunk) {
       cnt = r.r_car_count[a];
       cls = r.r_class[a];
       gt0 = r.r_gt0[a];
@@ -491,7 +500,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       for (uint32_t k = 0; k < cnt; ++k) {
         const uint64_t c = gt0 + k;
         const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
-        carriers[cb + k] = im.car_sid[c] | (nib << 29);
+        carriers[cb + k] = (CT)(im.car_sid[c] | (nib << kGtShift));
       }
       continue;
     }
@@ -534,7 +543,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           const uint64_t cb_L = s_cb[L];
           const uint64_t g = gt0_L + k;
           const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
-          carriers[cb_L + k] = im.cls_list_ids[idb_L + k] | (nib << 29);
+          carriers[cb_L + k] = (CT)(im.cls_list_ids[idb_L + k] | (nib << kGtShift));
         }
       }
     }
@@ -595,21 +604,19 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
         if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
       }
-      uint32_t* out = carriers + cb_t;
-      if (WIDE && (!staged || wpc > 64)) {
-        // rows wider than one wave or more than 4096 staged genotypes: generic path
-        expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, out, lane);
-        word_cur = word_next;
-        continue;
+      if constexpr (WIDE) {
+        if (!staged || wpc > 64) {
+          // rows wider than one wave or more than 4096 staged genotypes: generic path
+          expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, carriers + cb_t, lane);
+          word_cur = word_next;
+          continue;
+        }
       }
       uint64_t mine = word_cur;
       if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
-      const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
-      uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
-      const uint32_t endpos = a0 + cnt_t;
       if ((ablate & 2) && cnt_t <= kMidMax) { word_cur = word_next; continue; }
       if ((ablate & 4) && cnt_t > kMidMax) { word_cur = word_next; continue; }
-      if (!WIDE) {
+      if constexpr (!WIDE) {
         // ---- slice path: every lane owns wpc consecutive bits of the row (64 x wpc bits = the whole row), peels
         //      them into a 16-bit id list in LDS at its prefix-sum position, then the list leaves in 1 KiB-aligned
         //      blocks, one 16-byte store per lane, genotypes merged from the raw nibble stream on the way out.
@@ -632,8 +639,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           const uint32_t up = __shfl_up(incl, d, 64);
           if (lane >= (uint32_t)d) incl += up;
         }
-        const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
-        uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+        const uint32_t a1k = (uint32_t)(cb_t & 511);        // offset of the variant inside its 1 KiB block (512 x 2 B)
+        uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
         const uint32_t end1k = a1k + cnt_t;
         uint32_t j = a1k + incl - pc;                       // list index of this lane's first carrier
         while (lo) {
@@ -644,29 +651,33 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           ids16[j++] = (uint16_t)(b0s + 32 + __builtin_ctz(hi));
           hi &= hi - 1;
         }
-        // copy-out: lane q of a pass owns list entries 4q..4q+3; their nibbles are 16 consecutive bits of the
-        // stream.  nibble index = list index + D; the staging is biased by 32 nibbles so that the first, partly
-        // valid quad (entries before a1k are not the variant's) still addresses forwards.
+        // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32
+        // consecutive bits of the stream.  nibble index = list index + D; the staging is biased by 32 nibbles so
+        // that the first, partly valid group (entries before a1k are not the variant's) still addresses forwards.
         const uint32_t D = nshift + 32 - a1k;
-        for (uint32_t q4 = lane * 4; q4 < end1k; q4 += 256) {
-          if (q4 + 4 <= a1k) continue;
-          const uint2 iw = *reinterpret_cast<const uint2*>(ids16 + q4);
-          const uint32_t n0 = q4 + D;
+        for (uint32_t q8 = lane * 8; q8 < end1k; q8 += 512) {
+          if (q8 + 8 <= a1k) continue;
+          const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
+          const uint32_t n0 = q8 + D;
           const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
           const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
-          uint4 v;
-          v.x = (iw.x & 0xFFFFu) | (n << 29);
-          v.y = (iw.x >> 16) | ((n << 25) & 0xE0000000u);
-          v.z = (iw.y & 0xFFFFu) | ((n << 21) & 0xE0000000u);
-          v.w = (iw.y >> 16) | ((n << 17) & 0xE0000000u);
-          if (q4 >= a1k && q4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + q4) = v;
+          uint4 v;   // two carriers per word: id | gt << 13 in each half
+          v.x = iw.x | ((n & 0x7u) << 13) | ((n & 0x70u) << 25);
+          v.y = iw.y | ((n & 0x700u) << 5) | ((n & 0x7000u) << 17);
+          v.z = iw.z | ((n & 0x70000u) >> 3) | ((n & 0x700000u) << 9);
+          v.w = iw.w | ((n & 0x7000000u) >> 11) | ((n & 0x70000000u) << 1);
+          if (q8 >= a1k && q8 + 8 <= end1k) *reinterpret_cast<uint4*>(g1k + q8) = v;
           else {
             const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (q4 + i >= a1k && q4 + i < end1k) g1k[q4 + i] = e[i];
+            for (int i = 0; i < 8; ++i)
+              if (q8 + i >= a1k && q8 + i < end1k) g1k[q8 + i] = (uint16_t)(e[i >> 1] >> ((i & 1) * 16));
           }
         }
       } else if (cnt_t <= kMidMax) {
+        const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
+        uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
+        const uint32_t endpos = a0 + cnt_t;
         // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
         const uint32_t pc = __popcll(mine);
         uint32_t incl = pc;
@@ -1294,8 +1305,12 @@ __global__ void __launch_bounds__(256) k_digest(DevImage im, DevResult r, uint64
     if (r.r_flags[a] & kVarDropped) continue;
     uint64_t h = 0;
     const uint32_t cnt = r.r_car_count[a];
-    const uint32_t* car = r.carriers + r.r_car_begin[a];
-    for (uint32_t k = lane; k < cnt; k += 64) h += mix64(((uint64_t)car[k] << 32) | k);
+    const uint32_t* car32 = reinterpret_cast<const uint32_t*>(r.carriers) + r.r_car_begin[a];
+    const uint16_t* car16 = reinterpret_cast<const uint16_t*>(r.carriers) + r.r_car_begin[a];
+    for (uint32_t k = lane; k < cnt; k += 64) {   // the digest is defined over the 32-bit form of a carrier word
+      const uint32_t c = r.car_width == 2 ? ((uint32_t)(car16[k] & 0x1FFFu) | ((uint32_t)(car16[k] >> 13) << 29)) : car32[k];
+      h += mix64(((uint64_t)c << 32) | k);
+    }
     if (lane == 0) {
       uint64_t s = mix64(r.r_region[a] * 0x9E3779B97F4A7C15ULL + r.r_pos[a]);
       for (uint32_t i = 0; i < r.r_ref_len[a]; ++i) s = mix64(s ^ (im.seq_codes[r.r_ref_off[a] + i] + 1));
