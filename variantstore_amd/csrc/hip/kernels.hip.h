@@ -425,6 +425,19 @@ __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (no LDS round trips): Hillis-Steele
+// inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of each odd row's
+// predecessor into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+
 // 32 packed genotype nibbles (one uint4) -> 32 bytes in LDS, nibble order preserved.
 __device__ __forceinline__ void stage_unpacked(uint8_t* dst, uint4 n) {
   uint32_t in[4] = {n.x, n.y, n.z, n.w};
@@ -516,12 +529,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
       const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
       const uint32_t c = sp ? cnt : 0u;
-      uint32_t incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += up;
-      }
+      const uint32_t incl = wave_inclusive_scan(c);
       const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
       if (total) {
         // per-variant parameters go through LDS (not lane shuffles: in the last pass the owning lane may be idle)
@@ -633,12 +641,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         slice &= (1ULL << wpc) - 1;
         uint32_t lo = (uint32_t)slice, hi = (uint32_t)(slice >> 32);
         const uint32_t pc = __popc(lo) + __popc(hi);
-        uint32_t incl = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t up = __shfl_up(incl, d, 64);
-          if (lane >= (uint32_t)d) incl += up;
-        }
+        const uint32_t incl = wave_inclusive_scan(pc);
         const uint32_t a1k = (uint32_t)(cb_t & 511);        // offset of the variant inside its 1 KiB block (512 x 2 B)
         uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
         const uint32_t end1k = a1k + cnt_t;
