@@ -215,8 +215,10 @@ def main():
     fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
     # The bytes this layout actually has to move (lower): 32 B of slot header per variant, the class row
     # only for variants above 32 carriers (rarer ones read a decoded id list, 4 B per carrier), half a byte
-    # of genotype per carrier in, one packed 4-byte word per carrier out.
-    fill_bytes_layout = nvar * 32 + (nvar - n_sparse) * W + 4 * car_sparse + (ncar + 1) // 2 + 4 * ncar
+    # of genotype per carrier in, one packed carrier word out: 2 bytes (id | gt << 13) when every sample id
+    # fits 13 bits (cohorts of at most 4032 samples), else 4.
+    car_word = 2 if info.num_samples <= 4032 else 4
+    fill_bytes_layout = nvar * 32 + (nvar - n_sparse) * W + 4 * car_sparse + (ncar + 1) // 2 + car_word * ncar
     fill_s = fill_ms / args.steps / 1e3
     achieved = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
     achieved_layout = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0

@@ -170,7 +170,8 @@ typedef struct {
   const uint64_t* car_begin;     /* [n_slots] first carrier of the slot */
   const uint32_t* car_count;     /* [n_slots] Variant::samples.size() */
   uint64_t n_carriers;
-  const uint32_t* carriers;      /* sample id | gt << 29, s_info order; NULL when carriers were not fetched */
+  const uint32_t* carriers;      /* sample id | gt << 29, s_info order; NULL when carriers were not fetched.  (In HBM the
+                                  * arena holds 16-bit words for cohorts of at most 4032 samples; the copy widens them.) */
   const char* seq_pool;          /* index-owned: one character per base */
 } vs_result_view;
 
