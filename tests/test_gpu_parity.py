@@ -337,6 +337,11 @@ def _parse_rows(text):
     (302, dict(p_same=0.25, p_near=0.6)),
     (303, dict(n_samples=70, carrier_p=0.2, ref_len=3000, n_rows=90)),
     (304, dict(n_samples=40, carrier_p=0.004, ref_len=2500, n_rows=60)),   # explicit sample ids
+    # crowded rows that stop a third into the reference, repeated positions (zero-length dummy ref nodes at the
+    # last sites): the step back from beyond the last variant must land on the FIRST reportable slot at or after
+    # the find() image, not on the last slot (found by tools/stress_parity.py, cohort 12199)
+    (305, dict(ref_len=1352, n_rows=370, n_samples=5, p_ins=0.15, p_del=0.27, p_multi=0.36, p_mnp=0.1, p_near=0.86,
+               carrier_p=0.05, p_same=0.5, max_indel=2)),
 ])
 def test_type1_closest_var_matches_oracle(seed, kw, tmp_path):
     """Query type 1 at EVERY position of the reference (and past its end), text-exact, including the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (GPU): many small cohorts of varied shape, every region compared with the
-CPU oracle as text, for query types 6 and 4.  Usage: python tools/stress_parity.py [n_cohorts] [seed0]"""
+CPU oracle as text, for all seven query types.  Usage: python tools/stress_parity.py [n_cohorts] [seed0]"""
 import os
 import sys
 import tempfile
@@ -21,7 +21,7 @@ for c in range(n_cohorts):
     seed = seed0 + c
     rng = np.random.default_rng(seed)
     kw = dict(ref_len=int(rng.integers(300, 6000)), n_rows=int(rng.integers(5, 400)),
-              n_samples=int(rng.choice([1, 2, 5, 9, 40, 70, 130])), p_ins=float(rng.uniform(0, 0.35)),
+              n_samples=int(rng.choice([1, 2, 5, 9, 40, 70, 130, 300, 700])), p_ins=float(rng.uniform(0, 0.35)),
               p_del=float(rng.uniform(0, 0.35)), p_multi=float(rng.uniform(0, 0.4)), p_mnp=float(rng.uniform(0, 0.15)),
               p_near=float(rng.uniform(0, 0.9)), carrier_p=float(rng.choice([0.004, 0.05, 0.3, 0.7])),
               unphased_p=float(rng.uniform(0, 0.3)), missing_p=float(rng.uniform(0, 0.1)),
@@ -63,6 +63,57 @@ for c in range(n_cohorts):
             if r4.region_text(q) != text:
                 bad += 1
                 print(f"MISMATCH t4 cohort {seed} sample {sample} region {x}:{y}\n--- gpu\n{r4.region_text(q)}--- oracle\n{text}")
+        # ---- types 1 and 7 ----
+        L = vs.info().ref_length
+        positions = [int(p) for p in rng.integers(0, L + 30, size=80)]
+        r1 = vs.closest_var(positions)
+        f1 = r1.view(False)["region_flags"]
+        rows = []
+        for q, p in enumerate(positions):
+            n, text = orc.closest_var(p)
+            checked += 1
+            if (n < 0) != bool(f1[q] & 4) or (n >= 0 and r1.region_text(q) != text):
+                bad += 1
+                print(f"MISMATCH t1 cohort {seed} pos {p}")
+            if n > 0:
+                for line in text.split("\n")[1:-1]:
+                    a, b, c_, _ = line.split("\t")
+                    rows.append((int(a), b, c_))
+        rows = rows[:60] + [(p, "A", "C") for p in positions[:20]]
+        if rows:
+            r7 = vs.samples_has_var([x[0] for x in rows], [x[1] for x in rows], [x[2] for x in rows])
+            f7 = r7.view(False)["region_flags"]
+            for q, (p, a, b) in enumerate(rows):
+                want = orc.samples_has_var(p, a, b)
+                checked += 1
+                if (want is None) != bool(f7[q] & 4) or (want is not None and r7.region_text(q) != want):
+                    bad += 1
+                    print(f"MISMATCH t7 cohort {seed} {p} {a} {b}")
+            r7.close()
+        r1.close()
+        # ---- types 2, 3 and 5 (sample coordinates) ----
+        sc_regions = regions[:50]
+        for smp in ("ref", sample):
+            for coords in (False, True):
+                rs = vs.query_sample_seq(sc_regions, smp, sample_coordinates=coords)
+                fl, seqs = rs.sequences()
+                for q, (x, y) in enumerate(sc_regions):
+                    n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, smp)
+                    checked += 1
+                    okq = (bool(fl[q] & 8) if n == -1 else bool(fl[q] & 2) if n == -3 else (not fl[q] and seqs[q] == seq))
+                    if not okq:
+                        bad += 1
+                        print(f"MISMATCH t{3 if coords else 2} cohort {seed} sample {smp} region {x}:{y} code {n} flags {fl[q]}")
+                rs.close()
+            r5 = vs.get_sample_var_in_sample(sc_regions, smp)
+            f5 = r5.view(False)["region_flags"]
+            for q, (x, y) in enumerate(sc_regions):
+                n, text = orc.get_sample_var_in_sample(x, y, smp)
+                checked += 1
+                if (n == -1) != bool(f5[q] & 8) or (n >= 0 and r5.region_text(q) != text):
+                    bad += 1
+                    print(f"MISMATCH t5 cohort {seed} sample {smp} region {x}:{y}")
+            r5.close()
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "

@@ -948,14 +948,23 @@ __global__ void __launch_bounds__(256) k_point_bounds(DevImage im, DevResult r, 
       const uint32_t s2 = next_valid_slot(im, slot_of_find(im, (uint64_t)cur_pos));
       if (s2 < P) chosen = s2;
       else if (im.s_carpre[im.G] == 0) fl = kRegionNotFound;  // reaches cur_pos == 1: returns false
-      else {  // the last slot with a reportable branch
+      else {
+        // The first call that finds something is the one at the largest position whose find() slot is not
+        // beyond Z, the last slot with a reportable branch; it reports the first such slot from there on
+        // (slots between two find() images are the zero-length dummy nodes' successors, so that need not be Z).
         const uint64_t total = im.s_carpre[im.G];
         uint32_t lo = 0, hi = P - 1;
         while (lo < hi) {
           const uint32_t m = lo + ((hi - lo) >> 1);
           if (im.s_carpre[im.rp_cand_prefix[m + 1]] >= total) hi = m; else lo = m + 1;
         }
-        chosen = lo;
+        const uint32_t Z = lo;
+        uint64_t rlo = 0, rhi = im.R - 1;   // largest rank whose first slot is <= Z (rank 0 maps to slot 0)
+        while (rlo < rhi) {
+          const uint64_t m = rlo + ((rhi - rlo + 1) >> 1);
+          if (im.rank_to_slot[m] <= Z) rlo = m; else rhi = m - 1;
+        }
+        chosen = next_valid_slot(im, im.rank_to_slot[rlo]);
       }
     }  // else: the loop is not entered, vars stays empty and the call returns true
   }
