@@ -377,9 +377,9 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       if (gt_words < 448) gt_words = 448;   // the medium path keeps 640 ids at word 256..
       const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
       if (idx->d.wpc <= 63)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -559,15 +559,15 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
   hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
   {
-    const uint64_t nchunks = (capA + 63) / 64;
-    const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 2048);
+    const uint64_t nchunks = (capA + kFillChunkSmall - 1) / kFillChunkSmall;
+    const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 4096);
     uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
     if (gt_words < 448) gt_words = 448;
     const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
     if (idx->d.wpc <= 63)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));

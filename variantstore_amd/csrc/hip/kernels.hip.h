@@ -386,10 +386,8 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 //          is requested before the current one is expanded.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 32;
-#ifndef VS_FILL_CHUNK
-#define VS_FILL_CHUNK 64
-#endif
-constexpr uint32_t kFillChunk = VS_FILL_CHUNK;   // variant slots per wave task (<= 64)
+constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
+constexpr uint32_t kFillChunkSmall = 8;      // latency launches (a handful of regions): more waves per region
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
 // per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
 constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
@@ -481,13 +479,13 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
 // fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
 // one wave of occupancy -- is compiled out.
-template <bool WIDE>
+template <bool WIDE, uint32_t CH>
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   const uint64_t A = r.dyn_totals ? (r.dyn_totals[3] ? 0 : r.dyn_totals[0]) : r.A;
-  const uint64_t nchunks = (A + kFillChunk - 1) / kFillChunk;
+  const uint64_t nchunks = (A + CH - 1) / CH;
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
@@ -499,10 +497,10 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
 
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const uint64_t a = chunk * kFillChunk + lane;
+    const uint64_t a = chunk * CH + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
-    if (a < A && lane < kFillChunk) {
+    if (a < A && lane < CH) {
       cnt = r.r_car_count[a];
       cls = r.r_class[a];
       gt0 = r.r_gt0[a];
