@@ -143,6 +143,10 @@ int vs_query_sample_var_in_sample(vs_index* idx, const vs_region* regions, uint6
 /* host view of a sequence result: region i is chars[seq_begin[i] .. seq_begin[i+1]) */
 int vs_result_get_sequences(vs_result* r, uint64_t* n_regions, const uint8_t** region_flags, const uint64_t** seq_begin,
                             const char** chars);
+/* `variantstore draw` (src/commands.cc:217-242 -> draw_subgraph, include/query.h:825-842 -> createDotGraph,
+ * include/dot_graph.h:71-132): the vertices within `radius` hops of the vertex at `pos` (on the path of `sample`;
+ * NULL or "ref" = the reference) as a Graphviz file.  Host-only; works on handles opened without a device. */
+int vs_index_draw_subgraph(const vs_index* idx, uint64_t pos, uint64_t radius, const char* sample, const char* outfile);
 /* batched Index::find (index.h:119-133): vertex id of the ref node covering each position */
 int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vertex_out);
 

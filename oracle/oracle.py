@@ -46,6 +46,8 @@ def _load():
             fn.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
         lib.vso_last_seq.restype = C.c_void_p
         lib.vso_last_seq.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.vso_draw_subgraph.restype = C.c_int
+        lib.vso_draw_subgraph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
         lib.vso_raw_text.restype = C.c_void_p
         lib.vso_raw_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.vso_last_text.restype = C.c_void_p
@@ -129,6 +131,14 @@ class Oracle:
         """Query type 5: (n_variants, text); n == -1 non-terminating, -2 unknown sample."""
         n = self._lib.vso_get_sample_var_in_sample(self._h, x, y, sample.encode())
         return n, (self.last_text() if n >= 0 else None)
+
+    def draw_subgraph(self, pos, radius, sample="ref"):
+        """`variantstore draw`: the text of graph.dot, or None for an unknown sample."""
+        if self._lib.vso_draw_subgraph(self._h, pos, radius, sample.encode()) != 0:
+            return None
+        n = C.c_uint64()
+        p = self._lib.vso_raw_text(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode("latin-1")
 
     def last_text(self):
         n = C.c_uint64()

@@ -23,6 +23,7 @@
 //   closest_var (type 1), samples_has_var (type 7)         include/query.h:441-483, 792-823
 //   query_sample_from_ref (2), query_sample_from_sample (3) include/query.h:118-261
 //   get_sample_var_in_sample (5)                           include/query.h:490-612
+//   draw_subgraph / createDotGraph                         include/query.h:825-842, include/dot_graph.h:42-132
 //
 // Input: the "plain dump" of an index (HostGraph::write_plain) -- the decoded
 // content of the index directory.  Neighbour sets are rebuilt here with the
@@ -783,6 +784,73 @@ struct Oracle {
     return (long)last_vars.size();
   }
 
+  // ---- `variantstore draw` ----
+  bool is_ref_node(const Vertex* v) {  // dot_graph.h:42-52
+    for (size_t i = 0; i < v->s_info.size(); i++)
+      if (get_sample_id(*v, (uint32_t)i) == 0) return true;
+    return false;
+  }
+  std::string dot_label(const Vertex* v) {  // get_samples, dot_graph.h:54-69
+    std::string samples;
+    samples += "[ label=\"" + std::to_string(v->vertex_id) + " l:" + std::to_string(static_cast<int>(v->length)) + "\n(";
+    for (size_t i = 0; i < v->s_info.size(); ++i) {
+      const SampleInfo& s = v->s_info[i];
+      uint32_t s_id = get_sample_id(*v, (uint32_t)i);
+      samples += get_sample_name(s_id) + " i:" + std::to_string(static_cast<int>(s.index));
+      if (i + 1 < v->s_info.size()) samples += "\n";
+    }
+    samples += ")\"]";
+    return samples;
+  }
+  std::string create_dot_graph(uint32_t v, uint64_t radius) {  // dot_graph.h:71-132
+    std::string labels, ref, sample, out;
+    {
+      VGIterator it(this, v, radius);
+      while (!it.done()) {
+        labels += std::to_string((*it)->vertex_id) + dot_label(*it) + "\n";
+        ++it;
+      }
+    }
+    out += "digraph {\n";
+    out += labels;
+    VGIterator it(this, v, radius);
+    ref += "\tsubgraph cluster_0 {\n";
+    ref += "\t\tlabel=\"reference\";\n";
+    while (!it.done()) {
+      uint64_t node_id = (*it)->vertex_id;
+      VGIterator node(this, (uint32_t)node_id, 1);
+      ++node;
+      while (!node.done()) {
+        uint64_t neibor_id = (*node)->vertex_id;
+        if (is_ref_node(*node) && is_ref_node(*it)) {
+          ref += "\t\t" + std::to_string(node_id) + " -> ";
+          ref += std::to_string(neibor_id) + "\n";
+        } else {
+          sample += "\t" + std::to_string(node_id) + " -> ";
+          sample += std::to_string(neibor_id) + "\n";
+        }
+        ++node;
+      }
+      ++it;
+    }
+    ref += "\t}\n";
+    out += ref;
+    out += sample;
+    out += "}";
+    return out;
+  }
+  int draw_subgraph(uint64_t pos, uint64_t radius, const std::string& sample_id) {  // query.h:825-842
+    uint32_t v;
+    if (sample_id == REF) v = find(pos);
+    else {
+      if (sampleid_map.find(sample_id) == sampleid_map.end()) return -2;
+      uint64_t ref_pos = 0, sample_pos = 0;
+      v = get_prev_vertex_with_sample(pos, sample_id, ref_pos, sample_pos);
+    }
+    last_text = create_dot_graph(v, radius);
+    return 0;
+  }
+
   void format_last() {
     last_text.clear();
     print_header(last_text);
@@ -906,6 +974,10 @@ const char* vso_last_seq(void* h, uint64_t* len) {
 // type 5: number of variants (vso_last_text formats them), -1 / -2 as above
 long vso_get_sample_var_in_sample(void* h, uint64_t x, uint64_t y, const char* sample) {
   return ((Oracle*)h)->get_sample_var_in_sample(x, y, sample);
+}
+// `draw`: 0 and the .dot text in vso_raw_text, or -2 for an unknown sample
+int vso_draw_subgraph(void* h, uint64_t pos, uint64_t radius, const char* sample) {
+  return ((Oracle*)h)->draw_subgraph(pos, radius, sample);
 }
 const char* vso_raw_text(void* h, uint64_t* len) {
   Oracle* o = (Oracle*)h;

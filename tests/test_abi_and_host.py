@@ -70,3 +70,37 @@ def test_synthetic_is_deterministic_and_matches_its_vcf(tmp_path):
     a.export_plain(pa)
     b.export_plain(pb)
     assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
+def test_draw_subgraph_matches_the_oracle(golden_dir, tmp_path):
+    """`variantstore draw` (host-only): graph.dot text of the product against the literal restatement in the oracle,
+    on the goldens and on random cohorts, for several radii and start samples."""
+    import numpy as np
+    from helpers import write_random_cohort
+    from oracle.oracle import Oracle
+    from variantstore_amd import VariantStore
+    cases = [(os.path.join(golden_dir, "x.small.fa"), os.path.join(golden_dir, "g4.vcf"), ["S2", "S10", "S1"]),
+             (os.path.join(golden_dir, "x.fa"), os.path.join(golden_dir, "x.vcf"), ["1"])]
+    for seed, kw in ((601, dict()), (602, dict(p_same=0.3, p_near=0.6, p_multi=0.3)),
+                     (603, dict(n_samples=40, carrier_p=0.004, ref_len=2500, n_rows=60))):
+        fa, vcf, names = write_random_cohort(str(tmp_path), seed, **kw)
+        cases.append((fa, vcf, names[:3]))
+    checked = 0
+    for i, (fa, vcf, names) in enumerate(cases):
+        vs = VariantStore.from_vcf(fa, vcf, device=-1)
+        plain = os.path.join(tmp_path, f"p{i}.bin")
+        vs.export_plain(plain)
+        orc = Oracle(plain)
+        L = vs.info().ref_length
+        rng = np.random.default_rng(i)
+        for pos in [1, 9, 20, L // 2, L - 1, L + 5] + [int(x) for x in rng.integers(1, L, size=6)]:
+            for radius in (0, 1, 2, 5):
+                for smp in ["ref"] + names[:2]:
+                    out = os.path.join(tmp_path, "g.dot")
+                    vs.draw_subgraph(pos, radius, out, sample=smp)
+                    assert open(out, encoding="latin-1").read() == orc.draw_subgraph(pos, radius, smp), (i, pos, radius, smp)
+                    checked += 1
+    assert checked > 500
+    # shape of the file (dot_graph.h:25-39)
+    text = open(os.path.join(tmp_path, "g.dot"), encoding="latin-1").read()
+    assert text.startswith("digraph {\n") and "\tsubgraph cluster_0 {\n\t\tlabel=\"reference\";\n" in text and text.endswith("}")

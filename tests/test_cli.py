@@ -152,3 +152,16 @@ def test_query_types_2_3_5(golden_dir, tmp_path):
     assert "Number of variants get_sample_var_in_sample: 3" in msgs
     assert open(ofile).read() == ("Pos\tRef\tAlt\tSamples\n9\tG\tA\tS2(1/1) S10(0|1) S1(1|0) \n"
                                   "20\t\tC\tS2(0|1) S10(1|0) \n39\tT\t\tS10(0|1) S1(1|0) \n")
+
+
+def test_draw_writes_graph_dot(golden_dir, tmp_path):
+    """`variantstore draw -p <dir> -r <pos> -h <hops>` (commands.cc:217-242) is host-only."""
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    out = subprocess.run([CLI, "draw", "-p", d, "-r", "100", "-h", "3"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    msgs = _msgs(out.stdout)
+    assert "Looking up vertex corresponding to the queried region" in msgs
+    assert "Chromosome: x #Vertices: 212 #Edges: 0 Seq length: 1074" in msgs
+    text = open(os.path.join(d, "graph.dot")).read()
+    assert text.startswith("digraph {\n") and text.endswith("}") and " -> " in text and "ref i:" in text

@@ -78,6 +78,7 @@ SYMBOLS = {
     "vs_query_sample_var_in_sample": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(_P)]),
     "vs_result_get_sequences": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint8)),
                                           C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_char_p)]),
+    "vs_index_draw_subgraph": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p]),
     "vs_index_find": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),
     "vs_result_get_view": (C.c_int, [_P, C.c_int, C.POINTER(ResultView)]),
     "vs_result_totals": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

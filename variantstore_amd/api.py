@@ -328,3 +328,9 @@ class VariantStore:
         _check(self._lib.vs_query_sample_var_in_sample(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                        C.byref(h)), "vs_query_sample_var_in_sample")
         return QueryResult(self, h)
+
+    def draw_subgraph(self, pos, radius, outfile, sample=None):
+        """`variantstore draw` (query.h:825-842, dot_graph.h:71-132): Graphviz file of the neighbourhood of the
+        vertex at `pos`.  Host-only."""
+        _check(self._lib.vs_index_draw_subgraph(self._h, int(pos), int(radius), sample.encode() if sample else None,
+                                                str(outfile).encode()), "vs_index_draw_subgraph")

@@ -93,6 +93,8 @@ bool dir_exists(const std::string& p) {
 struct Args {
   std::string cmd, ref, vcf, prefix, region, outfile, sample, alt, refseq, batch_out;
   uint32_t type = 0, mode = 0;
+  uint64_t hops = 0;
+  bool have_hops = false;
   bool have_type = false, have_mode = false, verbose = false;
   int device = 0;
 };
@@ -103,14 +105,19 @@ int usage() {
                "        variantstore query -p <output-prefix> -t <query-type> -r <region> -m <mode> [-o <outfile>]\n"
                "                     [-s <sample-name>] [-a <alt-seq>] [-b <ref-seq>] [-v]\n"
                "                     [--batch-out <file>] [--device <n>]\n"
+               "        variantstore draw -p <output-prefix> -r <region> -h <hops> [-s <sample-name>]\n"
                "        variantstore help\n\n"
                "OPTIONS\n"
-               "        <query-type>  4  Get sample's variants in reference coordinates.   (GPU)\n"
-               "                      6  Get variants in reference coordinates.            (GPU)\n"
-               "                      1,2,3,5,7 are not part of this engine.\n"
-               "        <region>      <start>:<end>, regions separated by ',', or @file with one region per line\n"
-               "        <mode>        READ_INDEX_ONLY: 0, READ_COMPLETE_GRAPH:1 (both fully resident here)\n";
-  return 0;
+               "        <query-type>  1  Return closest variant in reference coordinates.\n"
+               "                      2  Get sample's sequence in reference coordinates.\n"
+               "                      3  Get sample's sequence in sample coordinates.\n"
+               "                      4  Get sample's variants in reference coordinates.\n"
+               "                      5  Get sample's variants in sample coordinates.\n"
+               "                      6  Get variants in reference coordinates.\n"
+               "                      7  Return samples with a given mutation.\n"
+               "        <region>      <start>:<end>[,<start>:<end>...] or @file with one region per line\n"
+               "        <mode>        READ_INDEX_ONLY: 0, READ_COMPLETE_GRAPH: 1 (the index is always resident here)\n";
+  return EXIT_FAILURE;
 }
 
 int construct_main(const Args& a) {
@@ -271,6 +278,29 @@ int point_query_main(const Args& a, vs_index* idx, const std::vector<vs_region>&
   return EXIT_SUCCESS;
 }
 
+// `variantstore draw` (commands.cc:217-242): <prefix>/graph.dot for the neighbourhood of the vertex at the region's
+// start.  The reference's option grammar stores -s into the QUERY options (variantstore.cc:146-150), so its draw
+// always starts from the reference path; the same here.
+int draw_main(const Args& a) {
+  info("Loading Index ...");
+  info("Loading variant graph ...");
+  info("Read complete graph ..");
+  vs_index* idx = nullptr;
+  int rc = vs_index_open(a.prefix.c_str(), -1, &idx);   // host-only: nothing here runs on the GPU
+  if (rc != VS_OK) die(rc, "load");
+  vs_index_info inf;
+  vs_index_get_info(idx, &inf);
+  info("Graph stats:");
+  info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(inf.num_topology_keys) +
+       " #Edges: 0 Seq length: " + std::to_string(inf.seq_length));
+  auto regions = read_regions(a.region);
+  info("Looking up vertex corresponding to the queried region");
+  rc = vs_index_draw_subgraph(idx, std::get<0>(regions[0]), a.hops, "ref", (a.prefix + "/graph.dot").c_str());
+  if (rc != VS_OK) die(rc, "draw");
+  vs_index_close(idx);
+  return EXIT_SUCCESS;
+}
+
 int query_main(const Args& a) {
   info("Loading Index ...");
   info("Loading variant graph ...");
@@ -377,6 +407,12 @@ int main(int argc, char** argv) {
       else if (f == "-v" || f == "--vcf") a.vcf = need(i);
       else if (f == "-p" || f == "--output-prefix") a.prefix = need(i);
       else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
+    } else if (a.cmd == "draw") {
+      if (f == "-p" || f == "--output-prefix") a.prefix = need(i);
+      else if (f == "-r" || f == "--region") a.region = need(i);
+      else if (f == "-h" || f == "--hops") { a.hops = (uint64_t)atoll(need(i).c_str()); a.have_hops = true; }
+      else if (f == "-s" || f == "--sample-name") a.sample = need(i);
+      else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
     } else if (a.cmd == "query") {
       if (f == "-p" || f == "--output-prefix") a.prefix = need(i);
       else if (f == "-t" || f == "--type") { a.type = (uint32_t)atoi(need(i).c_str()); a.have_type = true; }
@@ -403,6 +439,10 @@ int main(int argc, char** argv) {
   if (a.cmd == "query") {
     if (a.prefix.empty() || !a.have_type || a.region.empty() || !a.have_mode) return usage();
     return query_main(a);
+  }
+  if (a.cmd == "draw") {
+    if (a.prefix.empty() || a.region.empty() || !a.have_hops) return usage();
+    return draw_main(a);
   }
   return usage();
 }

@@ -19,6 +19,7 @@
 #include "../host/synth.hpp"
 #include "../host/device_image.hpp"
 #include "../host/index_files.hpp"
+#include "../host/dot_graph.hpp"
 #include "kernels.hip.h"
 
 using namespace vsamd;
@@ -890,6 +891,26 @@ int vs_result_get_sequences(vs_result* r, uint64_t* n_regions, const uint8_t** r
   if (region_flags) *region_flags = r->h_flags.data();
   if (seq_begin) *seq_begin = r->h_byte_begin.data();
   if (chars) *chars = (const char*)r->h_chars.data();
+  return VS_OK;
+}
+
+int vs_index_draw_subgraph(const vs_index* idx, uint64_t pos, uint64_t radius, const char* sample, const char* outfile) {
+  if (!idx || !outfile) return fail(VS_ERR_ARG, "null argument");
+  uint32_t sid = 0;
+  if (sample && *sample && std::string(sample) != "ref") {
+    auto it = idx->sample_ids.find(sample);
+    if (it == idx->sample_ids.end()) return fail(VS_ERR_UNKNOWN_SAMPLE, "Sample not found: %s", sample);
+    sid = it->second;
+  }
+  try {
+    const std::string text = dot_text(idx->g, draw_start_vertex(idx->g, pos, sid), radius);
+    FILE* f = fopen(outfile, "wb");
+    if (!f) return fail(VS_ERR_IO, "Can't open the file graph output: %s", outfile);
+    fwrite(text.data(), 1, text.size(), f);
+    fclose(f);
+  } catch (const std::exception& e) {
+    return fail(VS_ERR_INTERNAL, "%s", e.what());
+  }
   return VS_OK;
 }
 
