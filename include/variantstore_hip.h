@@ -73,6 +73,8 @@ typedef struct {
   uint32_t sample_coordinates; /* != 0: also compute the per-carrier sample-coordinate indexes (the reference's
                                 * "Fixing sample indexes" pass, variant_graph.h:1919-1997) that query types 2, 3 and 5
                                 * read; 4 bytes per carrier record                                                      */
+  double max_af;             /* cap of the allele frequency; 0 = 0.5.  Small caps give somatic-like cohorts that the
+                              * constructor stores with explicit sample ids instead of class bit vectors          */
 } vs_synth_params;
 int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats* stats, vs_index** out);
 

@@ -548,3 +548,53 @@ def test_sample_coordinate_queries_need_the_indexes(tmp_path):
         vs.query_sample_seq([(100, 200)], "S00001")
     with pytest.raises(Exception, match="sample coordinates"):
         vs.get_sample_var_in_sample([(100, 200)], "S00001")
+
+
+def test_tcga_shaped_cohort_mixed_types(tmp_path):
+    """BASELINE config #5's shape at reduced scale: 10,000 samples, somatic-like sparse carriers (explicit sample ids,
+    not class bit vectors), 10 % indels; mixed query types 3 / 6 / 7 (the code's numbering) against the oracle."""
+    vs = VariantStore.synthetic(device=0, ref_length=3_000_000, num_variants=30_000, num_samples=10_000, seed=55,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6,
+                                af_exponent=2.0, max_af=0.0004, sample_coordinates=True)
+    info = vs.info()
+    assert not info.use_bit_vector and info.num_samples == 10_001
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(55)
+    starts = rng.integers(1, 2_990_000, size=400)
+    regions = [(int(s), int(s) + 8000) for s in starts]
+    assert _compare_t6(vs, orc, regions) == 400
+    # type 7 for every variant type 6 reports in the first regions (and a miss beside each)
+    rows = []
+    for x, y in regions[:60]:
+        rows += _parse_rows(orc.get_var_in_ref(x, y)[2])
+    qs = [(p, r, a) for p, r, a in rows] + [(p + 1, r, a) for p, r, a in rows]
+    res = vs.samples_has_var([q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs])
+    fl = res.view(False)["region_flags"]
+    hits = 0
+    for q, (p, r, a) in enumerate(qs):
+        want = orc.samples_has_var(p, r, a)
+        assert (want is None) == bool(fl[q] & 4) and (want is None or res.region_text(q) == want), qs[q]
+        hits += want is not None
+    assert hits > 5
+    # type 3 (a sample's sequence in its own coordinates) for carriers of some variants and for "ref"
+    carriers = sorted({s.split("(")[0] for x, y in regions[:40] for line in orc.get_var_in_ref(x, y)[2].split("\n")[1:-1]
+                       for s in line.split("\t")[3].split()})[:6]
+    assert len(carriers) >= 3
+    for smp in ["ref"] + carriers:
+        sub = regions[:80]
+        rs = vs.query_sample_seq(sub, smp, sample_coordinates=True)
+        fl3, seqs = rs.sequences()
+        good = 0
+        for q, (x, y) in enumerate(sub):
+            n, seq = orc.query_sample_from_sample(x, y, smp)
+            if n == -1:
+                assert fl3[q] & 8
+            elif n == -3:
+                assert fl3[q] & 2
+            else:
+                assert not fl3[q] and seqs[q] == seq, (smp, x, y)
+                good += 1
+        assert good > 60
+        rs.close()

@@ -25,7 +25,7 @@ class SynthParams(C.Structure):
     _fields_ = [("ref_length", C.c_uint64), ("num_variants", C.c_uint64), ("num_samples", C.c_uint32),
                 ("seed", C.c_uint64), ("first_pos", C.c_uint64), ("frac_ins", C.c_double), ("frac_del", C.c_double),
                 ("frac_multi", C.c_double), ("max_indel", C.c_uint32), ("af_exponent", C.c_double),
-                ("sample_coordinates", C.c_uint32)]
+                ("sample_coordinates", C.c_uint32), ("max_af", C.c_double)]
 
 
 class IndexInfo(C.Structure):

@@ -186,7 +186,8 @@ class VariantStore:
                         first_pos=kw.get("first_pos", 1000), frac_ins=kw.get("frac_ins", 0.0),
                         frac_del=kw.get("frac_del", 0.0), frac_multi=kw.get("frac_multi", 0.0),
                         max_indel=kw.get("max_indel", 6), af_exponent=kw.get("af_exponent", 3.0),
-                        sample_coordinates=1 if kw.get("sample_coordinates") else 0)
+                        sample_coordinates=1 if kw.get("sample_coordinates") else 0,
+                        max_af=float(kw.get("max_af", 0.0)))
         h = C.c_void_p()
         st = ConstructStats()
         _check(lib.vs_index_synthetic(C.byref(p), device, C.byref(st), C.byref(h)), "vs_index_synthetic")

@@ -647,6 +647,7 @@ int vs_index_synthetic(const vs_synth_params* p, int device, vs_construct_stats*
     sp.seed = p->seed; sp.first_pos = p->first_pos; sp.frac_ins = p->frac_ins; sp.frac_del = p->frac_del;
     sp.frac_multi = p->frac_multi; sp.max_indel = p->max_indel ? p->max_indel : 1; sp.af_exponent = p->af_exponent;
     sp.sample_coordinates = p->sample_coordinates != 0;
+    sp.max_af = (p->max_af > 0 && p->max_af < 0.5) ? p->max_af : 0.5;
     uint64_t nk = 0, ne = 0, sl = 0;
     SynthStats st = construct_synthetic(sp, idx->g, &nk, &ne, &sl);
     idx->cstats = vs_construct_stats{st.num_vars, st.num_mutations, st.num_mutations_samples, nk, ne, sl,

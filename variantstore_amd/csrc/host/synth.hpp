@@ -30,6 +30,7 @@ struct SynthParams {
   uint32_t max_indel = 6;
   double af_exponent = 3.0;
   bool sample_coordinates = false;
+  double max_af = 0.5;
 };
 
 struct SplitMix64 {
@@ -113,7 +114,7 @@ class SynthSource {
     }
     // genotypes: geometric skipping over the 2N haplotypes
     double af = std::pow(10.0, -p_.af_exponent * rng_.uniform());
-    if (af > 0.5) af = 0.5;
+    if (af > p_.max_af) af = p_.max_af;
     rec.carriers.clear();
     const uint64_t H = 2ull * p_.num_samples;
     const double lq = std::log1p(-af);
