@@ -506,14 +506,14 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = r.r_gt0[a];
       cb = r.r_car_begin[a];
     }
-    if (!im.use_bv) {
-      // explicit sample ids: a copy, lane per variant (lists are short in this mode)
+    const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
+    if (explicit_ids && cnt > kSparseMax) {
+      // long lists are rare in this mode: a plain copy, lane per variant (short ones go lane per carrier below)
       for (uint32_t k = 0; k < cnt; ++k) {
         const uint64_t c = gt0 + k;
         const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
         carriers[cb + k] = (CT)(im.car_sid[c] | (nib << kGtShift));
       }
-      continue;
     }
 
     // ---------------- sparse: lane per CARRIER ----------------
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
         uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
         s_off[lane] = incl - c;
-        s_idb[lane] = sp ? im.cls_list_begin[cls] : 0u;
+        s_idb[lane] = (sp && !explicit_ids) ? im.cls_list_begin[cls] : 0u;
         s_gt0[lane] = gt0;
         s_cb[lane] = cb;
         for (uint32_t e = lane; e < total; e += 64) {
@@ -549,13 +549,14 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           const uint64_t cb_L = s_cb[L];
           const uint64_t g = gt0_L + k;
           const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
-          carriers[cb_L + k] = (CT)(im.cls_list_ids[idb_L + k] | (nib << kGtShift));
+          const uint32_t id = explicit_ids ? im.car_sid[g] : im.cls_list_ids[idb_L + k];
+          carriers[cb_L + k] = (CT)(id | (nib << kGtShift));
         }
       }
     }
 
     // ---------------- mid / dense: wave per variant ----------------
-    uint64_t dmask = __ballot(cnt > kSparseMax);
+    uint64_t dmask = __ballot(cnt > kSparseMax && !explicit_ids);
     if (dmask == 0) continue;
     // Per-wave LDS block (4 KiB): one genotype BYTE per carrier (unpacked from the nibble
     // pool while staging, so the expansion loops read it with a single ds_read_u8);
