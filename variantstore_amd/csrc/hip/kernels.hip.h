@@ -368,22 +368,22 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 }
 
 // ---------------------------------------------------------------------------
-// Carrier expansion (k_fill_carriers).  One wave owns 64 consecutive variant slots; every lane
-// first gathers the metadata of "its" slot (all 64 gathers in flight together),
-// then the wave works through the chunk in two regimes:
+// Carrier expansion (k_fill_carriers).  One wave owns CH consecutive variant slots (64; 8 in latency launches);
+// every lane first gathers the metadata of "its" slot, then the wave works through the task in two regimes:
 //
-//  sparse  (<= kSparseMax carriers): LANE PER VARIANT.  The lane walks the class
-//          row of its own variant and peels the few set bits; its genotype
-//          nibbles were fetched beforehand as three unaligned 64-bit windows, so
-//          the peel loop is pure ALU + stores.  Consecutive slots own consecutive
-//          pieces of the carrier arena, so the lanes' small stores land in a
-//          handful of adjacent cache lines.
-//  dense   (>  kSparseMax carriers): WAVE PER VARIANT, BIT PER LANE.  The row is
-//          loaded once, coalesced (lane w holds word w); for every non-zero word
-//          the lanes whose bit is set compute their rank with mbcnt and store
-//          id|gt into consecutive arena words (fully coalesced), genotype
-//          nibbles are read as consecutive bytes.  The next dense variant's row
-//          is requested before the current one is expanded.
+//  sparse  (<= kSparseMax carriers, and every short list of an explicit-id cohort): LANE PER CARRIER.  The
+//          carriers of all sparse variants of the task form one list; a DPP prefix sum over the counts gives
+//          every variant its slice, a lane takes list entry e, finds its variant by bisection over the 64
+//          offsets (LDS), and expands that one carrier (id from the class's decoded id list or the explicit id
+//          pool, genotype nibble from the pool).
+//  others  WAVE PER VARIANT.  WIDE=false (cohorts of at most 4032 samples): LANE PER SLICE -- 64 lanes x wpc bits
+//          is the whole class row, every lane peels its own wpc bits into a 16-bit id list in LDS at its
+//          prefix-sum position; the list leaves in 1 KiB-aligned blocks, one 16-byte store per lane (8 carriers
+//          of 16 bits: id | gt << 13), genotypes merged from the raw nibble stream on the way out.  The next
+//          variant's row and nibbles are requested before the current one is expanded.
+//          WIDE=true (wider cohorts): the round-1 code -- medium variants lane per row word with an LDS id list,
+//          dense ones bit per lane (exec = row word, v_mbcnt rank) through a 512-entry LDS ring, 32-bit carrier
+//          words (id | gt << 29); rows wider than one wave take the out-of-line generic path.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 32;
 constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
