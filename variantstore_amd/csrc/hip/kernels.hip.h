@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       }
       // request the next variant's row and nibbles before expanding this one
       uint64_t word_next = 0;
-      nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0};
+      if (WIDE) { nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0}; }   // (the slice path never reads nibbles it did not load)
       if (dmask) {
         const int tn = __builtin_ctzll(dmask);
         const uint32_t cls_n = __builtin_amdgcn_readlane(cls, tn);
