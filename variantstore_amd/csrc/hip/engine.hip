@@ -73,9 +73,10 @@ struct vs_result {
   // host copies
   bool have_headers = false, have_carriers = false;
   std::vector<uint8_t> h_flags;
-  std::vector<uint64_t> h_var_begin, h_var_count, h_car_base, h_pos, h_car_begin;
+  std::vector<uint64_t> h_var_begin, h_var_count, h_car_base, h_pos, h_car_begin;   // h_car_begin: arena (padded) offsets
+  std::vector<uint64_t> h_car_begin_view;   // what views hand out: carrier lists back to back
   std::vector<uint32_t> h_ref_off, h_ref_len, h_alt_off, h_alt_len, h_vflags, h_car_count, h_carriers;
-  uint64_t n_variants = 0, n_carriers_kept = 0, n_bases = 0;
+  uint64_t n_variants = 0, n_carriers_kept = 0, n_bases = 0, n_view_carriers = 0;
   bool have_totals = false;
   std::string text;
   std::vector<uint32_t> slice_carriers;
@@ -232,7 +233,12 @@ static int build_device_image(vs_index* idx) {
     HIP_TRY(hipGetLastError());
   }
   std::vector<DevBuf> scratch;
-  VS_TRY(exclusive_scan<uint32_t>(idx, d.s_ncar, G, d.s_carpre, &scratch));
+  {  // arena offsets: prefix of the counts rounded up to the carrier alignment (kernels.hip.h: pad_car)
+    void* padded = nullptr;
+    VS_TRY(dev_alloc(idx, (G + 1) * 4, &padded, &scratch));
+    if (G) hipLaunchKernelGGL(k_pad_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, (const uint32_t*)d.s_ncar, (uint32_t*)padded, G);
+    VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)padded, G, d.s_carpre, &scratch));
+  }
   std::vector<uint32_t> h_dup(G), h_fl(G);
   if (G) {
     hipLaunchKernelGGL(k_mark_dups, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, d);
@@ -443,6 +449,12 @@ static int fetch_headers(vs_result* r) {
   VS_TRY(fetch(idx, r->h_car_begin, (const uint64_t*)d.r_car_begin, d.A));
   VS_TRY(fetch(idx, r->h_car_count, (const uint32_t*)d.r_car_count, d.A));
   HIP_TRY(hipStreamSynchronize(idx->stream));
+  r->h_car_begin_view.resize(d.A);
+  {
+    uint64_t acc = 0;
+    for (uint64_t a = 0; a < d.A; ++a) { r->h_car_begin_view[a] = acc; acc += r->h_car_count[a]; }
+    r->n_view_carriers = acc;
+  }
   for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
   r->have_headers = true;
   return VS_OK;
@@ -939,8 +951,13 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
   if (!r || !view) return fail(VS_ERR_ARG, "null argument");
   VS_TRY(fetch_headers(r));
   if (with_carriers && !r->have_carriers) {
-    VS_TRY(fetch_carriers(r, 0, r->d.S, r->h_carriers));
-    HIP_TRY(hipStreamSynchronize(r->idx->stream));
+    // the arena pads every variant's range; the view packs the lists back to back
+    std::vector<uint32_t> arena;
+    VS_TRY(fetch_carriers(r, 0, r->d.S, arena));
+    r->h_carriers.resize(r->n_view_carriers);
+    for (uint64_t a = 0; a < r->d.A; ++a)
+      if (r->h_car_count[a])
+        memcpy(r->h_carriers.data() + r->h_car_begin_view[a], arena.data() + r->h_car_begin[a], (size_t)r->h_car_count[a] * 4);
     r->have_carriers = true;
   }
   view->n_regions = r->d.Q;
@@ -952,9 +969,9 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
   view->ref_off = r->h_ref_off.data(); view->ref_len = r->h_ref_len.data();
   view->alt_off = r->h_alt_off.data(); view->alt_len = r->h_alt_len.data();
   view->var_flags = r->h_vflags.data();
-  view->car_begin = r->h_car_begin.data();
+  view->car_begin = r->h_car_begin_view.data();
   view->car_count = r->h_car_count.data();
-  view->n_carriers = r->d.S;
+  view->n_carriers = r->n_view_carriers;
   view->carriers = (with_carriers || r->have_carriers) ? r->h_carriers.data() : nullptr;
   view->seq_pool = r->idx->seq_chars.data();
   return VS_OK;
@@ -1006,8 +1023,8 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   const uint64_t a0 = r->h_var_begin[q], a1 = r->h_var_begin[q + 1];
   const uint64_t c0 = r->h_car_base[q], c1 = r->h_car_base[q + 1];
   const uint32_t* car = nullptr;
-  if (r->have_carriers) car = r->h_carriers.data() + c0;
-  else {
+  const bool from_view = r->have_carriers;
+  if (!from_view) {
     VS_TRY(fetch_carriers(r, c0, c1 - c0, r->slice_carriers));
     car = r->slice_carriers.data();
   }
@@ -1016,7 +1033,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   if (r->kind == 7) {  // samples_has_var's output line, query.h:811-816: `name gt` pairs with nothing between them
     for (uint64_t a = a0; a < a1; ++a) {
       if (r->h_vflags[a] & kVarDropped) continue;
-      const uint32_t* c = car + (r->h_car_begin[a] - c0);
+      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (r->h_car_begin[a] - c0);
       for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
         const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
         out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
@@ -1045,7 +1062,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
     out += '\t';
     out.append(idx->seq_chars, r->h_alt_off[a], r->h_alt_len[a]);
     out += '\t';
-    const uint32_t* c = car + (r->h_car_begin[a] - c0);
+    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (r->h_car_begin[a] - c0);
     for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
       const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
       out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");

@@ -65,7 +65,7 @@ struct DevImage {
   const uint8_t* seq_codes;
   // site table (one entry per branch of a ref-path node, ref-path order)
   uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev, *s_class;
-  uint64_t* s_carpre;  // [G+1] exclusive prefix of s_ncar
+  uint64_t* s_carpre;  // [G+1] exclusive prefix of pad_car(s_ncar): arena offsets relative to a region's first site
   uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
@@ -91,6 +91,15 @@ struct DevResult {
   // latency path: sizes are decided on the device ({slots, carriers, any-slow, overflow}); NULL otherwise
   const uint64_t* dyn_totals;
 };
+
+// Every variant's carrier range in the result arena starts on a multiple of 8 entries (16 bytes of 16-bit carrier
+// words) and owns the padding up to the next multiple: k_fill_carriers then writes whole 16-byte groups only.
+constexpr uint32_t kCarAlign = 8;
+__host__ __device__ __forceinline__ uint32_t pad_car(uint32_t n) { return (n + kCarAlign - 1) & ~(kCarAlign - 1); }
+__global__ void __launch_bounds__(256) k_pad_counts(const uint32_t* in, uint32_t* out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pad_car(in[i]);
+}
 
 // ones in bit positions [0, p): number of ref-node start indexes <= p
 __device__ __forceinline__ uint32_t rank1(const DevImage& im, uint64_t p) {
@@ -668,13 +677,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           v.y = iw.y | ((n & 0x700u) << 5) | ((n & 0x7000u) << 17);
           v.z = iw.z | ((n & 0x70000u) >> 3) | ((n & 0x700000u) << 9);
           v.w = iw.w | ((n & 0x7000000u) >> 11) | ((n & 0x70000000u) << 1);
-          if (q8 >= a1k && q8 + 8 <= end1k) *reinterpret_cast<uint4*>(g1k + q8) = v;
-          else {
-            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (q8 + i >= a1k && q8 + i < end1k) g1k[q8 + i] = (uint16_t)(e[i >> 1] >> ((i & 1) * 16));
-          }
+          *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
         }
       } else if (cnt_t <= kMidMax) {
         const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
               r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
             }
-            nvar++; ncar += c;
+            nvar++; ncar += pad_car(c);
           }
         }
         cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
@@ -884,7 +887,9 @@ __global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst
   dst[4 * q + 0] = region_base + q;
   dst[4 * q + 1] = (uint64_t)r.q_g0[q] | (fl << 32) | (dropped << 40);
   dst[4 * q + 2] = r.var_count[q];
-  dst[4 * q + 3] = r.car_base[q + 1] - r.car_base[q];
+  uint64_t ncar = 0;   // carriers of the reported variants (the arena range car_base[q+1] - car_base[q] includes padding)
+  for (uint64_t a = r.var_begin[q]; a < r.var_begin[q + 1]; ++a) ncar += r.r_car_count[a];
+  dst[4 * q + 3] = ncar;
 }
 
 // ---------------------------------------------------------------------------
@@ -1147,7 +1152,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
           r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
-        nvar++; ncar += c;
+        nvar++; ncar += pad_car(c);
         // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
       }
       cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
