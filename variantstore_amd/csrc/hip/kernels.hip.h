@@ -432,6 +432,13 @@ __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// (a & mask) | c in one VOP3 instruction; the mask must sit in an SGPR (no literals in VOP3 on gfx9)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask_sgpr, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask_sgpr), "v"(c));
+  return r;
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (no LDS round trips): Hillis-Steele
 // inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of each odd row's
 // predecessor into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
@@ -502,6 +509,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
   using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
   constexpr uint32_t kGtShift = WIDE ? 29 : 13;
   CT* __restrict__ carriers = reinterpret_cast<CT*>(r.carriers);
+  uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi));
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
 
@@ -649,7 +658,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         slice &= (1ULL << wpc) - 1;
         uint32_t lo = (uint32_t)slice, hi = (uint32_t)(slice >> 32);
         const uint32_t pc = __popc(lo) + __popc(hi);
-        const uint32_t incl = wave_inclusive_scan(pc);
+        uint32_t incl = wave_inclusive_scan(pc);
+        asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
         const uint32_t a1k = (uint32_t)(cb_t & 511);        // offset of the variant inside its 1 KiB block (512 x 2 B)
         uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
         const uint32_t end1k = a1k + cnt_t;
@@ -672,11 +682,12 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           const uint32_t n0 = q8 + D;
           const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
           const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
-          uint4 v;   // two carriers per word: id | gt << 13 in each half
-          v.x = iw.x | ((n & 0x7u) << 13) | ((n & 0x70u) << 25);
-          v.y = iw.y | ((n & 0x700u) << 5) | ((n & 0x7000u) << 17);
-          v.z = iw.z | ((n & 0x70000u) >> 3) | ((n & 0x700000u) << 9);
-          v.w = iw.w | ((n & 0x7000000u) >> 11) | ((n & 0x70000000u) << 1);
+          uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
+                     // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
           *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
         }
       } else if (cnt_t <= kMidMax) {
