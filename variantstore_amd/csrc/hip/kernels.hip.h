@@ -402,15 +402,21 @@ constexpr uint32_t kRingWords = 512;             // per wave: output ring of the
 constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
 // Slice path (cohorts of at most 4032 samples): per-wave LDS = row staging + raw genotype nibbles + 16-bit id list
 constexpr uint32_t kRowWords = 132;          // 65 x uint64 (the row and one zero word behind it), padded
+// layout: [raw nibbles][id list; the row staging aliases its start -- the slices are cut before the list is written]
 __host__ __device__ inline uint32_t slice_gt_words(uint32_t n_samples) {
-  uint32_t b = (n_samples + 32) / 2 + 32;   // nibbles of one variant, first one anywhere in a 16-byte group, + the bias
+  uint32_t b = 16 + (n_samples + 32) / 2;   // the bias, then the nibbles of one variant starting anywhere in a 16-byte group
   b = (b + 15) & ~15u;
   if (b < 1024 + 16) b = 1024 + 16;         // the first 1 KiB is written by all lanes
   return b / 4;
 }
-__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) { return ((512 + n_samples + 8 + 7) & ~7u) / 2; }
+constexpr uint32_t kListWindow = 64;         // the id list is laid out by arena position modulo 64 entries (128 bytes)
+__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) {
+  const uint32_t w = ((kListWindow + n_samples + 8 + 7) & ~7u) / 2;
+  return w < kRowWords ? kRowWords : w;
+}
 __host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
-  return kRowWords + slice_gt_words(n_samples) + slice_ids_words(n_samples);
+  const uint32_t w = slice_gt_words(n_samples) + slice_ids_words(n_samples);
+  return w < 384 ? 384 : w;                  // the sparse phase keeps 6 x 64 words at the start of the region
 }
 constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
 
@@ -611,7 +617,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         stage_unpacked(gt_lds + lane * 32, nq0);
         if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
       } else {      // raw nibbles, behind the row staging area
-        uint8_t* nib_st = gt_lds + kRowWords * 4 + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
+        uint8_t* nib_st = gt_lds + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
         *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
         if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
       }
@@ -647,9 +653,9 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         //      blocks, one 16-byte store per lane, genotypes merged from the raw nibble stream on the way out.
         //      Compared with the bit-per-lane ring (kept below for wide cohorts) this needs ~2.5x fewer
         //      instructions per carrier and no scalar work per row word. ----
-        uint64_t* rowq = reinterpret_cast<uint64_t*>(gt_lds);                     // [65]
-        const uint8_t* nib_lds = gt_lds + kRowWords * 4;
-        uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + (kRowWords + slice_gt_words(im.num_samples)) * 4);
+        const uint8_t* nib_lds = gt_lds;
+        uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
+        uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
         rowq[lane] = mine;
         if (lane == 0) rowq[64] = 0;
         const uint32_t b0s = wpc * lane, wi = b0s >> 6, sh = b0s & 63;
@@ -660,7 +666,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         const uint32_t pc = __popc(lo) + __popc(hi);
         uint32_t incl = wave_inclusive_scan(pc);
         asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
-        const uint32_t a1k = (uint32_t)(cb_t & 511);        // offset of the variant inside its 1 KiB block (512 x 2 B)
+        const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
         uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
         const uint32_t end1k = a1k + cnt_t;
         uint32_t j = a1k + incl - pc;                       // list index of this lane's first carrier
