@@ -212,15 +212,15 @@ def main():
     v = res.view(with_carriers=False)
     kept = (v["var_flags"] & 1) == 0
     cc = v["car_count"][kept].astype(np.int64)
-    n_sparse = int((cc <= 32).sum())
-    car_sparse = int(cc[cc <= 32].sum())
+    n_sparse = int((cc <= 64).sum())      # kSparseMax of k_fill_carriers
+    car_sparse = int(cc[cc <= 64].sum())
     W = ((info.num_samples + 63) // 64) * 8
     # Dominant kernel k_fill_carriers.  `achieved` prices one launch with SURVEY.md §8(d)'s formula,
     # restricted to the terms this kernel owns: per variant its class row (W bytes) and
     # its car_begin word (8), per carrier 3 genotype bits in and a 4-byte id + 1-byte genotype out.
     fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
     # The bytes this layout actually has to move (lower): 32 B of slot header per variant, the class row
-    # only for variants above 32 carriers (rarer ones read a decoded id list, 4 B per carrier), half a byte
+    # only for variants above 64 carriers (rarer ones read a decoded id list, 4 B per carrier), half a byte
     # of genotype per carrier in, one packed carrier word out: 2 bytes (id | gt << 13) when every sample id
     # fits 13 bits (cohorts of at most 4032 samples), else 4.
     car_word = 2 if info.num_samples <= 4032 else 4

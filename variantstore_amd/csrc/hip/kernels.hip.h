@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 //          dense ones bit per lane (exec = row word, v_mbcnt rank) through a 512-entry LDS ring, 32-bit carrier
 //          words (id | gt << 29); rows wider than one wave take the out-of-line generic path.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kSparseMax = 32;
+constexpr uint32_t kSparseMax = 64;
 constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
 constexpr uint32_t kFillChunkSmall = 8;      // latency launches (a handful of regions): more waves per region
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)

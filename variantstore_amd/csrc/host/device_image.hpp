@@ -30,7 +30,7 @@
 namespace vsamd {
 
 constexpr uint32_t VS_NONE = 0xFFFFFFFFu;
-constexpr uint32_t kSparseClassMax = 32;  // must equal kSparseMax in kernels.hip.h
+constexpr uint32_t kSparseClassMax = 64;  // must equal kSparseMax in kernels.hip.h
 
 struct HostImage {
   // scalars
