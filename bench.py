@@ -361,6 +361,10 @@ def main():
                          "bytes_per_launch": fill_bytes_survey, "avg_launch_ms": fill_ms / args.steps,
                          "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": fill_bytes_layout,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                         # what crossed the HBM pins (PMC) over the same launch time: the layout writes 2-byte carrier
+                         # words where the survey formula prices 5 bytes, so `frac` can exceed 1 while this cannot
+                         "traffic_GBps": (traffic / fill_s / 1e9) if (traffic and fill_s > 0) else None,
+                         "traffic_frac": (traffic / fill_s / 1e9 / HBM_PEAK_GBPS) if (traffic and fill_s > 0) else None,
                          "pipeline_ms": tot_ms / args.steps},
             "p50_latency_us": p50,
             "type4": t4,
