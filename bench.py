@@ -177,7 +177,9 @@ def main():
         res = vs.get_var_in_ref(regions)
         gathered = None
         if use_dist:
-            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True)
+            # every rank answers nreg regions: the record counts are known without asking
+            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True,
+                                           counts=[nreg] * world)
         return res, gathered
 
     def fence():

@@ -78,7 +78,8 @@ struct DevResult {
   uint8_t* q_flags;         // [Q]
   uint32_t* q_g0;           // [Q] first site of the region
   uint64_t* q_nvar;         // [Q] slots
-  uint64_t* q_ncar;         // [Q] carriers (upper bound when a variant gets dropped)
+  uint64_t* q_ncar;         // [Q] arena entries of the region (padded counts) until the offsets are scanned; afterwards the
+                            //     header kernels overwrite it with the carriers of the region's REPORTED variants
   uint64_t* var_begin;      // [Q+1]
   uint64_t* car_base;       // [Q+1]
   uint64_t* var_count;      // [Q]
@@ -111,6 +112,26 @@ __device__ __forceinline__ uint32_t rank1(const DevImage& im, uint64_t p) {
   const uint32_t rem = (uint32_t)(p & 63);
   if (rem) r += __popcll(im.bits[w1] & ((1ULL << rem) - 1));
   return r;
+}
+
+// (a & mask) | c in one VOP3 instruction; the mask must sit in an SGPR (no literals in VOP3 on gfx9)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask_sgpr, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask_sgpr), "v"(c));
+  return r;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (no LDS round trips): Hillis-Steele
+// inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of each odd row's
+// predecessor into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
+  return v;
 }
 
 __device__ __forceinline__ bool seq_equal(const DevImage& im, uint32_t a_off, uint32_t b_off, uint32_t len) {
@@ -327,10 +348,12 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
   const uint32_t g0 = r.q_g0[q];
   const uint64_t pre0 = im.s_carpre[g0];
+  uint32_t kept = 0;
   for (uint64_t j = lane; j < n; j += 64) {
     const uint64_t a = a0 + j;
     const uint32_t g = g0 + (uint32_t)j;
     const uint32_t fl = im.s_flags[g];
+    kept += im.s_ncar[g];
     r.r_pos[a] = im.s_pos[g];
     r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
     r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
@@ -342,7 +365,8 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
     r.r_class[a] = im.s_class[g];
     r.r_gt0[a] = im.s_gt0[g];
   }
-  if (lane == 0 && !(r.q_flags[q] & kRegionSlow)) r.var_count[q] = n;
+  kept = wave_inclusive_scan(kept);
+  if (lane == 63 && !(r.q_flags[q] & kRegionSlow)) { r.var_count[q] = n; r.q_ncar[q] = kept; }
 }
 
 // The reference's "only add var if not seen before" rule (query.h:397-414),
@@ -352,7 +376,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
   if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
   if (r.dyn_totals && r.dyn_totals[3]) return;
   const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
-  uint64_t kept = 0, back = 0;
+  uint64_t kept = 0, back = 0, kept_car = 0;
   for (uint64_t j = 0; j < n; ++j) {
     const uint64_t a = a0 + j;
     if (r.r_flags[a] & kVarDropped) { r.r_car_count[a] = 0; continue; }
@@ -370,10 +394,11 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
         }
       }
     }
-    if (push) { kept++; back = a; }
+    if (push) { kept++; back = a; kept_car += r.r_car_count[a]; }
     else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
   }
   r.var_count[q] = kept;
+  r.q_ncar[q] = kept_car;
 }
 
 // ---------------------------------------------------------------------------
@@ -436,26 +461,6 @@ __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
   const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
   const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
   return ((uint64_t)hi << 32) | lo;
-}
-
-// (a & mask) | c in one VOP3 instruction; the mask must sit in an SGPR (no literals in VOP3 on gfx9)
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask_sgpr, uint32_t c) {
-  uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask_sgpr), "v"(c));
-  return r;
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (no LDS round trips): Hillis-Steele
-// inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of each odd row's
-// predecessor into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
-  return v;
 }
 
 // 32 packed genotype nibbles (one uint4) -> 32 bytes in LDS, nibble order preserved.
@@ -803,7 +808,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   const uint32_t sid = sid_per_region ? sid_per_region[q] : sid_all;
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   uint8_t fl = 0;
-  uint64_t nvar = 0, ncar = 0;
+  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
   if (x < 1) fl = kRegionInvalid;
   else {
     bool empty = false;  // Index::is_empty, index.h:150-166
@@ -879,7 +884,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
               r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
             }
-            nvar++; ncar += pad_car(c);
+            nvar++; ncar += pad_car(c); ncar_kept += c;
           }
         }
         cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
     }
   }
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
-  else r.var_count[q] = nvar;
+  else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
 }
 
 // Compact hit lists for a collective: the index (and so the site table) is replicated on every rank,
@@ -904,9 +909,7 @@ __global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst
   dst[4 * q + 0] = region_base + q;
   dst[4 * q + 1] = (uint64_t)r.q_g0[q] | (fl << 32) | (dropped << 40);
   dst[4 * q + 2] = r.var_count[q];
-  uint64_t ncar = 0;   // carriers of the reported variants (the arena range car_base[q+1] - car_base[q] includes padding)
-  for (uint64_t a = r.var_begin[q]; a < r.var_begin[q + 1]; ++a) ncar += r.r_car_count[a];
-  dst[4 * q + 3] = ncar;
+  dst[4 * q + 3] = r.q_ncar[q];   // carriers of the reported variants (the arena range car_base[q+1] - car_base[q] is padded)
 }
 
 // ---------------------------------------------------------------------------
@@ -1018,6 +1021,7 @@ __global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r,
   const uint64_t alt_len = str_off[2 * q + 2] - str_off[2 * q + 1];
   const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
   bool found = false;
+  uint64_t kept_car = 0;
   for (uint64_t j = 0; j < n; ++j) {
     const uint64_t a = a0 + j;
     if (r.r_flags[a] & kVarDropped) continue;
@@ -1027,10 +1031,11 @@ __global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r,
       for (uint64_t i = 0; match && i < ref_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_ref_off[a] + i] & 7] == ref[i];
       for (uint64_t i = 0; match && i < alt_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_alt_off[a] + i] & 7] == alt[i];
     }
-    if (match) found = true;
+    if (match) { found = true; kept_car = r.r_car_count[a]; }
     else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
   }
   r.var_count[q] = found ? 1 : 0;
+  r.q_ncar[q] = kept_car;
   if (!found) r.q_flags[q] |= kRegionNotFound;
 }
 
@@ -1124,7 +1129,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
   const uint32_t sid = sid_per_region[q];
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   uint8_t fl = 0;
-  uint64_t nvar = 0, ncar = 0;
+  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t closest_v = 0;
   if (!rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
@@ -1169,7 +1174,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
           r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
-        nvar++; ncar += pad_car(c);
+        nvar++; ncar += pad_car(c); ncar_kept += c;
         // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
       }
       cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
@@ -1181,7 +1186,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
     }
   }
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
-  else r.var_count[q] = nvar;
+  else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
 }
 
 // Query types 2 and 3: the sequence of a sample over [x, y).  The walk produces the list of (pool offset,

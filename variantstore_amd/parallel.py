@@ -26,22 +26,31 @@ def shard_regions(regions, rank, world):
     return regions[lo:hi], lo
 
 
-def allgather_hit_lists(result, region_base, device, compact=False):
+def allgather_hit_lists(result, region_base, device, compact=False, counts=None):
     """All-gatherv of hit lists.
 
     compact=False: one 32-byte record per VARIANT (vs_result_pack_headers) -- self-contained rows.
     compact=True:  one 32-byte record per REGION (vs_result_pack_regions): the region's range of the
                    site table, which every rank can expand locally because the index is replicated.
                    For the bench cohort that is 3.2 MB per rank instead of 650 MB.
+    counts: the per-rank record counts when every rank already knows them (compact records of a batch that was
+            sharded with shard_bounds: the region counts) -- skips the count all-gather and its host round trip.
     Returns (records[int64, world x max_n x 4], counts[int64, world]).
     """
     world = dist.get_world_size()
     n = result.num_region_records() if compact else result.num_header_records()
-    counts = torch.zeros(world, dtype=torch.int64, device=device)
-    mine = torch.tensor([n], dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, mine)
-    max_n = max(int(counts.max().item()), 1)
-    buf = torch.zeros((max_n, 4), dtype=torch.int64, device=device)
+    if counts is None:
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        mine = torch.tensor([n], dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(counts, mine)
+        max_n = max(int(counts.max().item()), 1)
+    else:
+        if len(counts) != world or int(counts[dist.get_rank()]) != n:
+            raise ValueError("counts does not describe this batch")
+        max_n = max(int(max(counts)), 1)
+        counts = torch.as_tensor(list(counts), dtype=torch.int64)
+    # rows beyond this rank's count are never read (counts delimit them): no need to clear the send buffer
+    buf = torch.empty((max_n, 4), dtype=torch.int64, device=device)
     if compact:
         result.pack_regions_into(buf.data_ptr(), max_n, region_base)
     else:
