@@ -268,10 +268,7 @@ class VariantStore:
         arr, ptr, n = _regions_array(regions)
         h = C.c_void_p()
         if isinstance(sample, (list, tuple, np.ndarray)):  # one sample per region
-            sids = np.ascontiguousarray([self.sample_id(s) if isinstance(s, str) else int(s) for s in sample],
-                                        dtype=np.uint32)
-            if sids.shape[0] != n:
-                raise ValueError("one sample per region expected")
+            sids = self._sample_ids(sample, n)
             _check(self._lib.vs_query_samples_var_in_ref(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                          C.byref(h)), "vs_query_samples_var_in_ref")
             return QueryResult(self, h)
@@ -303,6 +300,11 @@ class VariantStore:
         return QueryResult(self, h)
 
     def _sample_ids(self, sample, n):
+        if isinstance(sample, np.ndarray) and sample.dtype.kind in "ui":   # ids already: no per-element Python
+            sids = np.ascontiguousarray(sample, dtype=np.uint32)
+            if sids.shape[0] != n:
+                raise ValueError("one sample per region expected")
+            return sids
         if isinstance(sample, (list, tuple, np.ndarray)):
             sids = np.ascontiguousarray([self.sample_id(x) if isinstance(x, str) else int(x) for x in sample], dtype=np.uint32)
             if sids.shape[0] != n:

@@ -319,9 +319,36 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   std::vector<DevBuf> scratch;
   uint64_t totals[2] = {0, 0};
-  if (n) {
+  // Type 4, single walk: capacities from the type-6 bounds of the same regions, one recording walk, headers from
+  // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
+  WalkScratch ws{};
+  bool single_walk = false;
+  if (n && t4 && walk_mode == 4 && getenv("VS_T4_TWO_WALKS") == nullptr) {
+    hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    uint64_t* cap_begin = nullptr;
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch));
+    uint64_t cap_total = 0;
+    HIP_TRY(hipMemcpyAsync(&cap_total, cap_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    ws.cap_begin = cap_begin;
+    VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.cur, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ro, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.rl, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ao, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch));
+    VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch));
+    HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, ws);
+    HIP_TRY(hipGetLastError());
+    single_walk = true;
+  }
+  uint64_t walk_overflow = 0;
+  if (single_walk) {
+  } else if (n) {
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
@@ -331,7 +358,17 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
   HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
+  if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
+    single_walk = false;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
+    HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+  }
   d.A = totals[0];
   d.S = totals[1];
   VS_TRY(ralloc(r, d.A, &d.r_pos));
@@ -355,7 +392,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids);
+    else if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, ws);
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);

@@ -801,8 +801,21 @@ __device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v
   return false;
 }
 
-template <bool EMIT>
-__global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region) {
+// MODE 0 counts, MODE 1 writes the variant headers at the scanned offsets (a second walk), MODE 2 walks ONCE:
+// it records every reported vertex in a scratch list whose per-region capacity is the region's type-6 slot count
+// (a sample's variants are branches of the same ref-path range) and flags an overflow instead of writing past it;
+// k_emit_from_walk then lays the headers out without walking again.
+struct WalkScratch {
+  const uint64_t* cap_begin;   // [Q+1] exclusive scan of the capacities
+  uint64_t* pos;
+  uint32_t *cur, *ro, *rl, *ao, *al;
+  uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path)
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
+                                                    WalkScratch ws) {
+  constexpr bool EMIT = MODE == 1;
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
   const uint32_t sid = sid_per_region ? sid_per_region[q] : sid_all;
@@ -884,6 +897,13 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
               r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
             }
+            if (MODE == 2) {
+              const uint64_t s0 = ws.cap_begin[q];
+              if (nvar < ws.cap_begin[q + 1] - s0) {
+                const uint64_t s = s0 + nvar;
+                ws.pos[s] = pos; ws.cur[s] = cur; ws.ro[s] = ro; ws.rl[s] = rl; ws.ao[s] = ao; ws.al[s] = al;
+              } else *ws.overflow = 1;
+            }
             nvar++; ncar += pad_car(c); ncar_kept += c;
           }
         }
@@ -896,6 +916,25 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   }
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
   else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
+}
+
+// Headers of a type-4 batch from the scratch list of the single walk (one thread per region; ~10 variants each)
+__global__ void __launch_bounds__(64) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], s0 = ws.cap_begin[q];
+  uint64_t cb = r.car_base[q], kept = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t a = a0 + i, s = s0 + i;
+    const uint32_t cur = ws.cur[s], c = im.v_ncar[cur];
+    r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
+    r.r_flags[a] = 0; r.r_car_begin[a] = cb; r.r_car_count[a] = c;
+    r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+    r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+    cb += pad_car(c); kept += c;
+  }
+  r.var_count[q] = n;
+  r.q_ncar[q] = kept;
 }
 
 // Compact hit lists for a collective: the index (and so the site table) is replicated on every rank,
