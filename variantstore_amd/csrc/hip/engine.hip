@@ -378,7 +378,6 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_alt_len));
   VS_TRY(ralloc(r, d.A, &d.r_flags));
   VS_TRY(ralloc(r, d.A, &d.r_car_count));
-  VS_TRY(ralloc(r, d.A, &d.r_site));
   VS_TRY(ralloc(r, d.A, &d.r_region));
   VS_TRY(ralloc(r, d.A, &d.r_car_begin));
   VS_TRY(ralloc(r, d.A, &d.r_class));
@@ -593,7 +592,6 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   VS_TRY(ralloc(r, capA, &d.r_alt_len));
   VS_TRY(ralloc(r, capA, &d.r_flags));
   VS_TRY(ralloc(r, capA, &d.r_car_count));
-  VS_TRY(ralloc(r, capA, &d.r_site));
   VS_TRY(ralloc(r, capA, &d.r_region));
   VS_TRY(ralloc(r, capA, &d.r_car_begin));
   VS_TRY(ralloc(r, capA, &d.r_class));

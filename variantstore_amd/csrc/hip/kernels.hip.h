@@ -84,7 +84,7 @@ struct DevResult {
   uint64_t* car_base;       // [Q+1]
   uint64_t* var_count;      // [Q]
   uint64_t* r_pos;
-  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_site, *r_region, *r_class;
+  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_region, *r_class;
   uint64_t* r_car_begin;
   uint64_t* r_gt0;
   void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
@@ -360,7 +360,6 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
     r.r_flags[a] = (fl & kSiteAlwaysDrop) ? kVarDropped : 0u;
     r.r_car_begin[a] = cb + (im.s_carpre[g] - pre0);
     r.r_car_count[a] = im.s_ncar[g];
-    r.r_site[a] = g;
     r.r_region[a] = (uint32_t)q;
     r.r_class[a] = im.s_class[g];
     r.r_gt0[a] = im.s_gt0[g];
@@ -894,7 +893,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               const uint64_t a = a0 + nvar;
               r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
               r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
-              r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+              r.r_region[a] = (uint32_t)q;
               r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
             }
             if (MODE == 2) {
@@ -929,7 +928,7 @@ __global__ void __launch_bounds__(64) k_emit_from_walk(DevImage im, DevResult r,
     const uint32_t cur = ws.cur[s], c = im.v_ncar[cur];
     r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
     r.r_flags[a] = 0; r.r_car_begin[a] = cb; r.r_car_count[a] = c;
-    r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+    r.r_region[a] = (uint32_t)q;
     r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
     cb += pad_car(c); kept += c;
   }
@@ -1210,7 +1209,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           const uint64_t a = a0 + nvar;
           r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
           r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
-          r.r_site[a] = cur; r.r_region[a] = (uint32_t)q;
+          r.r_region[a] = (uint32_t)q;
           r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
         nvar++; ncar += pad_car(c); ncar_kept += c;
