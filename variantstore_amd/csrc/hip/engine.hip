@@ -518,28 +518,60 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-  if (n) {
-    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, false>), grid, block, 0, idx->stream, idx->d, q);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, false>), grid, block, 0, idx->stream, idx->d, q);
-    HIP_TRY(hipGetLastError());
-  }
   std::vector<DevBuf> scratch;
   uint64_t totals[2] = {0, 0};
-  VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
-  VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
-  HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-  HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-  HIP_TRY(hipStreamSynchronize(idx->stream));
-  VS_TRY(ralloc(r, totals[0], &q.seg_src));
-  VS_TRY(ralloc(r, totals[0], &q.seg_len));
-  VS_TRY(ralloc(r, totals[0], &q.seg_dst));
-  VS_TRY(ralloc(r, totals[1], &q.chars));
-  r->seq_bytes = totals[1];
-  if (n) {
-    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, true>), grid, block, 0, idx->stream, idx->d, q);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, true>), grid, block, 0, idx->stream, idx->d, q);
-    hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, q);
+  // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
+  // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
+  bool single_walk = n > 0 && getenv("VS_SEQ_TWO_WALKS") == nullptr;
+  if (single_walk) {
+    VS_TRY(ralloc(r, 1, &q.overflow));
+    HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
+    hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
+    HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(ralloc(r, totals[0], &q.seg_src));
+    VS_TRY(ralloc(r, totals[0], &q.seg_len));
+    VS_TRY(ralloc(r, totals[0], &q.seg_dst));
+    q.relative = 1;
+    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 2>), grid, block, 0, idx->stream, idx->d, q);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 2>), grid, block, 0, idx->stream, idx->d, q);
     HIP_TRY(hipGetLastError());
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
+    uint64_t over = 0;
+    HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(&over, q.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (over) { single_walk = false; q.relative = 0; }
+    else {
+      VS_TRY(ralloc(r, totals[1], &q.chars));
+      r->seq_bytes = totals[1];
+      hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, q);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (!single_walk) {
+    if (n) {
+      if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 0>), grid, block, 0, idx->stream, idx->d, q);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 0>), grid, block, 0, idx->stream, idx->d, q);
+      HIP_TRY(hipGetLastError());
+    }
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
+    HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(ralloc(r, totals[0], &q.seg_src));
+    VS_TRY(ralloc(r, totals[0], &q.seg_len));
+    VS_TRY(ralloc(r, totals[0], &q.seg_dst));
+    VS_TRY(ralloc(r, totals[1], &q.chars));
+    r->seq_bytes = totals[1];
+    if (n) {
+      if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 1>), grid, block, 0, idx->stream, idx->d, q);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 1>), grid, block, 0, idx->stream, idx->d, q);
+      hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, q);
+      HIP_TRY(hipGetLastError());
+    }
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));

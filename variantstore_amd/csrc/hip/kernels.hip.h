@@ -1237,58 +1237,63 @@ struct DevSeqResult {
   uint64_t *q_nseg, *q_nbytes;      // [Q] counting pass
   uint64_t *seg_begin, *byte_begin; // [Q+1]
   uint32_t *seg_src, *seg_len;      // [nseg]
-  uint64_t* seg_dst;                // [nseg] byte offset in chars
+  uint64_t* seg_dst;                // [nseg] byte offset in chars (relative to the region's first byte when `relative`)
   uint8_t* chars;
+  uint64_t* overflow;               // single-walk mode: set when a region outgrew its piece capacity
+  uint32_t relative, pad_;          // single-walk mode: pieces sit at seg_begin[q] .. + q_nseg[q], seg_begin = capacities' scan
 };
 
 struct SeqSink {
   uint64_t nseg, nbytes;
 };
 
-template <bool EMIT>
+// PASS 0 counts, PASS 1 writes the pieces at their scanned places (second walk), PASS 2 is the single walk: pieces go
+// to the region's slice of a capacity-sized list with byte offsets relative to the region's first byte.
+template <int PASS>
 __device__ __forceinline__ void seq_append(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint32_t off,
-                                           uint64_t len) {
+                                           uint64_t len, uint64_t cap) {
   if (len == 0) return;
-  if (EMIT) {
+  if (PASS == 1 || (PASS == 2 && s.nseg < cap)) {
     r.seg_src[seg0 + s.nseg] = off; r.seg_len[seg0 + s.nseg] = (uint32_t)len; r.seg_dst[seg0 + s.nseg] = byte0 + s.nbytes;
-  }
+  } else if (PASS == 2) *r.overflow = 1;
   s.nseg++; s.nbytes += len;
 }
 
 // the window logic of query.h:160-177 / :236-247 on (off, l) instead of a std::string.
 // Returns 0 continue, 1 stop, 2 std::out_of_range (uncaught in the reference).
-template <bool EMIT>
-__device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, bool& record,
+template <int PASS>
+__device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint64_t cap, bool& record,
                                           uint32_t off, uint64_t l, uint64_t cur, uint64_t next, uint64_t x, uint64_t y) {
   if (record && next < y) {
-    seq_append<EMIT>(r, s, seg0, byte0, off, l);
+    seq_append<PASS>(r, s, seg0, byte0, off, l, cap);
   } else if (record && next >= y) {
     const uint64_t n = y - cur;  // substr(0, n): n may have wrapped, it is clipped to the string
-    seq_append<EMIT>(r, s, seg0, byte0, off, n < l ? n : l);
+    seq_append<PASS>(r, s, seg0, byte0, off, n < l ? n : l, cap);
     return 1;
   } else if (next >= x && next < y) {
     record = true;
     const uint64_t p = x - cur;
     if (p > l) return 2;
-    seq_append<EMIT>(r, s, seg0, byte0, off + (uint32_t)p, l - p);
+    seq_append<PASS>(r, s, seg0, byte0, off + (uint32_t)p, l - p, cap);
   } else if (next >= x && next >= y) {
     const uint64_t p = x - cur;
     if (p > l) return 2;
     const uint64_t n = y - x;
-    seq_append<EMIT>(r, s, seg0, byte0, off + (uint32_t)p, n < l - p ? n : l - p);
+    seq_append<PASS>(r, s, seg0, byte0, off + (uint32_t)p, n < l - p ? n : l - p, cap);
     return 1;
   }
   return 0;
 }
 
-template <int MODE, bool EMIT>
+template <int MODE, int PASS>
 __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
-  if (EMIT && r.q_flags[q]) return;
+  if (PASS == 1 && r.q_flags[q]) return;
   const uint32_t sid = r.sids[q];
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
-  const uint64_t seg0 = EMIT ? r.seg_begin[q] : 0, byte0 = EMIT ? r.byte_begin[q] : 0;
+  const uint64_t seg0 = PASS ? r.seg_begin[q] : 0, byte0 = PASS == 1 ? r.byte_begin[q] : 0;
+  const uint64_t cap = PASS == 2 ? r.seg_begin[q + 1] - seg0 : 0;
   SeqSink s{0, 0};
   uint8_t fl = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
@@ -1309,11 +1314,11 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
           const uint32_t nr = im.v_ridx[im.col[e]];
           if (nr) { next_ref_pos = nr; break; }  // the FIRST ref neighbour here (query.h:150-153)
         }
-        st = seq_window<EMIT>(r, s, seg0, byte0, record, off, l, ref_pos, next_ref_pos, x, y);
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, l, ref_pos, next_ref_pos, x, y);
         ref_pos = next_ref_pos;
       } else {
         const uint64_t next_sample_pos = sample_pos + l;
-        st = seq_window<EMIT>(r, s, seg0, byte0, record, off, l, sample_pos, next_sample_pos, x, y);
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, l, sample_pos, next_sample_pos, x, y);
         sample_pos = next_sample_pos;
       }
       if (st == 2) { fl = kRegionInvalid; break; }
@@ -1323,11 +1328,25 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
       cur = nxt;
     }
   }
-  if (!EMIT) {
+  if (PASS != 1) {
     r.q_flags[q] = fl;
     r.q_nseg[q] = fl ? 0 : s.nseg;
     r.q_nbytes[q] = fl ? 0 : s.nbytes;
   }
+}
+
+// Piece capacity of a region for the single walk: twice the ref-path slots plus branch sites of the (for sample
+// coordinates: generously widened) reference range, plus slack.  Too small a guess only costs the fallback.
+__global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, uint32_t sample_coordinates) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t margin = sample_coordinates ? (y > x ? y - x : 0) + 256 : 0;
+  const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
+  const uint32_t s0 = slot_of_find(im, lo), s1 = slot_of_find(im, hi);
+  const uint64_t slots = s1 >= s0 ? (uint64_t)(s1 - s0) + 1 : 1;
+  const uint64_t sites = s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0;
+  r.q_nseg[q] = 2 * (slots + sites) + 8;
 }
 
 // Decode the pieces into characters: one wave per region, 64 piece descriptors at a time.
@@ -1335,12 +1354,13 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t s0 = r.seg_begin[q], s1 = r.seg_begin[q + 1];
+  const uint64_t s0 = r.seg_begin[q], s1 = r.relative ? s0 + r.q_nseg[q] : r.seg_begin[q + 1];
+  const uint64_t dst0 = r.relative ? r.byte_begin[q] : 0;
   for (uint64_t base = s0; base < s1; base += 64) {
     const uint64_t mine = base + lane;
     uint32_t src = 0, len = 0;
     uint64_t dst = 0;
-    if (mine < s1) { src = r.seg_src[mine]; len = r.seg_len[mine]; dst = r.seg_dst[mine]; }
+    if (mine < s1) { src = r.seg_src[mine]; len = r.seg_len[mine]; dst = dst0 + r.seg_dst[mine]; }
     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
     for (uint32_t k = 0; k < cnt; ++k) {
       const uint32_t ksrc = __builtin_amdgcn_readlane(src, k), klen = __builtin_amdgcn_readlane(len, k);
