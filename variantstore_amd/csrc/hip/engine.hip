@@ -323,8 +323,9 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
   WalkScratch ws{};
   bool single_walk = false;
-  if (n && t4 && walk_mode == 4 && getenv("VS_T4_TWO_WALKS") == nullptr) {
-    hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+  if (n && t4 && getenv("VS_T4_TWO_WALKS") == nullptr) {
+    if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     uint64_t* cap_begin = nullptr;
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch));
@@ -340,14 +341,15 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch));
     VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch));
     HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, ws);
+    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
   }
   uint64_t walk_overflow = 0;
   if (single_walk) {
   } else if (n) {
-    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
+    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
@@ -362,7 +364,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipStreamSynchronize(idx->stream));
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
+    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
     HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
@@ -390,8 +393,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids);
-    else if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, ws);
+    if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, ws);
+    else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);

@@ -1159,9 +1159,22 @@ __device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_
   return true;
 }
 
-// Query type 5.  One thread per region; EMIT=false counts, EMIT=true writes the variant headers.
-template <bool EMIT>
-__global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region) {
+// Capacities of the single recording walk of type 5: branch sites of the reference range [x, y) widened by the
+// region's own length (the sample's coordinates are shifted against the reference's by its net indel length).
+__global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t margin = (y > x ? y - x : 0) + 256;
+  const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
+  const uint32_t s0 = slot_of_find(im, lo), s1 = slot_of_find(im, hi);
+  r.q_nvar[q] = (s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0) + 8;
+}
+
+// Query type 5.  One thread per region; MODE as in k_sample_walk (0 count, 1 emit, 2 record once).
+template <int MODE>
+__global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+  constexpr bool EMIT = MODE == 1;
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
   const uint32_t sid = sid_per_region[q];
@@ -1211,6 +1224,13 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
           r.r_region[a] = (uint32_t)q;
           r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+        }
+        if (MODE == 2) {
+          const uint64_t s0 = ws.cap_begin[q];
+          if (nvar < ws.cap_begin[q + 1] - s0) {
+            const uint64_t s = s0 + nvar;
+            ws.pos[s] = pos; ws.cur[s] = cur; ws.ro[s] = ro; ws.rl[s] = rl; ws.ao[s] = ao; ws.al[s] = al;
+          } else *ws.overflow = 1;
         }
         nvar++; ncar += pad_car(c); ncar_kept += c;
         // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
