@@ -26,6 +26,9 @@ for c in range(n_cohorts):
               p_near=float(rng.uniform(0, 0.9)), carrier_p=float(rng.choice([0.004, 0.05, 0.3, 0.7])),
               unphased_p=float(rng.uniform(0, 0.3)), missing_p=float(rng.uniform(0, 0.1)),
               p_same=float(rng.choice([0.0, 0.0, 0.2, 0.5])), max_indel=int(rng.choice([2, 4, 12, 40])))
+    if os.environ.get("VS_STRESS_WIDE"):   # wide cohorts: every row width of the slice path, and the WIDE kernel beyond 4032
+        kw.update(n_samples=int(rng.choice([900, 1300, 1500, 2100, 2504, 2600, 3300, 3900, 4030, 4031, 4032, 4040, 5000])),
+                  n_rows=int(rng.integers(5, 60)), carrier_p=float(rng.choice([0.01, 0.05, 0.3, 0.7])))
     if rng.random() < 0.3:
         names = [f"n{int(x)}" for x in rng.permutation(kw["n_samples"])]
         kw["sample_names"] = names
