@@ -55,6 +55,20 @@ for c in range(n_cohorts):
                 bad += 1
                 print(f"MISMATCH t6 cohort {seed} region {x}:{y}\n--- gpu\n{res.region_text(q)}--- oracle\n{text}")
         slow_regions += int((flags["var_count"] != np.diff(flags["var_begin"].astype(np.int64))).sum())
+        # the same regions again through the small-batch paths (one launch in front of the fill kernel up to 8
+        # regions, the single-sync latency path up to 512)
+        for lo, hi in ((0, 1), (1, 4), (4, 12), (12, 20), (20, 21)):
+            sub_r = regions[lo:hi]
+            rs = vs.get_var_in_ref(sub_r)
+            for q, (x, y) in enumerate(sub_r):
+                n, early, text = orc.get_var_in_ref(x, y)
+                if n < 0:
+                    continue
+                checked += 1
+                if rs.region_text(q) != text:
+                    bad += 1
+                    print(f"MISMATCH t6 small batch cohort {seed} region {x}:{y}")
+            rs.close()
         sample = names[int(rng.integers(0, len(names)))]
         r4 = vs.get_sample_var_in_ref(regions[:60], sample)
         for q, (x, y) in enumerate(regions[:60]):

@@ -639,9 +639,13 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   }
   d.A = capA; d.S = capS;
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
-  hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
-  hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-  hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+  if (n <= 8) {   // a handful of regions: one single-block launch in front of the fill kernel
+    hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
+  } else {
+    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
+    hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+    hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+  }
   {
     const uint64_t nchunks = (capA + kFillChunkSmall - 1) / kFillChunkSmall;
     const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 4096);

@@ -340,11 +340,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const T* in, uint64_t
 // ---------------------------------------------------------------------------
 // Variant headers: one wave per region, lanes stride the region's site range.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (q >= r.Q) return;
-  if (r.dyn_totals && r.dyn_totals[3]) return;  // speculative buffers too small: the host retries
-  const uint32_t lane = threadIdx.x & 63;
+__device__ __forceinline__ void emit_region(const DevImage& im, const DevResult& r, uint64_t q, uint32_t lane) {
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
   const uint32_t g0 = r.q_g0[q];
   const uint64_t pre0 = im.s_carpre[g0];
@@ -368,12 +364,16 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
   if (lane == 63 && !(r.q_flags[q] & kRegionSlow)) { r.var_count[q] = n; r.q_ncar[q] = kept; }
 }
 
+__global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  if (r.dyn_totals && r.dyn_totals[3]) return;  // speculative buffers too small: the host retries
+  emit_region(im, r, q, threadIdx.x & 63);
+}
+
 // The reference's "only add var if not seen before" rule (query.h:397-414),
 // literally, for the regions flagged by k_region_bounds.  One thread per region.
-__global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
-  if (r.dyn_totals && r.dyn_totals[3]) return;
+__device__ __forceinline__ void dedup_region(const DevImage& im, const DevResult& r, uint64_t q) {
   const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
   uint64_t kept = 0, back = 0, kept_car = 0;
   for (uint64_t j = 0; j < n; ++j) {
@@ -398,6 +398,40 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
   }
   r.var_count[q] = kept;
   r.q_ncar[q] = kept_car;
+}
+
+__global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
+  if (r.dyn_totals && r.dyn_totals[3]) return;
+  dedup_region(im, r, q);
+}
+
+// A handful of regions (single-region latency): bounds, offsets, headers and the dedup rule in ONE single-block
+// launch -- three kernel launches fewer in front of k_fill_carriers.  Writes of one phase are read by other waves of
+// the same workgroup in the next; __syncthreads() orders them (workgroup scope, one CU).
+__global__ void __launch_bounds__(256) k_small_front(DevImage im, DevResult r, uint64_t* totals, uint64_t* host_totals,
+                                                     uint64_t cap_slots, uint64_t cap_carriers) {
+  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t a = 0, c = 0, slow = 0;
+    for (uint64_t q = 0; q < r.Q; ++q) {
+      r.var_begin[q] = a; r.car_base[q] = c;
+      a += r.q_nvar[q]; c += r.q_ncar[q];
+      slow |= (r.q_flags[q] & kRegionSlow) ? 1 : 0;
+    }
+    r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
+    const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
+    totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
+    if (host_totals) { host_totals[0] = a; host_totals[1] = c; host_totals[2] = slow; host_totals[3] = over; }
+  }
+  __syncthreads();
+  if (totals[3]) return;
+  for (uint64_t q = threadIdx.x >> 6; q < r.Q; q += blockDim.x >> 6) emit_region(im, r, q, threadIdx.x & 63);
+  __syncthreads();
+  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x)
+    if (r.q_flags[q] & kRegionSlow) dedup_region(im, r, q);
 }
 
 // ---------------------------------------------------------------------------
