@@ -610,32 +610,27 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   const uint64_t capS = std::min<uint64_t>(std::max<uint64_t>(1u << 20, 131072 * n), 32u << 20);
   memcpy(idx->pinned + 8, regions, n * 16);
   d.regions = idx->pinned + 8;
-  VS_TRY(ralloc(r, n, &d.q_flags));
-  VS_TRY(ralloc(r, n, &d.q_g0));
-  VS_TRY(ralloc(r, n, &d.q_nvar));
-  VS_TRY(ralloc(r, n, &d.q_ncar));
-  VS_TRY(ralloc(r, n + 1, &d.var_begin));
-  VS_TRY(ralloc(r, n + 1, &d.car_base));
-  VS_TRY(ralloc(r, n, &d.var_count));
-  uint64_t* dtot = nullptr;
-  VS_TRY(ralloc(r, 4, &dtot));
-  d.dyn_totals = dtot;
-  VS_TRY(ralloc(r, capA, &d.r_pos));
-  VS_TRY(ralloc(r, capA, &d.r_ref_off));
-  VS_TRY(ralloc(r, capA, &d.r_ref_len));
-  VS_TRY(ralloc(r, capA, &d.r_alt_off));
-  VS_TRY(ralloc(r, capA, &d.r_alt_len));
-  VS_TRY(ralloc(r, capA, &d.r_flags));
-  VS_TRY(ralloc(r, capA, &d.r_car_count));
-  VS_TRY(ralloc(r, capA, &d.r_region));
-  VS_TRY(ralloc(r, capA, &d.r_car_begin));
-  VS_TRY(ralloc(r, capA, &d.r_class));
-  VS_TRY(ralloc(r, capA, &d.r_gt0));
+  // one pooled slab for everything (two dozen pool look-ups cost microseconds at this scale)
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  uint64_t* dtot = nullptr;
   {
-    uint8_t* arena = nullptr;
-    VS_TRY(ralloc(r, capS * d.car_width + 16, &arena));
-    d.carriers = arena;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_flags = take(n), o_g0 = take(n * 4), o_nvar = take(n * 8), o_ncar = take(n * 8), o_vb = take((n + 1) * 8),
+                 o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_tot = take(32), o_pos = take(capA * 8), o_ro = take(capA * 4),
+                 o_rl = take(capA * 4), o_ao = take(capA * 4), o_al = take(capA * 4), o_fl = take(capA * 4), o_cc = take(capA * 4),
+                 o_rg = take(capA * 4), o_cbg = take(capA * 8), o_cl = take(capA * 4), o_gt = take(capA * 8),
+                 o_car = take(capS * d.car_width + 16);
+    uint8_t* slab = nullptr;
+    VS_TRY(ralloc(r, off, &slab));
+    d.q_flags = slab + o_flags; d.q_g0 = (uint32_t*)(slab + o_g0); d.q_nvar = (uint64_t*)(slab + o_nvar);
+    d.q_ncar = (uint64_t*)(slab + o_ncar); d.var_begin = (uint64_t*)(slab + o_vb); d.car_base = (uint64_t*)(slab + o_cb);
+    d.var_count = (uint64_t*)(slab + o_vc); dtot = (uint64_t*)(slab + o_tot);
+    d.r_pos = (uint64_t*)(slab + o_pos); d.r_ref_off = (uint32_t*)(slab + o_ro); d.r_ref_len = (uint32_t*)(slab + o_rl);
+    d.r_alt_off = (uint32_t*)(slab + o_ao); d.r_alt_len = (uint32_t*)(slab + o_al); d.r_flags = (uint32_t*)(slab + o_fl);
+    d.r_car_count = (uint32_t*)(slab + o_cc); d.r_region = (uint32_t*)(slab + o_rg); d.r_car_begin = (uint64_t*)(slab + o_cbg);
+    d.r_class = (uint32_t*)(slab + o_cl); d.r_gt0 = (uint64_t*)(slab + o_gt); d.carriers = slab + o_car;
+    d.dyn_totals = dtot;
   }
   d.A = capA; d.S = capS;
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
