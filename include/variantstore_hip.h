@@ -209,7 +209,7 @@ void vs_result_free(vs_result* r);
 
 /* ---- timing of the last batch on this handle (HIP events on the engine's stream) ---- */
 typedef struct {
-  float ms_total;    /* first launch to last kernel completion */
+  float ms_total;    /* first launch to last kernel completion (small type-6 batches: host clock, submit -> done) */
   float ms_bounds;   /* rank / region-bounds kernel            */
   float ms_scan;     /* offset scans + dedup                   */
   float ms_emit;     /* variant-header kernel                  */
