@@ -5,6 +5,7 @@
 // that steady-state batches do no hipMalloc.  Mirrors the reference's seam
 // between query_main and query.h (reference src/commands.cc:114-215).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -64,6 +65,8 @@ struct vs_index {
   vs_construct_stats cstats{};
   uint64_t live_results = 0;
   bool close_pending = false;  // vs_index_close was called while results were alive
+  unsigned long long* done_counter = nullptr;   // device word of the latency path's completion mailbox
+  uint64_t lat_seq = 0;
   uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path
 };
 
@@ -180,7 +183,11 @@ static int build_device_image(vs_index* idx) {
   HIP_TRY(hipSetDevice(idx->device));
   HIP_TRY(hipStreamCreate(&idx->stream));
   for (auto& e : idx->ev) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(hipHostMalloc((void**)&idx->pinned, 16384, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&idx->pinned, 16384, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(idx->pinned, 0, 16384);
+  HIP_TRY(hipMalloc((void**)&idx->done_counter, 8));
+  idx->image_allocs.push_back(idx->done_counter);
+  HIP_TRY(hipMemsetAsync(idx->done_counter, 0, 8, idx->stream));
   d.ref_length = im.ref_length;
   d.nbits = (uint64_t)im.bits.size() * 64;
   d.num_samples = im.num_samples; d.wpc = im.wpc; d.use_bv = im.use_bit_vector;
@@ -634,6 +641,9 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     d.dyn_totals = dtot;
   }
   d.A = capA; d.S = capS;
+  d.done_counter = idx->done_counter;
+  d.done_flag = idx->pinned + 6;
+  d.done_seq = ++idx->lat_seq;
   const auto host_t0 = std::chrono::steady_clock::now();   // no HIP events here: each one is a packet on the critical path
   if (n <= 8) {   // a handful of regions: one single-block launch in front of the fill kernel
     hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
@@ -654,7 +664,19 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(idx->stream));
+  {  // spin on the mailbox (the runtime's completion wait costs several microseconds more); a kernel that never posts
+     // -- a fault -- is caught by the stream synchronisation after the deadline
+    volatile uint64_t* flag = idx->pinned + 6;
+    const auto deadline = host_t0 + std::chrono::microseconds(300);
+    bool posted = false;
+    while (!(posted = (*flag == d.done_seq))) {
+      __builtin_ia32_pause();
+      if (std::chrono::steady_clock::now() > deadline) break;
+    }
+    if (!posted) HIP_TRY(hipStreamSynchronize(idx->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  d.done_flag = nullptr;   // later launches with this result (none today) must not post
   if (idx->pinned[3]) return 1;  // overflow: nothing was written, retry with exact sizes
   d.A = idx->pinned[0];
   d.S = idx->pinned[1];

@@ -91,6 +91,11 @@ struct DevResult {
   uint32_t car_width, pad3_; // bytes per carrier word in the arena: 2 or 4
   // latency path: sizes are decided on the device ({slots, carriers, any-slow, overflow}); NULL otherwise
   const uint64_t* dyn_totals;
+  // latency path: the last block of k_fill_carriers posts done_seq into mapped host memory (the host spins on it
+  // instead of waiting for the runtime's completion signal); NULL otherwise
+  unsigned long long* done_counter;
+  volatile uint64_t* done_flag;
+  uint64_t done_seq;
 };
 
 // Every variant's carrier range in the result arena starts on a multiple of 8 entries (16 bytes of 16-bit carrier
@@ -802,6 +807,17 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         }
       }
       word_cur = word_next;
+    }
+  }
+  if (r.done_flag) {   // latency launches: completion mailbox
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1) {
+        *r.done_counter = 0;   // re-armed for the next launch on this stream
+        __threadfence_system();
+        *r.done_flag = r.done_seq;
+      }
     }
   }
 }
