@@ -262,6 +262,15 @@ static int build_device_image(vs_index* idx) {
     else if (h_dup[g] != kNone) { sus_g.push_back((uint32_t)g); sus_prev.push_back(h_dup[g]); }
   }
   d.n_sus = (uint32_t)sus_g.size();
+  {  // suspicious sites before each ref-path slot's first site
+    std::vector<uint32_t> pre(im.P + 1, 0);
+    size_t k = 0;
+    for (uint64_t s = 0; s <= im.P; ++s) {
+      while (k < sus_g.size() && sus_g[k] < im.rp_cand_prefix[s]) ++k;
+      pre[s] = (uint32_t)k;
+    }
+    VS_TRY(upload_image(idx, pre, &d.rp_sus_prefix));
+  }
   VS_TRY(upload_image(idx, sus_g, &d.sus_g));
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   HIP_TRY(hipStreamSynchronize(idx->stream));

@@ -69,6 +69,7 @@ struct DevImage {
   uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
+  const uint32_t* rp_sus_prefix;  // [P+1] suspicious sites before each ref-path slot's first site (no bisection per query)
   uint32_t n_sus, has_car_index;
 };
 
@@ -235,10 +236,9 @@ __device__ __forceinline__ void region_bounds(const DevImage& im, const DevResul
       if (s1 < s0) s1 = s0;
       g0 = im.rp_cand_prefix[s0];
       g1 = im.rp_cand_prefix[s1];
-      // can the "already seen" rule fire inside [g0,g1)?
-      uint32_t lo = 0, hi = im.n_sus;
-      while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (im.sus_g[m] < g0) lo = m + 1; else hi = m; }
-      for (uint32_t k = lo; k < im.n_sus && im.sus_g[k] < g1; ++k) {
+      // can the "already seen" rule fire inside [g0,g1)?  (g0, g1 are slot boundaries: the list range is tabulated)
+      const uint32_t lo = im.rp_sus_prefix[s0], hi = im.rp_sus_prefix[s1];
+      for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t pv = im.sus_prev[k];
         if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
       }
@@ -1083,9 +1083,8 @@ __global__ void __launch_bounds__(256) k_point_bounds(DevImage im, DevResult r, 
   uint32_t g0 = 0, g1 = 0;
   if (chosen < P) {
     g0 = im.rp_cand_prefix[chosen]; g1 = im.rp_cand_prefix[chosen + 1];
-    uint32_t lo = 0, hi = im.n_sus;
-    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (im.sus_g[m] < g0) lo = m + 1; else hi = m; }
-    for (uint32_t k = lo; k < im.n_sus && im.sus_g[k] < g1; ++k) {
+    const uint32_t lo = im.rp_sus_prefix[chosen], hi = im.rp_sus_prefix[chosen + 1];
+    for (uint32_t k = lo; k < hi; ++k) {
       const uint32_t pv = im.sus_prev[k];
       if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
     }
