@@ -104,3 +104,17 @@ def test_draw_subgraph_matches_the_oracle(golden_dir, tmp_path):
     # shape of the file (dot_graph.h:25-39)
     text = open(os.path.join(tmp_path, "g.dot"), encoding="latin-1").read()
     assert text.startswith("digraph {\n") and "\tsubgraph cluster_0 {\n\t\tlabel=\"reference\";\n" in text and text.endswith("}")
+
+
+def test_host_code_under_sanitizers(golden_dir, tmp_path):
+    """Constructor, index-directory codecs, image builder, synthetic generator and dot graph compiled with
+    AddressSanitizer + UBSan (CPU build only; the GPU pool has no sanitizer support)."""
+    import subprocess
+    exe = os.path.join(tmp_path, "host_sanitize")
+    src = os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-o", exe, src, "-lz"])
+    out = subprocess.run([exe, os.path.join(golden_dir, "x.fa"), os.path.join(golden_dir, "x.vcf"),
+                          os.path.join(tmp_path, "ser")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok 213 143 ") and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
