@@ -627,3 +627,18 @@ def test_saved_and_reloaded_index_answers_identically(tmp_path):
     fa, sa = vs.query_sample_seq(regions[:300], "S00150", sample_coordinates=True).sequences()
     fb, sb = vs2.query_sample_seq(regions[:300], "S00150", sample_coordinates=True).sequences()
     assert list(fa) == list(fb) and sa == sb
+
+
+def test_positions_far_beyond_the_reference(tmp_path):
+    """64-bit region bounds far past the reference end (and past 2^32) behave as in the oracle for types 6, 4 and 1."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 77)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = vs.info().ref_length
+    regions = [(2 ** 40, 2 ** 40 + 10), (5, 2 ** 40), (L - 5, 2 ** 33), (2 ** 62, 2 ** 62 + 5), (1, 2 ** 63)]
+    assert _compare_t6(vs, orc, regions) == len(regions)
+    assert _compare_t4(vs, orc, regions, names[0]) == len(regions)
+    res = vs.closest_var([2 ** 32 + 7, 2 ** 40 + 3])
+    flags = res.view(False)["region_flags"]
+    for q, p in enumerate([2 ** 32 + 7, 2 ** 40 + 3]):
+        n, text = orc.closest_var(p)
+        assert (n < 0) == bool(flags[q] & 4) and (n < 0 or res.region_text(q) == text), p
