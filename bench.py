@@ -141,7 +141,10 @@ def main():
     ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-samples", type=int, default=200)
+    ap.add_argument("--skip-extras", action="store_true", help="only the headline batch (no type 4 / point / sample-coordinate legs)")
     args = ap.parse_args()
+    if args.skip_extras:
+        os.environ["VS_BENCH_SKIP_T4"] = "1"
 
     import numpy as np
     import torch
@@ -214,22 +217,30 @@ def main():
     v = res.view(with_carriers=False)
     kept = (v["var_flags"] & 1) == 0
     cc = v["car_count"][kept].astype(np.int64)
-    n_sparse = int((cc <= 64).sum())      # kSparseMax of k_fill_carriers
-    car_sparse = int(cc[cc <= 64].sum())
     W = ((info.num_samples + 63) // 64) * 8
-    # Dominant kernel k_fill_carriers.  `achieved` prices one launch with SURVEY.md §8(d)'s formula,
-    # restricted to the terms this kernel owns: per variant its class row (W bytes) and
-    # its car_begin word (8), per carrier 3 genotype bits in and a 4-byte id + 1-byte genotype out.
-    fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
-    # The bytes this layout actually has to move (lower): 32 B of slot header per variant, the class row
-    # only for variants above 64 carriers (rarer ones read a decoded id list, 4 B per carrier), half a byte
-    # of genotype per carrier in, one packed carrier word out: 2 bytes (id | gt << 13) when every sample id
-    # fits 13 bits (cohorts of at most 4032 samples), else 4.
     car_word = 2 if info.num_samples <= 4032 else 4
-    fill_bytes_layout = nvar * 32 + (nvar - n_sparse) * W + 4 * car_sparse + (ncar + 1) // 2 + car_word * ncar
+    # Dominant kernel k_fill_carriers.  ALGORITHMIC BYTES of one launch = the bytes this kernel's data layout obliges it
+    # to move: per variant slot 24 B of slot parameters (count, class, genotype offset, arena
+    # offset); per variant of at most list_max carriers its decoded 16-bit id list, rounded up to whole 16-byte groups,
+    # plus the 4-byte list offset; per denser variant its class bit row (W bytes); half a byte of genotype per carrier
+    # in; one carrier word (2 B: id | gt << 13; 4 B above 4032 samples) per ARENA entry out -- every variant's range
+    # is padded to a multiple of 8 entries and the kernel writes whole groups.  roofline.achieved = that / the
+    # kernel's mean launch time, so roofline.frac can never exceed what the HBM pins carried.
+    padded = (cc + 7) // 8 * 8
+    if info.list_max:
+        listed = cc <= info.list_max
+        id_bytes = int((padded[listed] * 2 + 4).sum()) + int((~listed).sum()) * W
+    else:  # explicit sample ids (4 B per carrier record) or a cohort above 4032 samples (rows; lists up to 64 carriers)
+        id_bytes = int(4 * cc.sum()) if not info.use_bit_vector else int(np.where(cc <= 64, 4 * cc + 4, W).sum())
+    fill_bytes_layout = int(len(cc)) * 24 + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
+    # SURVEY.md section 8(d)'s implementation-independent formula, restricted to the terms this kernel owns: per
+    # variant its class row (W) + car_begin word (8), per carrier 3 genotype bits in and 4 + 1 bytes out.  It prices
+    # bytes this layout never moves (5 B per carrier written where the arena holds 2), so it is reported for
+    # comparison only, under its own key, and is NOT the roofline fraction.
+    fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
     fill_s = fill_ms / args.steps / 1e3
-    achieved = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
-    achieved_layout = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
+    achieved = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
+    survey_gbps = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
     res.close()
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
     # (counters cannot be read from inside the run); the committed measurement is attached when it is for
@@ -360,13 +371,14 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "bytes_per_launch": fill_bytes_survey, "avg_launch_ms": fill_ms / args.steps,
-                         "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": fill_bytes_layout,
+                         "bytes_per_launch": fill_bytes_layout, "avg_launch_ms": fill_ms / args.steps,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
-                         # what crossed the HBM pins (PMC) over the same launch time: the layout writes 2-byte carrier
-                         # words where the survey formula prices 5 bytes, so `frac` can exceed 1 while this cannot
+                         # what crossed the HBM pins (PMC, profiles/traffic_<workload>.json) over the same launch time
                          "traffic_GBps": (traffic / fill_s / 1e9) if (traffic and fill_s > 0) else None,
                          "traffic_frac": (traffic / fill_s / 1e9 / HBM_PEAK_GBPS) if (traffic and fill_s > 0) else None,
+                         "survey_formula": {"bytes_per_launch": fill_bytes_survey, "GBps": survey_gbps,
+                                            "note": "SURVEY 8(d) terms of this kernel; prices 5 B per carrier written where "
+                                                    "the arena holds 2 -- a time-per-algorithmic-unit figure, not pin traffic"},
                          "pipeline_ms": tot_ms / args.steps},
             "p50_latency_us": p50,
             "type4": t4,

@@ -95,6 +95,9 @@ typedef struct {
   uint64_t device_bytes;     /* HBM held by the image */
   int device;
   uint64_t num_topology_keys; /* Graph::get_num_vertices(): vertices with an adjacency entry (graph.h:318-320) */
+  uint32_t list_max;         /* classes of at most this many carriers are expanded from decoded 16-bit id lists, denser
+                              * ones from their bit row (0 when the cohort has no such lists: explicit ids, > 4032 samples) */
+  uint32_t reserved_;
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);
 /* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */

@@ -12,8 +12,10 @@ LIB_PATH = os.path.join(_HERE, "libvs_oracle.so")
 REF_GQF_PATH = os.path.join(_HERE, "_ref", "libgqf_ref.so")
 
 
-def build(verbose=False):
-    out = subprocess.run(["make", "-s", "-C", _HERE], capture_output=True, text=True)
+def build(verbose=False, with_ref=False):
+    """Compile the restatement; with_ref=True (explicit opt-in: it compiles files of the reference checkout where they
+    lie) also builds oracle/_ref/libgqf_ref.so from the reference's own CQF sources."""
+    out = subprocess.run(["make", "-s", "-C", _HERE] + (["all", "ref"] if with_ref else ["all"]), capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
     if verbose:

@@ -18,9 +18,7 @@ def pytest_configure(config):
 def _native_built():
     """Make sure the engine and the oracle are built (hipcc cross-compiles without a GPU)."""
     from variantstore_amd import build as vb
-    from variantstore_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        vb.build_all(verbose=False)
+    vb.build_all(force=False, verbose=False)   # rebuilds when any source under csrc/ is newer than the library
     from oracle import oracle as orc
     orc._load()
     return True

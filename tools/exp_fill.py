@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Same-process experiments on the type-6 throughput path: one index build, many configurations (env toggles are read
+per call by the engine).  python tools/exp_fill.py [config ...]; a config is NAME:ENV=VAL,ENV=VAL[,len=N]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from variantstore_amd import VariantStore
+
+w = dict(bench.WORKLOADS[os.environ.get("VS_BENCH_WORKLOAD", "chr1-2504")])
+vs = None
+cur_lm = None
+
+
+def reopen(lm):
+    """lm=N in a config: (re)build the index with VS_LIST_MAX=N (the threshold is fixed when an index is opened)"""
+    global vs, cur_lm
+    if vs is not None and lm == cur_lm:
+        return
+    if vs is not None:
+        vs.close()
+    if lm is None:
+        os.environ.pop("VS_LIST_MAX", None)
+    else:
+        os.environ["VS_LIST_MAX"] = str(lm)
+    vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
+    cur_lm = lm
+TOGGLES = ("VS_FILL_ABLATE", "VS_FILL_BLOCKS", "VS_T6_HEADER_KERNEL", "VS_FILL_MODE")
+
+
+def run(name, env, rlen, steps=8):
+    for k in TOGGLES:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ww = dict(w, region_len=rlen)
+    regions = bench.make_regions(ww, 0, w["regions"])
+    for _ in range(2):
+        vs.get_var_in_ref(regions).close()
+    fill = tot = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = vs.get_var_in_ref(regions)
+        t = vs.last_timing()
+        fill += t.ms_fill
+        tot += t.ms_total
+        dig = res.digest() if _ == steps - 1 else 0
+        res.close()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    print(f"{name:>28}: len {rlen:6d}  fill {fill / steps:.3f} ms  emit {t.ms_emit:.3f}  scan {t.ms_scan:.3f}  pipeline {tot / steps:.3f} ms  "
+          f"wall {wall:.3f} ms  digest {dig:016x}", flush=True)
+
+
+configs = sys.argv[1:] or ["default:"]
+for rep in range(int(os.environ.get("EXP_REPS", "2"))):
+    for c in configs:
+        name, _, rest = c.partition(":")
+        env, rlen, lm = {}, w["region_len"], None
+        for kv in filter(None, rest.split(",")):
+            k, v = kv.split("=")
+            if k == "len":
+                rlen = int(v)
+            elif k == "lm":
+                lm = int(v)
+            else:
+                env[k] = v
+        reopen(lm)
+        run(name, env, rlen)

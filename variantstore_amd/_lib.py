@@ -33,7 +33,7 @@ class IndexInfo(C.Structure):
                 ("ref_path_nodes", C.c_uint64), ("index_nodes", C.c_uint64), ("num_classes", C.c_uint64),
                 ("num_sites", C.c_uint64), ("num_carriers", C.c_uint64), ("seq_length", C.c_uint64),
                 ("num_samples", C.c_uint32), ("use_bit_vector", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("device", C.c_int), ("num_topology_keys", C.c_uint64)]
+                ("device", C.c_int), ("num_topology_keys", C.c_uint64), ("list_max", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class ResultView(C.Structure):

@@ -27,11 +27,10 @@ def _newer(target, sources):
 
 
 def _sources():
+    """Every file under csrc/ (recursively: csrc/host/formats/*.hpp are included by the engine too) + the ABI header."""
     out = []
-    for sub in ("csrc/hip", "csrc/host", "csrc/cli"):
-        d = os.path.join(PKG, sub)
-        if os.path.isdir(d):
-            out += [os.path.join(d, f) for f in sorted(os.listdir(d))]
+    for base, _dirs, files in os.walk(os.path.join(PKG, "csrc")):
+        out += [os.path.join(base, f) for f in sorted(files)]
     out.append(os.path.join(ROOT, "include", "variantstore_hip.h"))
     return out
 

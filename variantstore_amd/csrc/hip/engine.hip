@@ -67,7 +67,11 @@ struct vs_index {
   bool close_pending = false;  // vs_index_close was called while results were alive
   unsigned long long* done_counter = nullptr;   // device word of the latency path's completion mailbox
   uint64_t lat_seq = 0;
-  uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path
+  uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path, batch totals
+  static constexpr size_t kPinTotals = 0;     // [0..3] latency path: slots, carriers, any-slow, overflow
+  static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
+  static constexpr size_t kPinRegions = 8;    // [8 .. 8 + 2*512) latency path: the regions themselves
+  static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path: slots and arena entries of the batch
 };
 
 struct vs_result {
@@ -163,6 +167,20 @@ static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out,
   return VS_OK;
 }
 
+// var_begin / car_base of a batch in one pass (k_scan2_*): out[0..n) = exclusive prefixes, out[n] = totals, which the
+// spine kernel also writes to `host_totals` (mapped host memory; NULL = not wanted) -- no staged device-to-host copy.
+static int scan_offsets(vs_index* idx, const uint64_t* nvar, const uint64_t* ncar, uint64_t n, uint64_t* var_begin, uint64_t* car_base,
+                        uint64_t* host_totals, std::vector<DevBuf>* scratch_owner) {
+  const uint64_t ntiles = n ? (n + kScanTile - 1) / kScanTile : 0;
+  void* ts = nullptr;
+  VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan2), &ts, scratch_owner));
+  if (ntiles) hipLaunchKernelGGL(k_scan2_tile_sums, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, nvar, ncar, n, (Scan2*)ts);
+  hipLaunchKernelGGL(k_scan2_spine, dim3(1), dim3(kScanBlock), 0, idx->stream, (Scan2*)ts, ntiles, var_begin + n, car_base + n, host_totals);
+  if (ntiles) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, nvar, ncar, n, (const Scan2*)ts, var_begin, car_base);
+  HIP_TRY(hipGetLastError());
+  return VS_OK;
+}
+
 static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
   for (auto& b : bufs) idx->pool.push_back(b);
   bufs.clear();
@@ -175,6 +193,24 @@ static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
     idx->pool.erase(idx->pool.begin() + k);
   }
 }
+
+// Temporaries of one call.  Every early return (VS_TRY / HIP_TRY) runs the destructor: the stream is drained first
+// -- queued kernels may still be using the buffers -- and then they go back to the pool, so a failing call on a
+// long-lived handle neither leaks HBM nor recycles memory that is still in flight.  The success path calls
+// release() itself after its own synchronisation.
+struct ScratchBufs {
+  vs_index* idx;
+  std::vector<DevBuf> bufs;
+  explicit ScratchBufs(vs_index* i) : idx(i) {}
+  ScratchBufs(const ScratchBufs&) = delete;
+  ScratchBufs& operator=(const ScratchBufs&) = delete;
+  void release() { release_bufs(idx, bufs); }
+  ~ScratchBufs() {
+    if (bufs.empty()) return;
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    release_bufs(idx, bufs);
+  }
+};
 
 // ----------------------------------------------------------- image on device
 static int build_device_image(vs_index* idx) {
@@ -205,12 +241,15 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.v_len, &d.v_len));
   VS_TRY(upload_image(idx, im.v_ridx, &d.v_ridx));
   VS_TRY(upload_image(idx, im.v_class, &d.v_class));
+  VS_TRY(upload_image(idx, im.v_src, &d.v_src));
   VS_TRY(upload_image(idx, im.v_ncar, &d.v_ncar));
   VS_TRY(upload_image(idx, im.v_nri, &d.v_nri));
   VS_TRY(upload_image(idx, im.v_car_begin, &d.v_car_begin));
   VS_TRY(upload_image(idx, im.class_rows, &d.class_rows));
   VS_TRY(upload_image(idx, im.cls_list_begin, &d.cls_list_begin));
   VS_TRY(upload_image(idx, im.cls_list_ids, &d.cls_list_ids));
+  VS_TRY(upload_image(idx, im.cls_list16, &d.cls_list16));
+  d.list_max = im.list_max;
   VS_TRY(upload_image(idx, im.gt_nibbles, &d.gt_nibbles));
   VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
   VS_TRY(upload_image(idx, im.car_index, &d.car_index));
@@ -240,12 +279,12 @@ static int build_device_image(vs_index* idx) {
     }
     HIP_TRY(hipGetLastError());
   }
-  std::vector<DevBuf> scratch;
+  ScratchBufs scratch(idx);
   {  // arena offsets: prefix of the counts rounded up to the carrier alignment (kernels.hip.h: pad_car)
     void* padded = nullptr;
-    VS_TRY(dev_alloc(idx, (G + 1) * 4, &padded, &scratch));
+    VS_TRY(dev_alloc(idx, (G + 1) * 4, &padded, &scratch.bufs));
     if (G) hipLaunchKernelGGL(k_pad_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, (const uint32_t*)d.s_ncar, (uint32_t*)padded, G);
-    VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)padded, G, d.s_carpre, &scratch));
+    VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)padded, G, d.s_carpre, &scratch.bufs));
   }
   std::vector<uint32_t> h_dup(G), h_fl(G);
   if (G) {
@@ -255,7 +294,7 @@ static int build_device_image(vs_index* idx) {
     HIP_TRY(hipMemcpyAsync(h_fl.data(), d.s_flags, G * 4, hipMemcpyDeviceToHost, idx->stream));
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  release_bufs(idx, scratch);
+  scratch.release();
   std::vector<uint32_t> sus_g, sus_prev;
   for (uint64_t g = 0; g < G; ++g) {
     if (h_fl[g] & kSiteAlwaysDrop) { sus_g.push_back((uint32_t)g); sus_prev.push_back(kNone); }
@@ -279,6 +318,7 @@ static int build_device_image(vs_index* idx) {
 
 static int finish_open(vs_index* idx, int device) {
   try {
+    if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
     build_host_image(idx->g, idx->im);
   } catch (const std::exception& e) {
     return fail(VS_ERR_FORMAT, "%s", e.what());
@@ -308,6 +348,15 @@ struct PointStrings {
   const std::vector<uint64_t>* off;
 };
 
+// Fill-kernel launch shared by every path: LDS per wave from the cohort width, WIDE from the row width.
+static uint32_t fill_gt_words(const vs_index* idx) {
+  uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
+  return gt_words < 448 ? 448 : gt_words;   // the medium path keeps 640 ids at word 256..
+}
+static size_t fill_lds_bytes(const vs_index* idx) {
+  return 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : fill_gt_words(idx) + kRingWords) * 4;
+}
+
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
@@ -334,7 +383,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
-  std::vector<DevBuf> scratch;
+  ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
   // Type 4, single walk: capacities from the type-6 bounds of the same regions, one recording walk, headers from
   // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
@@ -344,19 +393,19 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     uint64_t* cap_begin = nullptr;
-    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch));
-    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch.bufs));
+    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch.bufs));
     uint64_t cap_total = 0;
     HIP_TRY(hipMemcpyAsync(&cap_total, cap_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
     ws.cap_begin = cap_begin;
-    VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch));
-    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.cur, &scratch));
-    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ro, &scratch));
-    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.rl, &scratch));
-    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ao, &scratch));
-    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch));
-    VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch));
+    VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.cur, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ro, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.rl, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ao, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch.bufs));
     HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, ws);
@@ -373,21 +422,20 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
-  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
-  VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
-  HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-  HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+  uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
+  VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
+  totals[0] = ((volatile uint64_t*)pin_totals)[0];
+  totals[1] = ((volatile uint64_t*)pin_totals)[1];
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
-    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, d.var_begin, &scratch));
-    VS_TRY(exclusive_scan<uint64_t>(idx, d.q_ncar, n, d.car_base, &scratch));
-    HIP_TRY(hipMemcpyAsync(&totals[0], d.var_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipMemcpyAsync(&totals[1], d.car_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
     HIP_TRY(hipStreamSynchronize(idx->stream));
+    totals[0] = ((volatile uint64_t*)pin_totals)[0];
+    totals[1] = ((volatile uint64_t*)pin_totals)[1];
   }
   d.A = totals[0];
   d.S = totals[1];
@@ -434,12 +482,14 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (d.A) {
     {
       const uint64_t nchunks = (d.A + 63) / 64;
-      const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 8192);
-      static const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;
+      const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;          // profiling aids
+      // one 64-slot task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
+      // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time)
+      const uint64_t max_blocks = getenv("VS_FILL_BLOCKS") ? (uint64_t)atoll(getenv("VS_FILL_BLOCKS")) : (1ull << 30);
+      const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, max_blocks);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
-      uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
-      if (gt_words < 448) gt_words = 448;   // the medium path keeps 640 ids at word 256..
-      const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
+      const uint32_t gt_words = fill_gt_words(idx);
+      const size_t lds_bytes = fill_lds_bytes(idx);
       if (idx->d.wpc <= 63)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else
@@ -449,7 +499,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  release_bufs(idx, scratch);
+  scratch.release();
   vs_timing& t = idx->timing;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
   HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
@@ -538,7 +588,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-  std::vector<DevBuf> scratch;
+  ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
   // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
   // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
@@ -547,7 +597,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     VS_TRY(ralloc(r, 1, &q.overflow));
     HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
     hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
-    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
     HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
     VS_TRY(ralloc(r, totals[0], &q.seg_src));
@@ -557,7 +607,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 2>), grid, block, 0, idx->stream, idx->d, q);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 2>), grid, block, 0, idx->stream, idx->d, q);
     HIP_TRY(hipGetLastError());
-    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
     uint64_t over = 0;
     HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipMemcpyAsync(&over, q.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
@@ -576,8 +626,8 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 0>), grid, block, 0, idx->stream, idx->d, q);
       HIP_TRY(hipGetLastError());
     }
-    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch));
-    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
+    VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
     HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
@@ -595,7 +645,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  release_bufs(idx, scratch);
+  scratch.release();
   vs_timing& t = idx->timing;
   t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
@@ -653,20 +703,20 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   d.done_counter = idx->done_counter;
   d.done_flag = idx->pinned + 6;
   d.done_seq = ++idx->lat_seq;
+  d.host_totals = idx->pinned;
   const auto host_t0 = std::chrono::steady_clock::now();   // no HIP events here: each one is a packet on the critical path
   if (n <= 8) {   // a handful of regions: one single-block launch in front of the fill kernel
-    hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
+    hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, capA, capS);
   } else {
-    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, idx->pinned, capA, capS);
+    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, capA, capS);
     hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
     hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
   }
   {
     const uint64_t nchunks = (capA + kFillChunkSmall - 1) / kFillChunkSmall;
     const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 4096);
-    uint32_t gt_words = ((std::min<uint32_t>(idx->d.num_samples, 4064) + 32 + 255) / 256) * 64;
-    if (gt_words < 448) gt_words = 448;
-    const size_t lds_bytes = 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : gt_words + kRingWords) * 4;
+    const uint32_t gt_words = fill_gt_words(idx);
+    const size_t lds_bytes = fill_lds_bytes(idx);
     if (idx->d.wpc <= 63)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
     else
@@ -686,6 +736,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   d.done_flag = nullptr;   // later launches with this result (none today) must not post
+  d.host_totals = nullptr;
   if (idx->pinned[3]) return 1;  // overflow: nothing was written, retry with exact sizes
   d.A = idx->pinned[0];
   d.S = idx->pinned[1];
@@ -694,6 +745,14 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   t.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();   // submit -> completion, host clock
   t.fill_launches = 1;
   return VS_OK;
+}
+
+// A failed call: kernels of the attempt may still be queued, so the stream is drained before the result's buffers
+// go back to the pool.
+static int drop_result(vs_result* r, int rc) {
+  if (r->idx && r->idx->stream) (void)hipStreamSynchronize(r->idx->stream);
+  vs_result_free(r);
+  return rc;
 }
 
 extern "C" {
@@ -818,6 +877,8 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   info->device = idx->device;
   info->num_topology_keys = 0;
   for (uint32_t v : idx->g.topo_val) info->num_topology_keys += v != 0;
+  info->list_max = (idx->im.use_bit_vector && idx->im.wpc <= 63) ? idx->im.list_max : 0;
+  info->reserved_ = 0;
   return VS_OK;
 }
 
@@ -885,7 +946,7 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
     }
   }
   if (rc == 1) rc = run_var_in_ref(idx, regions, n, r);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -899,7 +960,7 @@ int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t
   r->idx = idx;
   idx->live_results++;
   int rc = run_var_in_ref(idx, regions, n, r, sample_id);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -915,7 +976,7 @@ int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_
   r->idx = idx;
   idx->live_results++;
   int rc = run_var_in_ref(idx, regions, n, r, kNone, sample_ids);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -931,7 +992,7 @@ static int run_point_batch(vs_index* idx, const uint64_t* positions, uint64_t n,
   r->kind = mode == 7 ? 7 : 0;
   idx->live_results++;
   int rc = run_var_in_ref(idx, regions.data(), n, r, kNone, nullptr, mode, strings);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -978,7 +1039,7 @@ int vs_query_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, con
   r->kind = sample_coordinates ? 3 : 2;
   idx->live_results++;
   int rc = run_sample_seq(idx, regions, n, sample_ids, r->kind, r);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -991,7 +1052,7 @@ int vs_query_sample_var_in_sample(vs_index* idx, const vs_region* regions, uint6
   idx->live_results++;
   static const uint32_t none = 0;
   int rc = run_var_in_ref(idx, regions, n, r, kNone, n ? sample_ids : &none, 0, nullptr, 5);
-  if (rc != VS_OK) { vs_result_free(r); return rc; }
+  if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
 }
@@ -1033,16 +1094,16 @@ int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vert
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
   HIP_TRY(hipSetDevice(idx->device));
   if (n == 0) return VS_OK;
-  std::vector<DevBuf> bufs;
+  ScratchBufs tmp(idx);
   void *dp = nullptr, *dout = nullptr;
-  VS_TRY(dev_alloc(idx, n * 8, &dp, &bufs));
-  VS_TRY(dev_alloc(idx, n * 4, &dout, &bufs));
+  VS_TRY(dev_alloc(idx, n * 8, &dp, &tmp.bufs));
+  VS_TRY(dev_alloc(idx, n * 4, &dout, &tmp.bufs));
   HIP_TRY(hipMemcpyAsync(dp, pos, n * 8, hipMemcpyHostToDevice, idx->stream));
   hipLaunchKernelGGL(k_find, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, (const uint64_t*)dp, n, (uint32_t*)dout);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(vertex_out, dout, n * 4, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  release_bufs(idx, bufs);
+  tmp.release();
   return VS_OK;
 }
 
@@ -1185,9 +1246,9 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   VS_NOT_SEQ(r);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
-  std::vector<DevBuf> bufs;
+  ScratchBufs tmp(idx);
   void* dd = nullptr;
-  VS_TRY(dev_alloc(idx, 8, &dd, &bufs));
+  VS_TRY(dev_alloc(idx, 8, &dd, &tmp.bufs));
   HIP_TRY(hipMemsetAsync(dd, 0, 8, idx->stream));
   if (r->d.A) {
     uint64_t blocks = std::min<uint64_t>((r->d.A + 3) / 4, 8192);
@@ -1196,7 +1257,7 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   }
   HIP_TRY(hipMemcpyAsync(digest, dd, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  release_bufs(idx, bufs);
+  tmp.release();
   return VS_OK;
 }
 

@@ -55,10 +55,12 @@ struct DevImage {
   const uint32_t* row_ptr;
   const uint32_t* col;
   const uint32_t *v_off, *v_len, *v_ridx, *v_class, *v_ncar, *v_nri;
+  const uint32_t* v_src;   // per vertex: group index of its class's 16-bit id list (<= list_max carriers) or its class id (row)
   const uint64_t* v_car_begin;
   const uint64_t* class_rows;
   const uint32_t* cls_list_begin;
   const uint32_t* cls_list_ids;
+  const uint16_t* cls_list16;   // 16-bit lists, 8-entry aligned and padded, of every class of at most list_max carriers (wpc <= 63)
   const uint8_t* gt_nibbles;
   const uint32_t* car_sid;
   const uint32_t* car_index;  // sample-coordinate index per carrier record (types 2/3/5); valid when has_car_index
@@ -71,6 +73,7 @@ struct DevImage {
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
   const uint32_t* rp_sus_prefix;  // [P+1] suspicious sites before each ref-path slot's first site (no bisection per query)
   uint32_t n_sus, has_car_index;
+  uint32_t list_max, pad2_;
 };
 
 struct DevResult {
@@ -85,7 +88,8 @@ struct DevResult {
   uint64_t* car_base;       // [Q+1]
   uint64_t* var_count;      // [Q]
   uint64_t* r_pos;
-  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_region, *r_class;
+  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_region;
+  uint32_t* r_class;        // DevImage::v_src of the slot's vertex: list group index or class id, by r_car_count
   uint64_t* r_car_begin;
   uint64_t* r_gt0;
   void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
@@ -97,6 +101,9 @@ struct DevResult {
   unsigned long long* done_counter;
   volatile uint64_t* done_flag;
   uint64_t done_seq;
+  // latency path: mapped host copy of dyn_totals, written by the SAME thread that posts done_flag (totals, system
+  // fence, flag: one writer, so the flag orders the data it guards whatever the memory type of the mapping)
+  volatile uint64_t* host_totals;
 };
 
 // Every variant's carrier range in the result arena starts on a multiple of 8 entries (16 bytes of 16-bit carrier
@@ -181,7 +188,7 @@ __global__ void __launch_bounds__(256) k_build_sites(DevImage im, uint64_t slot_
     }
     im.s_pos[g] = pos; im.s_ref_off[g] = ro; im.s_ref_len[g] = rl; im.s_alt_off[g] = ao; im.s_alt_len[g] = al;
     im.s_vid[g] = b; im.s_ncar[g] = (fl & kSiteAlwaysDrop) ? 0u : ncar; im.s_flags[g] = fl;
-    im.s_class[g] = im.v_class[b]; im.s_gt0[g] = im.v_car_begin[b];
+    im.s_class[g] = im.v_src[b]; im.s_gt0[g] = im.v_car_begin[b];
     ++g;
   }
 }
@@ -258,7 +265,7 @@ __global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r)
 // Small batches (latency path): bounds of every region and both offset scans in ONE single-block
 // launch.  totals = {slots, carriers, any region needing the literal dedup rule}.
 __global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResult r, uint64_t* totals,
-                                                           uint64_t* host_totals, uint64_t cap_slots, uint64_t cap_carriers) {
+                                                           uint64_t cap_slots, uint64_t cap_carriers) {
   for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -271,7 +278,6 @@ __global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResul
     r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
     const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
     totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
-    if (host_totals) { host_totals[0] = a; host_totals[1] = c; host_totals[2] = slow; host_totals[3] = over; }
   }
 }
 
@@ -339,6 +345,79 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const T* in, uint64_t
   for (int i = 0; i < kScanItems; ++i) {
     if (base + i < n) out[base + i] = ex;
     ex += loc[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Both offset arrays of a batch -- var_begin (slots) and car_base (padded arena entries) -- in ONE pass over the
+// regions: three launches instead of six.  The grand totals also go to `totals` (mapped host memory).
+// ---------------------------------------------------------------------------
+struct Scan2 { uint64_t a, c; };
+
+__device__ __forceinline__ Scan2 block_exclusive_scan2(Scan2 v, Scan2* total) {
+  __shared__ Scan2 wsum[kScanBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  Scan2 incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t ta = __shfl_up(incl.a, d, 64), tc = __shfl_up(incl.c, d, 64);
+    if (lane >= d) { incl.a += ta; incl.c += tc; }
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  Scan2 woff{0, 0}, tot{0, 0};
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    if (w < wid) { woff.a += wsum[w].a; woff.c += wsum[w].c; }
+    tot.a += wsum[w].a; tot.c += wsum[w].c;
+  }
+  __syncthreads();
+  *total = tot;
+  return Scan2{woff.a + incl.a - v.a, woff.c + incl.c - v.c};
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan2_tile_sums(const uint64_t* nvar, const uint64_t* ncar, uint64_t n, Scan2* tile_sums) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  Scan2 s{0, 0};
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) { s.a += nvar[base + i]; s.c += ncar[base + i]; }
+  Scan2 tot;
+  block_exclusive_scan2(s, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: tile sums -> exclusive prefixes in place; grand totals to the two [n] entries and to totals[0..1]
+__global__ void __launch_bounds__(kScanBlock) k_scan2_spine(Scan2* tile_sums, uint64_t ntiles, uint64_t* var_end, uint64_t* car_end,
+                                                            uint64_t* totals) {
+  Scan2 carry{0, 0};
+  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const Scan2 v = i < ntiles ? tile_sums[i] : Scan2{0, 0};
+    Scan2 tot;
+    const Scan2 ex = block_exclusive_scan2(v, &tot);
+    if (i < ntiles) tile_sums[i] = Scan2{carry.a + ex.a, carry.c + ex.c};
+    carry.a += tot.a; carry.c += tot.c;
+  }
+  if (threadIdx.x == 0) {
+    *var_end = carry.a; *car_end = carry.c;
+    if (totals) { totals[0] = carry.a; totals[1] = carry.c; }
+  }
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const uint64_t* nvar, const uint64_t* ncar, uint64_t n, const Scan2* tile_sums,
+                                                            uint64_t* var_begin, uint64_t* car_base) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  Scan2 loc[kScanItems];
+  Scan2 s{0, 0};
+  for (int i = 0; i < kScanItems; ++i) {
+    loc[i] = base + i < n ? Scan2{nvar[base + i], ncar[base + i]} : Scan2{0, 0};
+    s.a += loc[i].a; s.c += loc[i].c;
+  }
+  Scan2 tot;
+  Scan2 ex = block_exclusive_scan2(s, &tot);
+  const Scan2 ts = tile_sums[blockIdx.x];
+  ex.a += ts.a; ex.c += ts.c;
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) { var_begin[base + i] = ex.a; car_base[base + i] = ex.c; }
+    ex.a += loc[i].a; ex.c += loc[i].c;
   }
 }
 
@@ -415,7 +494,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 // A handful of regions (single-region latency): bounds, offsets, headers and the dedup rule in ONE single-block
 // launch -- three kernel launches fewer in front of k_fill_carriers.  Writes of one phase are read by other waves of
 // the same workgroup in the next; __syncthreads() orders them (workgroup scope, one CU).
-__global__ void __launch_bounds__(256) k_small_front(DevImage im, DevResult r, uint64_t* totals, uint64_t* host_totals,
+__global__ void __launch_bounds__(256) k_small_front(DevImage im, DevResult r, uint64_t* totals,
                                                      uint64_t cap_slots, uint64_t cap_carriers) {
   for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
   __syncthreads();
@@ -429,7 +508,6 @@ __global__ void __launch_bounds__(256) k_small_front(DevImage im, DevResult r, u
     r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
     const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
     totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
-    if (host_totals) { host_totals[0] = a; host_totals[1] = c; host_totals[2] = slow; host_totals[3] = over; }
   }
   __syncthreads();
   if (totals[3]) return;
@@ -583,14 +661,102 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       }
     }
 
-    // ---------------- sparse: lane per CARRIER ----------------
-    // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
-    // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
-    // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
-    // the class's decoded id list (built once at load), genotype nibble from the pool.  Two or three
-    // full-width passes replace up to eight lane-per-variant iterations whose loads and stores ran with a
-    // handful of active lanes -- the cost of those was per instruction, not per byte.
-    {
+    const bool lists = !WIDE && !explicit_ids;
+    const uint32_t list_max = lists ? im.list_max : kSparseMax;
+
+    // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
+    //                  list phase runs in the shadow of that memory latency ----------------
+    uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
+    uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
+    uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
+    if (dmask) {
+      const int t0 = __builtin_ctzll(dmask);
+      const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
+      const uint64_t gt0_0 = wave_bcast64(gt0, t0);
+      if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
+      const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
+      const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+      const uint64_t d1 = dmask & (dmask - 1);
+      if (d1) {
+        const uint32_t cls_1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d1));
+        if (lane < wpc) word_n1 = class_rows[(uint64_t)cls_1 * wpc + lane];
+      }
+    }
+
+    // Cohorts of at most 4032 samples with class rows: every variant of at most list_max carriers is expanded from its
+    // class's decoded 16-bit id list, LANE PER GROUP of 8 carriers (= one 16-byte arena group; every variant's arena
+    // range and every list start on a group boundary and own their padding).  The groups of all such variants of the
+    // task form one list: a DPP prefix sum over the group counts gives every variant its slice, a lane takes entry e,
+    // finds its variant by bisection over the 64 offsets (LDS), loads the 8 ids (one 16-byte load) and the 32
+    // genotype bits that go with them (one 8-byte load of the nibble pool), and stores one finished 16-byte group.
+    // No bit row is read, nothing is staged, no lane idles: a rare variant is one group, a 640-carrier one is 80.
+    // Two entries per lane and pass, so that four independent loads are in flight per lane.
+    if (lists) {
+      uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
+      const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+      const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+      const uint32_t incl = wave_inclusive_scan(c);
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      if (total) {
+        uint32_t* s_idb = s_off + 64;
+        uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+        uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+        s_off[lane] = incl - c;
+        s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
+        s_gt0[lane] = gt0;
+        s_cb[lane] = cb;
+        const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list16);
+        const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+        uint4* __restrict__ arena_groups = reinterpret_cast<uint4*>(r.carriers);
+        for (uint32_t e0 = lane; e0 < total; e0 += 128) {
+          const uint32_t e1 = e0 + 64;
+          const bool two = e1 < total;
+          uint32_t L0 = 0, L1 = 0;
+#pragma unroll
+          for (uint32_t step = 32; step; step >>= 1) {
+            if (s_off[L0 + step] <= e0) L0 += step;
+            if (s_off[L1 + step] <= e1) L1 += step;
+          }
+          const uint32_t k0 = e0 - s_off[L0], k1 = e1 - s_off[L1];   // group within its variant
+          const uint64_t g0 = s_gt0[L0] + (uint64_t)k0 * kCarAlign;   // its first genotype nibble: 32 bits from bit 4g
+          const uint64_t g1 = s_gt0[L1] + (uint64_t)k1 * kCarAlign;
+          const uint4 iw0 = list_groups[(uint64_t)s_idb[L0] + k0];
+          uint2 nw0, nw1 = {0, 0};
+          __builtin_memcpy(&nw0, gt32 + (g0 >> 3), 8);
+          uint4 iw1 = {0, 0, 0, 0};
+          if (two) {
+            iw1 = list_groups[(uint64_t)s_idb[L1] + k1];
+            __builtin_memcpy(&nw1, gt32 + (g1 >> 3), 8);
+          }
+          const uint64_t dst0 = (s_cb[L0] >> 3) + k0, dst1 = (s_cb[L1] >> 3) + k1;   // arena ranges start on group boundaries
+          {
+            const uint32_t n = __builtin_amdgcn_alignbit(nw0.y, nw0.x, ((uint32_t)g0 & 7u) * 4);
+            uint4 v;
+            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw0.x));
+            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
+            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
+            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
+            arena_groups[dst0] = v;
+          }
+          if (two) {
+            const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
+            uint4 v;
+            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw1.x));
+            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
+            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
+            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
+            arena_groups[dst1] = v;
+          }
+        }
+      }
+    } else {
+      // ---------------- explicit-id cohorts and cohorts above 4032 samples: sparse variants lane per CARRIER ----------------
+      // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
+      // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
+      // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
+      // the class's decoded id list (built once at load), genotype nibble from the pool.
       uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
       const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
       const uint32_t c = sp ? cnt : 0u;
@@ -622,35 +788,19 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       }
     }
 
-    // ---------------- mid / dense: wave per variant ----------------
-    uint64_t dmask = __ballot(cnt > kSparseMax && !explicit_ids);
     if (dmask == 0) continue;
-    // Per-wave LDS block (4 KiB): one genotype BYTE per carrier (unpacked from the nibble
-    // pool while staging, so the expansion loops read it with a single ds_read_u8);
-    // the medium-density path also keeps its id list in the upper part of the block.
+    // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
+    // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
+    // cohorts, the output ring.
     uint8_t* gt_lds = reinterpret_cast<uint8_t*>(&lds_blk[(threadIdx.x >> 6) * lds_words_per_wave]);
     uint32_t* ids_lds = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + kMidIdsAt];
     uint32_t* ring = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + gt_words];
-    int t = __builtin_ctzll(dmask);
-    uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
-    uint64_t gt0_t = wave_bcast64(gt0, t);
-    uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
-    uint64_t word_cur = 0;
-    uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};
-    // first variant: request its row and its nibbles
-    {
-      if (lane < wpc) word_cur = class_rows[(uint64_t)cls_t * wpc + lane];
-      const uint64_t b0 = (gt0_t >> 1) & ~15ULL;                        // aligned byte base
-      const uint64_t need = ((gt0_t + cnt_t + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
-      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
-    }
     while (dmask) {
-      t = __builtin_ctzll(dmask);
+      const int t = __builtin_ctzll(dmask);
       dmask &= dmask - 1;
-      cnt_t = __builtin_amdgcn_readlane(cnt, t);
-      cls_t = __builtin_amdgcn_readlane(cls, t);
-      gt0_t = wave_bcast64(gt0, t);
+      const uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
+      const uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
+      const uint64_t gt0_t = wave_bcast64(gt0, t);
       const uint64_t cb_t = wave_bcast64(cb, t);
       const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
       const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
@@ -664,32 +814,37 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
         *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
         if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
       }
-      // request the next variant's row and nibbles before expanding this one
-      uint64_t word_next = 0;
+      // request the next variant's nibbles and the row of the one after it before expanding this one (rows are the
+      // random 320-byte reads of this kernel: two of them stay in flight per wave)
       if (WIDE) { nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0}; }   // (the slice path never reads nibbles it did not load)
+      word_n2 = 0;
       if (dmask) {
         const int tn = __builtin_ctzll(dmask);
-        const uint32_t cls_n = __builtin_amdgcn_readlane(cls, tn);
         const uint64_t gt0_n = wave_bcast64(gt0, tn);
         const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
-        if (lane < wpc) word_next = class_rows[(uint64_t)cls_n * wpc + lane];
         const uint64_t bn = (gt0_n >> 1) & ~15ULL;
         const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
         if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
         if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
+        const uint64_t d2 = dmask & (dmask - 1);
+        if (d2) {
+          const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
+          if (lane < wpc) word_n2 = class_rows[(uint64_t)cls_2 * wpc + lane];
+        }
       }
+      const uint64_t word_this = word_cur;
+      word_cur = word_n1; word_n1 = word_n2;   // the queue advances here: every `continue` below leaves it consistent
       if constexpr (WIDE) {
         if (!staged || wpc > 64) {
           // rows wider than one wave or more than 4096 staged genotypes: generic path
           expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, carriers + cb_t, lane);
-          word_cur = word_next;
           continue;
         }
       }
-      uint64_t mine = word_cur;
+      uint64_t mine = word_this;
       if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
-      if ((ablate & 2) && cnt_t <= kMidMax) { word_cur = word_next; continue; }
-      if ((ablate & 4) && cnt_t > kMidMax) { word_cur = word_next; continue; }
+      if ((ablate & 2) && cnt_t <= kMidMax) continue;
+      if ((ablate & 4) && cnt_t > kMidMax) continue;
       if constexpr (!WIDE) {
         // ---- slice path: every lane owns wpc consecutive bits of the row (64 x wpc bits = the whole row), peels
         //      them into a 16-bit id list in LDS at its prefix-sum position, then the list leaves in 1 KiB-aligned
@@ -806,7 +961,6 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
           }
         }
       }
-      word_cur = word_next;
     }
   }
   if (r.done_flag) {   // latency launches: completion mailbox
@@ -815,6 +969,8 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       __threadfence();
       if (atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1) {
         *r.done_counter = 0;   // re-armed for the next launch on this stream
+        if (r.host_totals && r.dyn_totals)   // written by an earlier kernel of the stream: visible here
+          for (int i = 0; i < 4; ++i) r.host_totals[i] = r.dyn_totals[i];
         __threadfence_system();
         *r.done_flag = r.done_seq;
       }
@@ -944,7 +1100,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
               r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
               r.r_region[a] = (uint32_t)q;
-              r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+              r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
             }
             if (MODE == 2) {
               const uint64_t s0 = ws.cap_begin[q];
@@ -979,7 +1135,7 @@ __global__ void __launch_bounds__(64) k_emit_from_walk(DevImage im, DevResult r,
     r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
     r.r_flags[a] = 0; r.r_car_begin[a] = cb; r.r_car_count[a] = c;
     r.r_region[a] = (uint32_t)q;
-    r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+    r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
     cb += pad_car(c); kept += c;
   }
   r.var_count[q] = n;
@@ -1272,7 +1428,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
           r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
           r.r_region[a] = (uint32_t)q;
-          r.r_class[a] = im.v_class[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+          r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
         if (MODE == 2) {
           const uint64_t s0 = ws.cap_begin[q];

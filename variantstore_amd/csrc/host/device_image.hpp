@@ -31,6 +31,8 @@ namespace vsamd {
 
 constexpr uint32_t VS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t kSparseClassMax = 64;  // must equal kSparseMax in kernels.hip.h
+constexpr uint32_t kListGroup = 8;        // must equal kCarAlign in kernels.hip.h: carriers per 16-byte arena group
+constexpr uint32_t kListMaxDefault = 640; // classes with at most this many carriers also get a decoded 16-bit id list
 
 struct HostImage {
   // scalars
@@ -62,7 +64,17 @@ struct HostImage {
   // sparse classes (<= kSparseClassMax carriers) also decoded once into explicit id lists, so the
   // expansion of a rare variant reads a few ids instead of scanning a whole bit row
   std::vector<uint32_t> cls_list_begin;  // [C+2]
-  std::vector<uint32_t> cls_list_ids;    // ascending sample ids (ref excluded), padded
+  std::vector<uint32_t> cls_list_ids;    // ascending sample ids (ref excluded), padded  (cohorts above 4032 samples)
+  // Cohorts of at most 4032 samples (16-bit carrier words): the lists are 16-bit, every list starts on a multiple of
+  // 8 entries (one 16-byte load = one arena group) and is zero-padded to the next one, and they exist for every class
+  // of at most list_max carriers -- k_fill_carriers expands those lane-per-GROUP straight from the list, only denser
+  // classes go through their bit row.
+  std::vector<uint16_t> cls_list16;
+  uint32_t list_max = kListMaxDefault;
+  // What k_fill_carriers needs to find a vertex's carrier ids, resolved once here so that the kernel has no dependent
+  // look-up in front of its first id load: for a listed vertex (<= list_max carriers, 16-bit lists in use) the GROUP
+  // index of its class's list in cls_list16 (entry offset / 8), otherwise its class id (row index).
+  std::vector<uint32_t> v_src;
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
   std::vector<uint32_t> car_index;   // sample-coordinate index per carrier record (query types 2/3/5); may be empty
@@ -250,22 +262,41 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     std::copy(g.class_bits.begin(), g.class_bits.end(), im.class_rows.begin() + im.wpc);
   im.cls_list_begin.assign(im.C + 2, 0);
   im.cls_list_ids.clear();
+  im.cls_list16.clear();
+  const bool narrow = im.wpc <= 63;   // 16-bit carrier words (kernels.hip.h: the non-WIDE instantiation)
   if (g.use_bit_vector) {
     for (uint64_t c = 1; c <= im.C; ++c) {
       const uint64_t* row = &im.class_rows[c * im.wpc];
       uint32_t pc = 0;
       for (uint32_t w = 0; w < im.wpc; ++w) pc += __builtin_popcountll(w == 0 ? (row[w] & ~1ULL) : row[w]);
-      im.cls_list_begin[c] = (uint32_t)im.cls_list_ids.size();
-      if (pc <= kSparseClassMax) {
-        for (uint32_t w = 0; w < im.wpc; ++w) {
-          uint64_t x = w == 0 ? (row[w] & ~1ULL) : row[w];
-          while (x) { im.cls_list_ids.push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
+      if (narrow) {
+        if (im.cls_list16.size() > 0xFFFFFFF0ull - im.num_samples) throw std::runtime_error("decoded class lists exceed 2^32 entries");
+        im.cls_list_begin[c] = (uint32_t)im.cls_list16.size();
+        if (pc <= im.list_max) {
+          for (uint32_t w = 0; w < im.wpc; ++w) {
+            uint64_t x = w == 0 ? (row[w] & ~1ULL) : row[w];
+            while (x) { im.cls_list16.push_back((uint16_t)(w * 64 + __builtin_ctzll(x))); x &= x - 1; }
+          }
+          im.cls_list16.resize((im.cls_list16.size() + kListGroup - 1) / kListGroup * kListGroup, 0);
+        }
+      } else {
+        im.cls_list_begin[c] = (uint32_t)im.cls_list_ids.size();
+        if (pc <= kSparseClassMax) {
+          for (uint32_t w = 0; w < im.wpc; ++w) {
+            uint64_t x = w == 0 ? (row[w] & ~1ULL) : row[w];
+            while (x) { im.cls_list_ids.push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
+          }
         }
       }
     }
-    im.cls_list_begin[im.C + 1] = (uint32_t)im.cls_list_ids.size();
+    im.cls_list_begin[im.C + 1] = (uint32_t)(narrow ? im.cls_list16.size() : im.cls_list_ids.size());
   }
   im.cls_list_ids.resize(im.cls_list_ids.size() + 8, 0);  // 16-byte reads may run past the last list
+  im.cls_list16.resize(im.cls_list16.size() + 8, 0);
+  im.v_src = im.v_class;
+  if (g.use_bit_vector && narrow)
+    for (uint64_t v = 0; v < V; ++v)
+      if (im.v_ncar[v] <= im.list_max) im.v_src[v] = im.cls_list_begin[im.v_class[v]] / kListGroup;
   im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 32, 0);  // windowed 64-bit reads run up to 24 bytes past a list
   for (uint64_t c = 0; c < g.car_flags.size(); ++c)
     im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
