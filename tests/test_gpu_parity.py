@@ -238,6 +238,36 @@ def test_wide_cohort_dense_variants(tmp_path):
     assert _compare_t4(vs, orc, regions[:40], "S00750") == 40
 
 
+@pytest.mark.parametrize("list_max", [0, 3, 17, 64, 200])
+@pytest.mark.parametrize("n_samples", [70, 150, 1500, 3900])
+def test_list_threshold_sweep(list_max, n_samples, tmp_path, monkeypatch):
+    """k_fill_carriers takes a variant either from its class's decoded 16-bit id list (<= list_max carriers) or from
+    its bit row (two rounds of half a row).  With the production threshold small cohorts never reach the row path,
+    so the threshold is swept here (VS_LIST_MAX is read when an index is opened): both paths, row widths of 2, 3
+    (odd), 24 and 61 (odd, 31-bit slices) words, text-exact against the oracle for query types 6 and 4."""
+    monkeypatch.setenv("VS_LIST_MAX", str(list_max))
+    small = n_samples <= 150
+    vs = VariantStore.synthetic(device=0, ref_length=60_000 if small else 120_000, num_variants=1500 if small else 700,
+                                num_samples=n_samples, seed=500 + n_samples, first_pos=100, frac_ins=0.06, frac_del=0.06,
+                                frac_multi=0.03, max_indel=4, af_exponent=2.5)
+    assert vs.info().list_max == list_max
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(list_max * 31 + n_samples)
+    L = vs.info().ref_length
+    starts = rng.integers(1, L - 4000, size=60 if small else 30)
+    regions = [(int(s), int(s) + int(rng.integers(1, 4000))) for s in starts] + [(1, 3000), (L - 2000, L + 5)]
+    cc = vs.get_var_in_ref(regions).view(False)["car_count"]
+    if list_max * 4 < n_samples:
+        assert (cc > list_max).sum() > 20, "the row path must be exercised"
+    assert _compare_t6(vs, orc, regions) == len(regions)
+    assert _compare_t6(vs, orc, regions[:3]) == 3          # latency path (8-slot tasks)
+    name = vs.sample_name(1 + n_samples // 2)
+    assert _compare_t4(vs, orc, regions[:12], name) == 12
+    vs.close()
+
+
 def test_cohort_wider_than_one_wave_of_row_words(tmp_path):
     """4500 samples: class rows of 71 words (> 64) take the generic expansion path."""
     vs = VariantStore.synthetic(device=0, ref_length=60_000, num_variants=400, num_samples=4500, seed=78,

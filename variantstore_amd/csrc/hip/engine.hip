@@ -489,7 +489,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, max_blocks);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
       const uint32_t gt_words = fill_gt_words(idx);
-      const size_t lds_bytes = fill_lds_bytes(idx);
+      const size_t lds_bytes = fill_lds_bytes(idx) + (getenv("VS_FILL_LDS_PAD") ? (size_t)atoll(getenv("VS_FILL_LDS_PAD")) : 0);   // occupancy experiments
       if (idx->d.wpc <= 63)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else

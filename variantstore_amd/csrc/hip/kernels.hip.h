@@ -552,7 +552,10 @@ __host__ __device__ inline uint32_t slice_gt_words(uint32_t n_samples) {
 }
 constexpr uint32_t kListWindow = 64;         // the id list is laid out by arena position modulo 64 entries (128 bytes)
 __host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) {
-  const uint32_t w = ((kListWindow + n_samples + 8 + 7) & ~7u) / 2;
+  // one round of the slice path: half a row (64 lanes x ceil(wpc / 2) bits) behind the alignment window, plus the
+  // incomplete group carried over from the first round
+  const uint32_t wpc = (n_samples + 63) / 64, round_bits = 64 * ((wpc + 1) / 2);
+  const uint32_t w = ((kListWindow + round_bits + 16 + 7) & ~7u) / 2;
   return w < kRowWords ? kRowWords : w;
 }
 __host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
@@ -846,53 +849,69 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       if ((ablate & 2) && cnt_t <= kMidMax) continue;
       if ((ablate & 4) && cnt_t > kMidMax) continue;
       if constexpr (!WIDE) {
-        // ---- slice path: every lane owns wpc consecutive bits of the row (64 x wpc bits = the whole row), peels
-        //      them into a 16-bit id list in LDS at its prefix-sum position, then the list leaves in 1 KiB-aligned
-        //      blocks, one 16-byte store per lane, genotypes merged from the raw nibble stream on the way out.
-        //      Compared with the bit-per-lane ring (kept below for wide cohorts) this needs ~2.5x fewer
-        //      instructions per carrier and no scalar work per row word. ----
+        // ---- slice path: the row is expanded in TWO rounds of 64 x sb bits (sb = ceil(wpc / 2) <= 32): in a round
+        //      every lane owns sb consecutive bits, peels them into a 16-bit id list in LDS at its prefix-sum position,
+        //      then the complete 16-byte groups of the list leave in 128-byte-aligned blocks, one store per lane,
+        //      genotypes merged from the raw nibble stream on the way out; the (< 8) ids of the last, incomplete group
+        //      move to the front of the list and the second round continues behind them.  The list therefore holds
+        //      half a row at most -- the per-wave LDS block is what limits this kernel's occupancy. ----
         const uint8_t* nib_lds = gt_lds;
         uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
         uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
         rowq[lane] = mine;
         if (lane == 0) rowq[64] = 0;
-        const uint32_t b0s = wpc * lane, wi = b0s >> 6, sh = b0s & 63;
-        const uint64_t ra = rowq[wi], rb = rowq[wi + 1];
-        uint64_t slice = sh ? ((ra >> sh) | (rb << (64 - sh))) : ra;
-        slice &= (1ULL << wpc) - 1;
-        uint32_t lo = (uint32_t)slice, hi = (uint32_t)(slice >> 32);
-        const uint32_t pc = __popc(lo) + __popc(hi);
-        uint32_t incl = wave_inclusive_scan(pc);
-        asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
+        const uint32_t sb = (wpc + 1) >> 1;                                       // bits per lane and round
+        const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1u;
+        const uint32_t* rowd = reinterpret_cast<const uint32_t*>(rowq);
+        const uint32_t bp0 = sb * lane, bp1 = bp0 + 64 * sb;                      // first bit of the lane's slice per round
+        uint32_t bits0 = __builtin_amdgcn_alignbit(rowd[(bp0 >> 5) + 1], rowd[bp0 >> 5], bp0 & 31u) & smask;
+        uint32_t bits1 = __builtin_amdgcn_alignbit(rowd[(bp1 >> 5) + 1], rowd[bp1 >> 5], bp1 & 31u) & smask;
         const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
         uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
-        const uint32_t end1k = a1k + cnt_t;
-        uint32_t j = a1k + incl - pc;                       // list index of this lane's first carrier
-        while (lo) {
-          ids16[j++] = (uint16_t)(b0s + __builtin_ctz(lo));
-          lo &= lo - 1;
-        }
-        while (hi) {
-          ids16[j++] = (uint16_t)(b0s + 32 + __builtin_ctz(hi));
-          hi &= hi - 1;
-        }
-        // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32
-        // consecutive bits of the stream.  nibble index = list index + D; the staging is biased by 32 nibbles so
-        // that the first, partly valid group (entries before a1k are not the variant's) still addresses forwards.
-        const uint32_t D = nshift + 32 - a1k;
-        for (uint32_t q8 = lane * 8; q8 < end1k; q8 += 512) {
-          if (q8 + 8 <= a1k) continue;
-          const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
-          const uint32_t n0 = q8 + D;
-          const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
-          const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
-          uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
-                     // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
-          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
-          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
-          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
-          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
-          *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+        // nibble index = list index + D; the staging is biased by 32 nibbles
+        uint32_t D = nshift + 32 - a1k;
+        uint32_t pos = a1k;                                 // list index of the round's first carrier
+        uint32_t done8 = a1k;                               // groups below this list index have been written
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          uint32_t bits = round ? bits1 : bits0;
+          const uint32_t idb = round ? bp1 : bp0;
+          const uint32_t pc = __popc(bits);
+          uint32_t incl = wave_inclusive_scan(pc);
+          asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
+          const uint32_t end = pos + __builtin_amdgcn_readlane(incl, 63);
+          uint32_t j = pos + incl - pc;                     // list index of this lane's first carrier of the round
+          while (bits) {
+            ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
+            bits &= bits - 1;
+          }
+          // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32 consecutive
+          // bits of the stream.  Round 0 writes complete groups only, round 1 everything (the range owns its padding).
+          const uint32_t flush = round ? ((end + 7u) & ~7u) : (end & ~7u);
+          for (uint32_t q8 = done8 + lane * 8; q8 < flush; q8 += 512) {
+            const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
+            const uint32_t n0 = q8 + D;
+            const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
+            const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
+            uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
+                       // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
+            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
+            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
+            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
+            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
+            *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+          }
+          if (round == 0) {
+            // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
+            const uint32_t o = flush & ~(kListWindow - 1);
+            if (o) {
+              if (lane == 0) *reinterpret_cast<uint4*>(ids16 + (flush - o)) = *reinterpret_cast<const uint4*>(ids16 + flush);
+              g1k += o;
+              D += o;
+            }
+            pos = end - o;
+            done8 = flush - o;
+          }
         }
       } else if (cnt_t <= kMidMax) {
         const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
