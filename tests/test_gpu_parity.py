@@ -330,10 +330,10 @@ def test_hit_list_records_for_the_collective(tmp_path):
                 assert res.region_text(a) == res.region_text(b)
 
 
-def test_small_batches_that_outgrow_the_speculative_buffers(tmp_path):
-    """Batches of <= 512 regions take the single-sync latency path with result buffers sized by guess;
-    regions holding more variants (> 4096) or more carriers (> 2^20) than the guess must fall back to
-    the exact-size path and give the same text."""
+def test_latency_path_with_large_answers(tmp_path):
+    """Batches of <= 64 regions take the single-launch latency path (k_query_small), whose result slab is sized on the
+    host from the same bounds arithmetic the device repeats: regions holding thousands of variants and millions of
+    carriers, mixed with tiny ones, and a 512-region batch (general path) all give the oracle's text."""
     vs = VariantStore.synthetic(device=0, ref_length=600_000, num_variants=9000, num_samples=1200, seed=91,
                                 first_pos=200, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=4,
                                 af_exponent=2.5)

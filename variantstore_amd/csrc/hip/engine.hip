@@ -67,6 +67,7 @@ struct vs_index {
   bool close_pending = false;  // vs_index_close was called while results were alive
   unsigned long long* done_counter = nullptr;   // device word of the latency path's completion mailbox
   uint64_t lat_seq = 0;
+  std::vector<uint64_t> h_carpre;   // host copy of DevImage::s_carpre (arena prefix): sizes of the latency path's results
   uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path, batch totals
   static constexpr size_t kPinTotals = 0;     // [0..3] latency path: slots, carriers, any-slow, overflow
   static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
@@ -266,6 +267,7 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(alloc_image(idx, G, &d.s_flags));
   VS_TRY(alloc_image(idx, G, &d.s_dup_prev));
   VS_TRY(alloc_image(idx, G + 1, &d.s_carpre));
+  VS_TRY(alloc_image(idx, G + 1, &d.s_kpre));
   VS_TRY(alloc_image(idx, G, &d.s_class));
   VS_TRY(alloc_image(idx, G, &d.s_gt0));
   d.sus_g = nullptr; d.sus_prev = nullptr; d.n_sus = 0;
@@ -285,6 +287,9 @@ static int build_device_image(vs_index* idx) {
     VS_TRY(dev_alloc(idx, (G + 1) * 4, &padded, &scratch.bufs));
     if (G) hipLaunchKernelGGL(k_pad_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, (const uint32_t*)d.s_ncar, (uint32_t*)padded, G);
     VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)padded, G, d.s_carpre, &scratch.bufs));
+    VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)d.s_ncar, G, d.s_kpre, &scratch.bufs));
+    idx->h_carpre.resize(G + 1);
+    HIP_TRY(hipMemcpyAsync(idx->h_carpre.data(), d.s_carpre, (G + 1) * 8, hipMemcpyDeviceToHost, idx->stream));
   }
   std::vector<uint32_t> h_dup(G), h_fl(G);
   if (G) {
@@ -485,8 +490,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;          // profiling aids
       // one 64-slot task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
       // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time)
-      const uint64_t max_blocks = getenv("VS_FILL_BLOCKS") ? (uint64_t)atoll(getenv("VS_FILL_BLOCKS")) : (1ull << 30);
-      const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, max_blocks);
+      const uint64_t blocks = (nchunks + 3) / 4;
+      if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
       const uint32_t gt_words = fill_gt_words(idx);
       const size_t lds_bytes = fill_lds_bytes(idx) + (getenv("VS_FILL_LDS_PAD") ? (size_t)atoll(getenv("VS_FILL_LDS_PAD")) : 0);   // occupancy experiments
@@ -666,25 +671,55 @@ static int fetch_sequences(vs_result* r) {
   return VS_OK;
 }
 
-// Latency path for small type-6 batches: regions are read from mapped host memory, result buffers are
-// taken speculatively (pooled, so free after the first call), the sizes are decided on the device and
-// all four kernels are queued back to back -- one host synchronisation per call.  Returns 1 when the
-// speculative buffers were too small (the caller then takes the general path).
+// Host-side SIZES of a region's answer: the arithmetic of k_region_bounds (kernels.hip.h: region_bounds_of) on the
+// host copies of the rank structure, the ref-path tables and the arena prefix -- slot count and padded carrier count,
+// nothing else.  The latency path allocates exactly this much and launches exactly the waves it needs; the device
+// works the bounds out again for itself and refuses to write if it ever disagrees.
+static uint32_t host_rank1(const HostImage& im, uint64_t p) {
+  const uint64_t nbits = (uint64_t)im.bits.size() * 64;
+  if (p > nbits) p = nbits;
+  const uint64_t blk = p >> 9, w1 = p >> 6;
+  uint32_t r = im.blk_rank[blk];
+  for (uint64_t w = blk << 3; w < w1; ++w) r += (uint32_t)__builtin_popcountll(im.bits[w]);
+  const uint32_t rem = (uint32_t)(p & 63);
+  if (rem) r += (uint32_t)__builtin_popcountll(im.bits[w1] & ((1ULL << rem) - 1));
+  return r;
+}
+static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64_t* slots, uint64_t* arena_entries) {
+  const HostImage& im = idx->im;
+  *slots = 0; *arena_entries = 0;
+  if (x < 1 || x > im.ref_length || !(x < y)) return;
+  const uint32_t rx = host_rank1(im, x);
+  if (rx >= im.R || !((uint64_t)im.idx_pos[rx] - 1 <= y)) return;   // Index::is_empty
+  const uint64_t rf = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rx - 1;
+  const uint32_t s0 = im.rank_to_slot[rf];
+  uint32_t s1 = im.rank_to_slot[host_rank1(im, y - 1)] - 1;
+  if (s1 < s0) s1 = s0;
+  const uint32_t g0 = im.rp_cand_prefix[s0], g1 = im.rp_cand_prefix[s1];
+  *slots = g1 - g0;
+  *arena_entries = idx->h_carpre[g1] - idx->h_carpre[g0];
+}
+
+// Latency path for type-6 batches of at most 64 regions: ONE launch (k_query_small), regions in the kernel arguments,
+// one exact-size pooled slab for the whole result, completion through a mailbox in mapped host memory the caller
+// spins on.  Returns 1 if the device found the slab too small (cannot happen unless host and device disagree; the
+// caller then takes the general path).
 static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
   DevResult& d = r->d;
   d.Q = n;
-  const uint64_t capA = std::max<uint64_t>(4096, 1024 * n);
-  const uint64_t capS = std::min<uint64_t>(std::max<uint64_t>(1u << 20, 131072 * n), 32u << 20);
-  memcpy(idx->pinned + 8, regions, n * 16);
-  d.regions = idx->pinned + 8;
-  // one pooled slab for everything (two dozen pool look-ups cost microseconds at this scale)
+  uint64_t capA = 0, capS = 0, ntasks = 0;
+  for (uint64_t q = 0; q < n; ++q) {
+    uint64_t a = 0, c = 0;
+    host_region_size(idx, regions[q].x, regions[q].y, &a, &c);
+    capA += a; capS += c; ntasks += (a + kFillChunkSmall - 1) / kFillChunkSmall;
+  }
+  d.regions = nullptr;   // they travel in the kernel arguments
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
-  uint64_t* dtot = nullptr;
-  {
+  {  // one pooled slab for everything (two dozen pool look-ups cost microseconds at this scale)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_flags = take(n), o_g0 = take(n * 4), o_nvar = take(n * 8), o_ncar = take(n * 8), o_vb = take((n + 1) * 8),
-                 o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_tot = take(32), o_pos = take(capA * 8), o_ro = take(capA * 4),
+                 o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_pos = take(capA * 8), o_ro = take(capA * 4),
                  o_rl = take(capA * 4), o_ao = take(capA * 4), o_al = take(capA * 4), o_fl = take(capA * 4), o_cc = take(capA * 4),
                  o_rg = take(capA * 4), o_cbg = take(capA * 8), o_cl = take(capA * 4), o_gt = take(capA * 8),
                  o_car = take(capS * d.car_width + 16);
@@ -692,40 +727,41 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     VS_TRY(ralloc(r, off, &slab));
     d.q_flags = slab + o_flags; d.q_g0 = (uint32_t*)(slab + o_g0); d.q_nvar = (uint64_t*)(slab + o_nvar);
     d.q_ncar = (uint64_t*)(slab + o_ncar); d.var_begin = (uint64_t*)(slab + o_vb); d.car_base = (uint64_t*)(slab + o_cb);
-    d.var_count = (uint64_t*)(slab + o_vc); dtot = (uint64_t*)(slab + o_tot);
+    d.var_count = (uint64_t*)(slab + o_vc);
     d.r_pos = (uint64_t*)(slab + o_pos); d.r_ref_off = (uint32_t*)(slab + o_ro); d.r_ref_len = (uint32_t*)(slab + o_rl);
     d.r_alt_off = (uint32_t*)(slab + o_ao); d.r_alt_len = (uint32_t*)(slab + o_al); d.r_flags = (uint32_t*)(slab + o_fl);
     d.r_car_count = (uint32_t*)(slab + o_cc); d.r_region = (uint32_t*)(slab + o_rg); d.r_car_begin = (uint64_t*)(slab + o_cbg);
     d.r_class = (uint32_t*)(slab + o_cl); d.r_gt0 = (uint64_t*)(slab + o_gt); d.carriers = slab + o_car;
-    d.dyn_totals = dtot;
   }
   d.A = capA; d.S = capS;
   d.done_counter = idx->done_counter;
-  d.done_flag = idx->pinned + 6;
+  d.done_flag = idx->pinned + vs_index::kPinFlag;
   d.done_seq = ++idx->lat_seq;
-  d.host_totals = idx->pinned;
+  d.host_totals = idx->pinned + vs_index::kPinTotals;
   const auto host_t0 = std::chrono::steady_clock::now();   // no HIP events here: each one is a packet on the critical path
-  if (n <= 8) {   // a handful of regions: one single-block launch in front of the fill kernel
-    hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, capA, capS);
-  } else {
-    hipLaunchKernelGGL(k_bounds_scan_small, dim3(1), dim3(256), 0, idx->stream, idx->d, d, dtot, capA, capS);
-    hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-    hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
-  }
   {
-    const uint64_t nchunks = (capA + kFillChunkSmall - 1) / kFillChunkSmall;
-    const uint64_t blocks = std::min<uint64_t>((nchunks + 3) / 4, 4096);
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, (ntasks + 3) / 4);
     const uint32_t gt_words = fill_gt_words(idx);
     const size_t lds_bytes = fill_lds_bytes(idx);
-    if (idx->d.wpc <= 63)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunkSmall>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, 0u, gt_words);
+    const bool wide = idx->d.wpc > 63;
+    if (n <= 8) {
+      SmallRegions<8> regs;
+      memset(&regs, 0, sizeof(regs));
+      memcpy(regs.xy, regions, n * 16);
+      if (!wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_small<false, 8>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, regs, gt_words, capA, capS);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_small<true, 8>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, regs, gt_words, capA, capS);
+    } else {
+      SmallRegions<64> regs;
+      memset(&regs, 0, sizeof(regs));
+      memcpy(regs.xy, regions, n * 16);
+      if (!wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_small<false, 64>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, regs, gt_words, capA, capS);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_small<true, 64>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, regs, gt_words, capA, capS);
+    }
   }
   HIP_TRY(hipGetLastError());
   {  // spin on the mailbox (the runtime's completion wait costs several microseconds more); a kernel that never posts
      // -- a fault -- is caught by the stream synchronisation after the deadline
-    volatile uint64_t* flag = idx->pinned + 6;
+    volatile uint64_t* flag = idx->pinned + vs_index::kPinFlag;
     const auto deadline = host_t0 + std::chrono::microseconds(300);
     bool posted = false;
     while (!(posted = (*flag == d.done_seq))) {
@@ -735,11 +771,12 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     if (!posted) HIP_TRY(hipStreamSynchronize(idx->stream));
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  d.done_flag = nullptr;   // later launches with this result (none today) must not post
+  d.done_flag = nullptr;
   d.host_totals = nullptr;
-  if (idx->pinned[3]) return 1;  // overflow: nothing was written, retry with exact sizes
-  d.A = idx->pinned[0];
-  d.S = idx->pinned[1];
+  const volatile uint64_t* tot = idx->pinned + vs_index::kPinTotals;
+  if (tot[3]) return 1;  // the device wanted more than the host computed: nothing was written
+  d.A = tot[0];
+  d.S = tot[1];
   vs_timing& t = idx->timing;
   t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
   t.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();   // submit -> completion, host clock
@@ -938,7 +975,7 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
   r->idx = idx;
   idx->live_results++;
   int rc = 1;
-  if (n > 0 && n <= 512) {
+  if (n > 0 && n <= 64) {
     rc = run_small_type6(idx, regions, n, r);
     if (rc == 1) {  // speculative buffers too small
       release_bufs(idx, r->bufs);

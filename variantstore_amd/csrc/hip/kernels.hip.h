@@ -35,6 +35,9 @@
 #include <stdint.h>
 #include <type_traits>
 
+#ifndef VS_EARLY_NIB
+#define VS_EARLY_NIB 0
+#endif
 namespace vsamd {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -68,6 +71,7 @@ struct DevImage {
   // site table (one entry per branch of a ref-path node, ref-path order)
   uint32_t *s_pos, *s_ref_off, *s_ref_len, *s_alt_off, *s_alt_len, *s_vid, *s_ncar, *s_flags, *s_dup_prev, *s_class;
   uint64_t* s_carpre;  // [G+1] exclusive prefix of pad_car(s_ncar): arena offsets relative to a region's first site
+  uint64_t* s_kpre;    // [G+1] exclusive prefix of s_ncar itself: carriers of the variants a site range reports
   uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
@@ -94,15 +98,12 @@ struct DevResult {
   uint64_t* r_gt0;
   void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
   uint32_t car_width, pad3_; // bytes per carrier word in the arena: 2 or 4
-  // latency path: sizes are decided on the device ({slots, carriers, any-slow, overflow}); NULL otherwise
-  const uint64_t* dyn_totals;
-  // latency path: the last block of k_fill_carriers posts done_seq into mapped host memory (the host spins on it
-  // instead of waiting for the runtime's completion signal); NULL otherwise
+  // latency path (k_query_small): the last block posts done_seq into mapped host memory (the host spins on it instead
+  // of waiting for the runtime's completion signal) after writing the batch totals {slots, arena entries, any region
+  // took the literal dedup rule, capacities exceeded} next to it -- one writer for the flag and the data it guards
   unsigned long long* done_counter;
   volatile uint64_t* done_flag;
   uint64_t done_seq;
-  // latency path: mapped host copy of dyn_totals, written by the SAME thread that posts done_flag (totals, system
-  // fence, flag: one writer, so the flag orders the data it guards whatever the memory type of the mapping)
   volatile uint64_t* host_totals;
 };
 
@@ -216,8 +217,11 @@ __global__ void __launch_bounds__(256) k_mark_dups(DevImage im) {
 // ---------------------------------------------------------------------------
 // Region bounds: one thread per region.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void region_bounds(const DevImage& im, const DevResult& r, uint64_t q) {
-  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+struct RegionBounds {
+  uint32_t g0, g1;   // site range [g0, g1)
+  uint8_t flags;
+};
+__device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uint64_t x, uint64_t y) {
   uint8_t fl = 0;
   uint32_t g0 = 0, g1 = 0;
   if (x < 1) {
@@ -251,34 +255,20 @@ __device__ __forceinline__ void region_bounds(const DevImage& im, const DevResul
       }
     }
   }
-  r.q_flags[q] = fl;
-  r.q_g0[q] = g0;
-  r.q_nvar[q] = g1 - g0;
-  r.q_ncar[q] = im.s_carpre[g1] - im.s_carpre[g0];
+  return RegionBounds{g0, g1, fl};
+}
+
+__device__ __forceinline__ void region_bounds(const DevImage& im, const DevResult& r, uint64_t q) {
+  const RegionBounds b = region_bounds_of(im, r.regions[2 * q], r.regions[2 * q + 1]);
+  r.q_flags[q] = b.flags;
+  r.q_g0[q] = b.g0;
+  r.q_nvar[q] = b.g1 - b.g0;
+  r.q_ncar[q] = im.s_carpre[b.g1] - im.s_carpre[b.g0];
 }
 
 __global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < r.Q) region_bounds(im, r, q);
-}
-
-// Small batches (latency path): bounds of every region and both offset scans in ONE single-block
-// launch.  totals = {slots, carriers, any region needing the literal dedup rule}.
-__global__ void __launch_bounds__(256) k_bounds_scan_small(DevImage im, DevResult r, uint64_t* totals,
-                                                           uint64_t cap_slots, uint64_t cap_carriers) {
-  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t a = 0, c = 0, slow = 0;
-    for (uint64_t q = 0; q < r.Q; ++q) {
-      r.var_begin[q] = a; r.car_base[q] = c;
-      a += r.q_nvar[q]; c += r.q_ncar[q];
-      slow |= (r.q_flags[q] & kRegionSlow) ? 1 : 0;
-    }
-    r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
-    const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
-    totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -451,7 +441,6 @@ __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult&
 __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
-  if (r.dyn_totals && r.dyn_totals[3]) return;  // speculative buffers too small: the host retries
   emit_region(im, r, q, threadIdx.x & 63);
 }
 
@@ -487,34 +476,7 @@ __device__ __forceinline__ void dedup_region(const DevImage& im, const DevResult
 __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
-  if (r.dyn_totals && r.dyn_totals[3]) return;
   dedup_region(im, r, q);
-}
-
-// A handful of regions (single-region latency): bounds, offsets, headers and the dedup rule in ONE single-block
-// launch -- three kernel launches fewer in front of k_fill_carriers.  Writes of one phase are read by other waves of
-// the same workgroup in the next; __syncthreads() orders them (workgroup scope, one CU).
-__global__ void __launch_bounds__(256) k_small_front(DevImage im, DevResult r, uint64_t* totals,
-                                                     uint64_t cap_slots, uint64_t cap_carriers) {
-  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x) region_bounds(im, r, q);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t a = 0, c = 0, slow = 0;
-    for (uint64_t q = 0; q < r.Q; ++q) {
-      r.var_begin[q] = a; r.car_base[q] = c;
-      a += r.q_nvar[q]; c += r.q_ncar[q];
-      slow |= (r.q_flags[q] & kRegionSlow) ? 1 : 0;
-    }
-    r.var_begin[r.Q] = a; r.car_base[r.Q] = c;
-    const uint64_t over = (a > cap_slots || c > cap_carriers) ? 1 : 0;
-    totals[0] = a; totals[1] = c; totals[2] = slow; totals[3] = over;
-  }
-  __syncthreads();
-  if (totals[3]) return;
-  for (uint64_t q = threadIdx.x >> 6; q < r.Q; q += blockDim.x >> 6) emit_region(im, r, q, threadIdx.x & 63);
-  __syncthreads();
-  for (uint64_t q = threadIdx.x; q < r.Q; q += blockDim.x)
-    if (r.q_flags[q] & kRegionSlow) dedup_region(im, r, q);
 }
 
 // ---------------------------------------------------------------------------
@@ -621,31 +583,379 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
   }
 }
 
-// `ablate` is a profiling aid (bit0: skip sparse, bit1: skip medium, bit2: skip dense); 0 in production.
+// Expansion of one task: the lanes hold (cnt, cls, gt0, cb) of up to 64 variant slots (cnt == 0: nothing to do for the
+// lane) and the wave writes their carrier words into the arena.  Shared by k_fill_carriers (slots whose headers an
+// earlier kernel wrote) and k_query_small (single-launch latency path, slots read straight from the site table).
+// `lds_wave` is the wave's LDS block (slice_lds_words / gt_words + kRingWords words).
+// `ablate` is a profiling aid (bit0: skip listed/sparse, bit1: skip medium, bit2: skip dense); 0 in production.
 // WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
 // fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
 // one wave of occupancy -- is compiled out.
-template <bool WIDE, uint32_t CH>
-__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint64_t A = r.dyn_totals ? (r.dyn_totals[3] ? 0 : r.dyn_totals[0]) : r.A;
-  const uint64_t nchunks = (A + CH - 1) / CH;
+template <bool WIDE>
+__device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
+                                            uint64_t gt0, uint64_t cb, uint32_t ablate, uint32_t gt_words) {
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
   // carrier word in the arena: 16 bits when every sample id fits 13 bits (the non-WIDE instantiation), else 32
   using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
   constexpr uint32_t kGtShift = WIDE ? 29 : 13;
-  CT* __restrict__ carriers = reinterpret_cast<CT*>(r.carriers);
+  CT* __restrict__ carriers = reinterpret_cast<CT*>(arena);
   uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
   asm volatile("" : "+s"(m_lo), "+s"(m_hi));
+  const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
+  if (explicit_ids && cnt > kSparseMax) {
+    // long lists are rare in this mode: a plain copy, lane per variant (short ones go lane per carrier below)
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint64_t c = gt0 + k;
+      const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
+      carriers[cb + k] = (CT)(im.car_sid[c] | (nib << kGtShift));
+    }
+  }
+
+  const bool lists = !WIDE && !explicit_ids;
+  const uint32_t list_max = lists ? im.list_max : kSparseMax;
+
+  // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
+  //                  list phase runs in the shadow of that memory latency ----------------
+  uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
+  uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
+  uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
+  if (dmask) {
+    const int t0 = __builtin_ctzll(dmask);
+    const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
+    const uint64_t gt0_0 = wave_bcast64(gt0, t0);
+    if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
+    if (!lists || VS_EARLY_NIB) {
+      const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
+      const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+    }
+    const uint64_t d1 = dmask & (dmask - 1);
+    if (d1) {
+      const uint32_t cls_1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d1));
+      if (lane < wpc) word_n1 = class_rows[(uint64_t)cls_1 * wpc + lane];
+    }
+  }
+
+  // Cohorts of at most 4032 samples with class rows: every variant of at most list_max carriers is expanded from its
+  // class's decoded 16-bit id list, LANE PER GROUP of 8 carriers (= one 16-byte arena group; every variant's arena
+  // range and every list start on a group boundary and own their padding).  The groups of all such variants of the
+  // task form one list: a DPP prefix sum over the group counts gives every variant its slice, a lane takes entry e,
+  // finds its variant by bisection over the 64 offsets (LDS), loads the 8 ids (one 16-byte load) and the 32
+  // genotype bits that go with them (one 8-byte load of the nibble pool), and stores one finished 16-byte group.
+  // No bit row is read, nothing is staged, no lane idles: a rare variant is one group, a 640-carrier one is 80.
+  // Two entries per lane and pass, so that four independent loads are in flight per lane.
+  if (lists) {
+    uint32_t* s_off = lds_wave;   // aliases the genotype staging area
+    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint32_t* s_idb = s_off + 64;
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list16);
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      uint4* __restrict__ arena_groups = reinterpret_cast<uint4*>(arena);
+      for (uint32_t e0 = lane; e0 < total; e0 += 128) {
+        const uint32_t e1 = e0 + 64;
+        const bool two = e1 < total;
+        uint32_t L0 = 0, L1 = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) {
+          if (s_off[L0 + step] <= e0) L0 += step;
+          if (s_off[L1 + step] <= e1) L1 += step;
+        }
+        const uint32_t k0 = e0 - s_off[L0], k1 = e1 - s_off[L1];   // group within its variant
+        const uint64_t g0 = s_gt0[L0] + (uint64_t)k0 * kCarAlign;   // its first genotype nibble: 32 bits from bit 4g
+        const uint64_t g1 = s_gt0[L1] + (uint64_t)k1 * kCarAlign;
+        const uint4 iw0 = list_groups[(uint64_t)s_idb[L0] + k0];
+        uint2 nw0, nw1 = {0, 0};
+        __builtin_memcpy(&nw0, gt32 + (g0 >> 3), 8);
+        uint4 iw1 = {0, 0, 0, 0};
+        if (two) {
+          iw1 = list_groups[(uint64_t)s_idb[L1] + k1];
+          __builtin_memcpy(&nw1, gt32 + (g1 >> 3), 8);
+        }
+        const uint64_t dst0 = (s_cb[L0] >> 3) + k0, dst1 = (s_cb[L1] >> 3) + k1;   // arena ranges start on group boundaries
+        {
+          const uint32_t n = __builtin_amdgcn_alignbit(nw0.y, nw0.x, ((uint32_t)g0 & 7u) * 4);
+          uint4 v;
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw0.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
+          arena_groups[dst0] = v;
+        }
+        if (two) {
+          const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
+          uint4 v;
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw1.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
+          arena_groups[dst1] = v;
+        }
+      }
+    }
+  } else {
+    // ---------------- explicit-id cohorts and cohorts above 4032 samples: sparse variants lane per CARRIER ----------------
+    // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
+    // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
+    // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
+    // the class's decoded id list (built once at load), genotype nibble from the pool.
+    uint32_t* s_off = lds_wave;   // aliases the genotype staging area
+    const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
+    const uint32_t c = sp ? cnt : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      // per-variant parameters go through LDS (not lane shuffles: in the last pass the owning lane may be idle)
+      uint32_t* s_idb = s_off + 64;
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_idb[lane] = (sp && !explicit_ids) ? im.cls_list_begin[cls] : 0u;
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t L = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_off[L + step] <= e) L += step;
+        const uint32_t k = e - s_off[L];
+        const uint32_t idb_L = s_idb[L];
+        const uint64_t gt0_L = s_gt0[L];
+        const uint64_t cb_L = s_cb[L];
+        const uint64_t g = gt0_L + k;
+        const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
+        const uint32_t id = explicit_ids ? im.car_sid[g] : im.cls_list_ids[idb_L + k];
+        carriers[cb_L + k] = (CT)(id | (nib << kGtShift));
+      }
+    }
+  }
+
+  if (dmask == 0) return;
+  if (lists && !VS_EARLY_NIB) {   // the first dense variant's nibbles (8 registers) are requested after the list phase: its peak register
+                 // demand decides how many waves a SIMD holds
+    const int t0 = __builtin_ctzll(dmask);
+    const uint32_t cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
+    const uint64_t gt0_0 = wave_bcast64(gt0, t0);
+    const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;
+    const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;
+    if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+    if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+  }
+  // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
+  // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
+  // cohorts, the output ring.
+  uint8_t* gt_lds = reinterpret_cast<uint8_t*>(lds_wave);
+  uint32_t* ids_lds = lds_wave + kMidIdsAt;
+  uint32_t* ring = lds_wave + gt_words;
+  while (dmask) {
+    const int t = __builtin_ctzll(dmask);
+    dmask &= dmask - 1;
+    const uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
+    const uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
+    const uint64_t gt0_t = wave_bcast64(gt0, t);
+    const uint64_t cb_t = wave_bcast64(cb, t);
+    const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
+    const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
+    const bool staged = (uint64_t)nshift + cnt_t <= gt_words * 4;     // fits the staging block
+    // stage this variant's genotypes (fetched during the previous variant)
+    if (WIDE) {   // one byte per carrier
+      stage_unpacked(gt_lds + lane * 32, nq0);
+      if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
+    } else {      // raw nibbles, behind the row staging area
+      uint8_t* nib_st = gt_lds + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
+      *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
+      if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
+    }
+    // request the next variant's nibbles and the row of the one after it before expanding this one (rows are the
+    // random 320-byte reads of this kernel: two of them stay in flight per wave)
+    if (WIDE) { nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0}; }   // (the slice path never reads nibbles it did not load)
+    word_n2 = 0;
+    if (dmask) {
+      const int tn = __builtin_ctzll(dmask);
+      const uint64_t gt0_n = wave_bcast64(gt0, tn);
+      const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
+      const uint64_t bn = (gt0_n >> 1) & ~15ULL;
+      const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
+      const uint64_t d2 = dmask & (dmask - 1);
+      if (d2) {
+        const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
+        if (lane < wpc) word_n2 = class_rows[(uint64_t)cls_2 * wpc + lane];
+      }
+    }
+    const uint64_t word_this = word_cur;
+    word_cur = word_n1; word_n1 = word_n2;   // the queue advances here: every `continue` below leaves it consistent
+    if constexpr (WIDE) {
+      if (!staged || wpc > 64) {
+        // rows wider than one wave or more than 4096 staged genotypes: generic path
+        expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, carriers + cb_t, lane);
+        continue;
+      }
+    }
+    uint64_t mine = word_this;
+    if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+    if ((ablate & 2) && cnt_t <= kMidMax) continue;
+    if ((ablate & 4) && cnt_t > kMidMax) continue;
+    if constexpr (!WIDE) {
+      // ---- slice path: the row is expanded in TWO rounds of 64 x sb bits (sb = ceil(wpc / 2) <= 32): in a round
+      //      every lane owns sb consecutive bits, peels them into a 16-bit id list in LDS at its prefix-sum position,
+      //      then the complete 16-byte groups of the list leave in 128-byte-aligned blocks, one store per lane,
+      //      genotypes merged from the raw nibble stream on the way out; the (< 8) ids of the last, incomplete group
+      //      move to the front of the list and the second round continues behind them.  The list therefore holds
+      //      half a row at most -- the per-wave LDS block is what limits this kernel's occupancy. ----
+      const uint8_t* nib_lds = gt_lds;
+      uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
+      uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
+      rowq[lane] = mine;
+      if (lane == 0) rowq[64] = 0;
+      const uint32_t sb = (wpc + 1) >> 1;                                       // bits per lane and round
+      const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1u;
+      const uint32_t* rowd = reinterpret_cast<const uint32_t*>(rowq);
+      const uint32_t bp0 = sb * lane, bp1 = bp0 + 64 * sb;                      // first bit of the lane's slice per round
+      uint32_t bits0 = __builtin_amdgcn_alignbit(rowd[(bp0 >> 5) + 1], rowd[bp0 >> 5], bp0 & 31u) & smask;
+      uint32_t bits1 = __builtin_amdgcn_alignbit(rowd[(bp1 >> 5) + 1], rowd[bp1 >> 5], bp1 & 31u) & smask;
+      const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
+      uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+      // nibble index = list index + D; the staging is biased by 32 nibbles
+      uint32_t D = nshift + 32 - a1k;
+      uint32_t pos = a1k;                                 // list index of the round's first carrier
+      uint32_t done8 = a1k;                               // groups below this list index have been written
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        uint32_t bits = round ? bits1 : bits0;
+        const uint32_t idb = round ? bp1 : bp0;
+        const uint32_t pc = __popc(bits);
+        uint32_t incl = wave_inclusive_scan(pc);
+        asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
+        const uint32_t end = pos + __builtin_amdgcn_readlane(incl, 63);
+        uint32_t j = pos + incl - pc;                     // list index of this lane's first carrier of the round
+        while (bits) {
+          ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
+          bits &= bits - 1;
+        }
+        // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32 consecutive
+        // bits of the stream.  Round 0 writes complete groups only, round 1 everything (the range owns its padding).
+        const uint32_t flush = round ? ((end + 7u) & ~7u) : (end & ~7u);
+        for (uint32_t q8 = done8 + lane * 8; q8 < flush; q8 += 512) {
+          const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
+          const uint32_t n0 = q8 + D;
+          const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
+          const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
+          uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
+                     // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
+          *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+        }
+        if (round == 0) {
+          // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
+          const uint32_t o = flush & ~(kListWindow - 1);
+          if (o) {
+            if (lane == 0) *reinterpret_cast<uint4*>(ids16 + (flush - o)) = *reinterpret_cast<const uint4*>(ids16 + flush);
+            g1k += o;
+            D += o;
+          }
+          pos = end - o;
+          done8 = flush - o;
+        }
+      }
+    } else if (cnt_t <= kMidMax) {
+      const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
+      uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
+      const uint32_t endpos = a0 + cnt_t;
+      // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
+      const uint32_t pc = __popcll(mine);
+      uint32_t incl = pc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+      }
+      uint32_t k = incl - pc;
+      const uint32_t idbase = lane * 64;
+      while (mine) {
+        const uint32_t bit = __builtin_ctzll(mine);
+        mine &= mine - 1;
+        ids_lds[k] = idbase + bit;
+        ++k;
+      }
+      // copy-out in 256-byte-aligned blocks of the arena
+      for (uint32_t pos = lane; pos < endpos; pos += 64)
+        if (pos >= a0) gbase[pos] = ids_lds[pos - a0] | ((uint32_t)gt_lds[nshift + pos - a0] << 29);
+    } else {
+      // ---- dense: bit per lane, two row words per step.  The lanes whose bit is set (exec mask =
+      //      the word itself) rank themselves with v_mbcnt and drop id|gt into a 512-entry LDS ring
+      //      indexed by arena position; the ring leaves 1 KiB at a time as one 16-byte store per lane
+      //      on a 1 KiB-aligned arena block (aligned full stores run at twice the rate of partial ones,
+      //      tools/microbench/write_bw.hip) ----
+      const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
+      uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+      const uint32_t end1k = a1k + cnt_t;
+      const uint32_t gtoff = nshift - a1k;                // staged genotype index = arena position + gtoff
+      uint32_t bpos = a1k;                                // arena position of the step's first carrier
+      uint32_t nfl = 0;                                   // 256-entry blocks already written
+      for (uint32_t w = 0; w < wpc; w += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint64_t word = (w + i < wpc) ? wave_bcast64(mine, w + i) : 0ULL;
+          if (__builtin_amdgcn_inverse_ballot_w64(word)) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, bpos));
+            ring[pos & 511u] = ((w + i) * 64 + lane) | ((uint32_t)gt_lds[pos + gtoff] << 29);
+          }
+          bpos += __popcll(word);
+        }
+        while (nfl < (bpos >> 8)) {                        // a complete 256-entry block is ready
+          const uint32_t p4 = nfl * 256 + lane * 4;
+          const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+          if (p4 >= a1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+          else if (p4 + 4 > a1k) {                         // the variant starts inside this lane's quad
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (p4 + j >= a1k) g1k[p4 + j] = e[j];
+          }
+          ++nfl;
+        }
+      }
+      for (uint32_t p4 = nfl * 256 + lane * 4; p4 < end1k; p4 += 256) {   // tail (at most 2 passes)
+        const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+        if (p4 >= a1k && p4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+        else {
+          const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (p4 + j >= a1k && p4 + j < end1k) g1k[p4 + j] = e[j];
+        }
+      }
+    }
+  }
+}
+
+template <bool WIDE, uint32_t CH>
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t A = r.A;
+  const uint64_t nchunks = (A + CH - 1) / CH;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
-
-  for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const uint64_t a = chunk * CH + lane;
+  // one task per wave (the launch covers every task): with no loop around it the compiler has no lane-dependent
+  // invariants to keep alive, and the hardware's block scheduler balances the tenfold spread of task costs
+  if (wave < nchunks) {
+    const uint64_t a = wave * CH + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
     if (a < A && lane < CH) {
@@ -654,345 +964,117 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = r.r_gt0[a];
       cb = r.r_car_begin[a];
     }
-    const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
-    if (explicit_ids && cnt > kSparseMax) {
-      // long lists are rare in this mode: a plain copy, lane per variant (short ones go lane per carrier below)
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const uint64_t c = gt0 + k;
-        const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
-        carriers[cb + k] = (CT)(im.car_sid[c] | (nib << kGtShift));
-      }
+    expand_task<WIDE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Latency path: a batch of at most 64 regions in ONE launch.  Every wave works the region bounds out for itself (lane
+// q takes region q: the same dozen loads in every wave, L2 hits after the first), a wave prefix sum lays the slot,
+// arena and task offsets out, and the wave then takes 8-slot tasks straight from the site table: it writes their
+// variant headers and expands their carriers (expand_task) -- no header kernel, no kernel-to-kernel dependency, no
+// host round trip.  The regions travel in the kernel arguments.  The result buffers were sized on the host from the
+// same arithmetic (engine.hip: host_region_size); should the device ever need more it writes nothing and says so.
+// The last block to finish applies the literal "already seen" rule to the regions that need it and posts the
+// completion mailbox.
+// ---------------------------------------------------------------------------
+template <int NMAX>
+struct SmallRegions { uint64_t xy[2 * NMAX]; };
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v, uint32_t lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(v, d, 64);
+    if (lane >= (uint32_t)d) v += t;
+  }
+  return v;
+}
+
+template <bool WIDE, int NMAX>
+__global__ void __launch_bounds__(256) k_query_small(DevImage im, DevResult r, SmallRegions<NMAX> regs, uint32_t gt_words,
+                                                     uint64_t cap_slots, uint64_t cap_carriers) {
+  constexpr uint32_t CH = kFillChunkSmall;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t n = (uint32_t)r.Q;
+  // ---- bounds of region `lane`, offsets of all regions ----
+  RegionBounds b{0, 0, 0};
+  uint64_t pre0 = 0, npad = 0, nkept = 0;
+  if (lane < n) {
+    b = region_bounds_of(im, regs.xy[2 * lane], regs.xy[2 * lane + 1]);
+    pre0 = im.s_carpre[b.g0];
+    npad = im.s_carpre[b.g1] - pre0;
+    nkept = im.s_kpre[b.g1] - im.s_kpre[b.g0];
+  }
+  const uint32_t nv = b.g1 - b.g0, ntask = (nv + CH - 1) / CH;
+  const uint64_t vend = wave_inclusive_scan64(nv, lane), cend = wave_inclusive_scan64(npad, lane);
+  const uint32_t tend = wave_inclusive_scan(ntask);
+  const uint64_t A = wave_bcast64(vend, 63), S = wave_bcast64(cend, 63);
+  const uint32_t T = __builtin_amdgcn_readlane(tend, 63);
+  const bool any_slow = __ballot(b.flags & kRegionSlow) != 0;
+  const bool over = A > cap_slots || S > cap_carriers;
+  if (wave == 0 && !over) {   // the per-region arrays of the result
+    if (lane < n) {
+      r.q_flags[lane] = b.flags; r.q_g0[lane] = b.g0; r.q_nvar[lane] = nv;
+      r.var_begin[lane] = vend - nv; r.car_base[lane] = cend - npad;
+      if (!(b.flags & kRegionSlow)) { r.var_count[lane] = nv; r.q_ncar[lane] = nkept; }
     }
-
-    const bool lists = !WIDE && !explicit_ids;
-    const uint32_t list_max = lists ? im.list_max : kSparseMax;
-
-    // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
-    //                  list phase runs in the shadow of that memory latency ----------------
-    uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
-    uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
-    uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
-    if (dmask) {
-      const int t0 = __builtin_ctzll(dmask);
-      const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
-      const uint64_t gt0_0 = wave_bcast64(gt0, t0);
-      if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
-      const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
-      const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
-      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
-      const uint64_t d1 = dmask & (dmask - 1);
-      if (d1) {
-        const uint32_t cls_1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d1));
-        if (lane < wpc) word_n1 = class_rows[(uint64_t)cls_1 * wpc + lane];
+    if (lane == 0) { r.var_begin[n] = A; r.car_base[n] = S; }
+  }
+  // ---- tasks: 8 consecutive sites of one region ----
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  if (!over) {
+    for (uint32_t c = wave; c < T; c += nwaves) {
+      // the region of task c: the last one whose first task is <= c (regions without tasks share their successor's offset)
+      const uint32_t q = (uint32_t)__popcll(__ballot(lane < n && tend - ntask <= c)) - 1u;
+      const uint32_t g0_q = __builtin_amdgcn_readlane(b.g0, q), nv_q = __builtin_amdgcn_readlane(nv, q);
+      const uint32_t t0_q = __builtin_amdgcn_readlane(tend - ntask, q);
+      const uint64_t a0_q = wave_bcast64(vend - nv, q), cb_q = wave_bcast64(cend - npad, q) - wave_bcast64(pre0, q);
+      const uint32_t j = (c - t0_q) * CH + lane;
+      uint32_t cnt = 0, cls = 0;
+      uint64_t gt0 = 0, cb = 0;
+      if (lane < CH && j < nv_q) {
+        const uint32_t g = g0_q + j;
+        const uint64_t a = a0_q + j;
+        const uint32_t fl = im.s_flags[g];
+        cnt = im.s_ncar[g];
+        cls = im.s_class[g];
+        gt0 = im.s_gt0[g];
+        cb = cb_q + im.s_carpre[g];
+        // the variant header (building std::vector<Variant>, query.h:736-771)
+        r.r_pos[a] = im.s_pos[g];
+        r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
+        r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
+        r.r_flags[a] = (fl & kSiteAlwaysDrop) ? kVarDropped : 0u;
+        r.r_car_begin[a] = cb;
+        r.r_car_count[a] = cnt;
+        r.r_region[a] = q;
+        r.r_class[a] = cls;
+        r.r_gt0[a] = gt0;
       }
-    }
-
-    // Cohorts of at most 4032 samples with class rows: every variant of at most list_max carriers is expanded from its
-    // class's decoded 16-bit id list, LANE PER GROUP of 8 carriers (= one 16-byte arena group; every variant's arena
-    // range and every list start on a group boundary and own their padding).  The groups of all such variants of the
-    // task form one list: a DPP prefix sum over the group counts gives every variant its slice, a lane takes entry e,
-    // finds its variant by bisection over the 64 offsets (LDS), loads the 8 ids (one 16-byte load) and the 32
-    // genotype bits that go with them (one 8-byte load of the nibble pool), and stores one finished 16-byte group.
-    // No bit row is read, nothing is staged, no lane idles: a rare variant is one group, a 640-carrier one is 80.
-    // Two entries per lane and pass, so that four independent loads are in flight per lane.
-    if (lists) {
-      uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
-      const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
-      const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
-      const uint32_t incl = wave_inclusive_scan(c);
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      if (total) {
-        uint32_t* s_idb = s_off + 64;
-        uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
-        uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
-        s_off[lane] = incl - c;
-        s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
-        s_gt0[lane] = gt0;
-        s_cb[lane] = cb;
-        const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list16);
-        const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
-        uint4* __restrict__ arena_groups = reinterpret_cast<uint4*>(r.carriers);
-        for (uint32_t e0 = lane; e0 < total; e0 += 128) {
-          const uint32_t e1 = e0 + 64;
-          const bool two = e1 < total;
-          uint32_t L0 = 0, L1 = 0;
-#pragma unroll
-          for (uint32_t step = 32; step; step >>= 1) {
-            if (s_off[L0 + step] <= e0) L0 += step;
-            if (s_off[L1 + step] <= e1) L1 += step;
-          }
-          const uint32_t k0 = e0 - s_off[L0], k1 = e1 - s_off[L1];   // group within its variant
-          const uint64_t g0 = s_gt0[L0] + (uint64_t)k0 * kCarAlign;   // its first genotype nibble: 32 bits from bit 4g
-          const uint64_t g1 = s_gt0[L1] + (uint64_t)k1 * kCarAlign;
-          const uint4 iw0 = list_groups[(uint64_t)s_idb[L0] + k0];
-          uint2 nw0, nw1 = {0, 0};
-          __builtin_memcpy(&nw0, gt32 + (g0 >> 3), 8);
-          uint4 iw1 = {0, 0, 0, 0};
-          if (two) {
-            iw1 = list_groups[(uint64_t)s_idb[L1] + k1];
-            __builtin_memcpy(&nw1, gt32 + (g1 >> 3), 8);
-          }
-          const uint64_t dst0 = (s_cb[L0] >> 3) + k0, dst1 = (s_cb[L1] >> 3) + k1;   // arena ranges start on group boundaries
-          {
-            const uint32_t n = __builtin_amdgcn_alignbit(nw0.y, nw0.x, ((uint32_t)g0 & 7u) * 4);
-            uint4 v;
-            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw0.x));
-            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
-            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
-            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
-            arena_groups[dst0] = v;
-          }
-          if (two) {
-            const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
-            uint4 v;
-            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw1.x));
-            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
-            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
-            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
-            arena_groups[dst1] = v;
-          }
-        }
-      }
-    } else {
-      // ---------------- explicit-id cohorts and cohorts above 4032 samples: sparse variants lane per CARRIER ----------------
-      // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
-      // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
-      // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
-      // the class's decoded id list (built once at load), genotype nibble from the pool.
-      uint32_t* s_off = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];   // aliases the genotype staging area
-      const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
-      const uint32_t c = sp ? cnt : 0u;
-      const uint32_t incl = wave_inclusive_scan(c);
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      if (total) {
-        // per-variant parameters go through LDS (not lane shuffles: in the last pass the owning lane may be idle)
-        uint32_t* s_idb = s_off + 64;
-        uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
-        uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
-        s_off[lane] = incl - c;
-        s_idb[lane] = (sp && !explicit_ids) ? im.cls_list_begin[cls] : 0u;
-        s_gt0[lane] = gt0;
-        s_cb[lane] = cb;
-        for (uint32_t e = lane; e < total; e += 64) {
-          uint32_t L = 0;
-#pragma unroll
-          for (uint32_t step = 32; step; step >>= 1)
-            if (s_off[L + step] <= e) L += step;
-          const uint32_t k = e - s_off[L];
-          const uint32_t idb_L = s_idb[L];
-          const uint64_t gt0_L = s_gt0[L];
-          const uint64_t cb_L = s_cb[L];
-          const uint64_t g = gt0_L + k;
-          const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
-          const uint32_t id = explicit_ids ? im.car_sid[g] : im.cls_list_ids[idb_L + k];
-          carriers[cb_L + k] = (CT)(id | (nib << kGtShift));
-        }
-      }
-    }
-
-    if (dmask == 0) continue;
-    // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
-    // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
-    // cohorts, the output ring.
-    uint8_t* gt_lds = reinterpret_cast<uint8_t*>(&lds_blk[(threadIdx.x >> 6) * lds_words_per_wave]);
-    uint32_t* ids_lds = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + kMidIdsAt];
-    uint32_t* ring = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave + gt_words];
-    while (dmask) {
-      const int t = __builtin_ctzll(dmask);
-      dmask &= dmask - 1;
-      const uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
-      const uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
-      const uint64_t gt0_t = wave_bcast64(gt0, t);
-      const uint64_t cb_t = wave_bcast64(cb, t);
-      const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
-      const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
-      const bool staged = (uint64_t)nshift + cnt_t <= gt_words * 4;     // fits the staging block
-      // stage this variant's genotypes (fetched during the previous variant)
-      if (WIDE) {   // one byte per carrier
-        stage_unpacked(gt_lds + lane * 32, nq0);
-        if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
-      } else {      // raw nibbles, behind the row staging area
-        uint8_t* nib_st = gt_lds + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
-        *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
-        if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
-      }
-      // request the next variant's nibbles and the row of the one after it before expanding this one (rows are the
-      // random 320-byte reads of this kernel: two of them stay in flight per wave)
-      if (WIDE) { nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0}; }   // (the slice path never reads nibbles it did not load)
-      word_n2 = 0;
-      if (dmask) {
-        const int tn = __builtin_ctzll(dmask);
-        const uint64_t gt0_n = wave_bcast64(gt0, tn);
-        const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
-        const uint64_t bn = (gt0_n >> 1) & ~15ULL;
-        const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
-        if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
-        if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
-        const uint64_t d2 = dmask & (dmask - 1);
-        if (d2) {
-          const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
-          if (lane < wpc) word_n2 = class_rows[(uint64_t)cls_2 * wpc + lane];
-        }
-      }
-      const uint64_t word_this = word_cur;
-      word_cur = word_n1; word_n1 = word_n2;   // the queue advances here: every `continue` below leaves it consistent
-      if constexpr (WIDE) {
-        if (!staged || wpc > 64) {
-          // rows wider than one wave or more than 4096 staged genotypes: generic path
-          expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, carriers + cb_t, lane);
-          continue;
-        }
-      }
-      uint64_t mine = word_this;
-      if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
-      if ((ablate & 2) && cnt_t <= kMidMax) continue;
-      if ((ablate & 4) && cnt_t > kMidMax) continue;
-      if constexpr (!WIDE) {
-        // ---- slice path: the row is expanded in TWO rounds of 64 x sb bits (sb = ceil(wpc / 2) <= 32): in a round
-        //      every lane owns sb consecutive bits, peels them into a 16-bit id list in LDS at its prefix-sum position,
-        //      then the complete 16-byte groups of the list leave in 128-byte-aligned blocks, one store per lane,
-        //      genotypes merged from the raw nibble stream on the way out; the (< 8) ids of the last, incomplete group
-        //      move to the front of the list and the second round continues behind them.  The list therefore holds
-        //      half a row at most -- the per-wave LDS block is what limits this kernel's occupancy. ----
-        const uint8_t* nib_lds = gt_lds;
-        uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
-        uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
-        rowq[lane] = mine;
-        if (lane == 0) rowq[64] = 0;
-        const uint32_t sb = (wpc + 1) >> 1;                                       // bits per lane and round
-        const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1u;
-        const uint32_t* rowd = reinterpret_cast<const uint32_t*>(rowq);
-        const uint32_t bp0 = sb * lane, bp1 = bp0 + 64 * sb;                      // first bit of the lane's slice per round
-        uint32_t bits0 = __builtin_amdgcn_alignbit(rowd[(bp0 >> 5) + 1], rowd[bp0 >> 5], bp0 & 31u) & smask;
-        uint32_t bits1 = __builtin_amdgcn_alignbit(rowd[(bp1 >> 5) + 1], rowd[bp1 >> 5], bp1 & 31u) & smask;
-        const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
-        uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
-        // nibble index = list index + D; the staging is biased by 32 nibbles
-        uint32_t D = nshift + 32 - a1k;
-        uint32_t pos = a1k;                                 // list index of the round's first carrier
-        uint32_t done8 = a1k;                               // groups below this list index have been written
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
-          uint32_t bits = round ? bits1 : bits0;
-          const uint32_t idb = round ? bp1 : bp0;
-          const uint32_t pc = __popc(bits);
-          uint32_t incl = wave_inclusive_scan(pc);
-          asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
-          const uint32_t end = pos + __builtin_amdgcn_readlane(incl, 63);
-          uint32_t j = pos + incl - pc;                     // list index of this lane's first carrier of the round
-          while (bits) {
-            ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
-            bits &= bits - 1;
-          }
-          // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32 consecutive
-          // bits of the stream.  Round 0 writes complete groups only, round 1 everything (the range owns its padding).
-          const uint32_t flush = round ? ((end + 7u) & ~7u) : (end & ~7u);
-          for (uint32_t q8 = done8 + lane * 8; q8 < flush; q8 += 512) {
-            const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
-            const uint32_t n0 = q8 + D;
-            const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
-            const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
-            uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
-                       // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
-            v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
-            v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
-            v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
-            v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
-            *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
-          }
-          if (round == 0) {
-            // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
-            const uint32_t o = flush & ~(kListWindow - 1);
-            if (o) {
-              if (lane == 0) *reinterpret_cast<uint4*>(ids16 + (flush - o)) = *reinterpret_cast<const uint4*>(ids16 + flush);
-              g1k += o;
-              D += o;
-            }
-            pos = end - o;
-            done8 = flush - o;
-          }
-        }
-      } else if (cnt_t <= kMidMax) {
-        const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
-        uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
-        const uint32_t endpos = a0 + cnt_t;
-        // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
-        const uint32_t pc = __popcll(mine);
-        uint32_t incl = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t up = __shfl_up(incl, d, 64);
-          if (lane >= (uint32_t)d) incl += up;
-        }
-        uint32_t k = incl - pc;
-        const uint32_t idbase = lane * 64;
-        while (mine) {
-          const uint32_t bit = __builtin_ctzll(mine);
-          mine &= mine - 1;
-          ids_lds[k] = idbase + bit;
-          ++k;
-        }
-        // copy-out in 256-byte-aligned blocks of the arena
-        for (uint32_t pos = lane; pos < endpos; pos += 64)
-          if (pos >= a0) gbase[pos] = ids_lds[pos - a0] | ((uint32_t)gt_lds[nshift + pos - a0] << 29);
-      } else {
-        // ---- dense: bit per lane, two row words per step.  The lanes whose bit is set (exec mask =
-        //      the word itself) rank themselves with v_mbcnt and drop id|gt into a 512-entry LDS ring
-        //      indexed by arena position; the ring leaves 1 KiB at a time as one 16-byte store per lane
-        //      on a 1 KiB-aligned arena block (aligned full stores run at twice the rate of partial ones,
-        //      tools/microbench/write_bw.hip) ----
-        const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
-        uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
-        const uint32_t end1k = a1k + cnt_t;
-        const uint32_t gtoff = nshift - a1k;                // staged genotype index = arena position + gtoff
-        uint32_t bpos = a1k;                                // arena position of the step's first carrier
-        uint32_t nfl = 0;                                   // 256-entry blocks already written
-        for (uint32_t w = 0; w < wpc; w += 2) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const uint64_t word = (w + i < wpc) ? wave_bcast64(mine, w + i) : 0ULL;
-            if (__builtin_amdgcn_inverse_ballot_w64(word)) {
-              const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, bpos));
-              ring[pos & 511u] = ((w + i) * 64 + lane) | ((uint32_t)gt_lds[pos + gtoff] << 29);
-            }
-            bpos += __popcll(word);
-          }
-          while (nfl < (bpos >> 8)) {                        // a complete 256-entry block is ready
-            const uint32_t p4 = nfl * 256 + lane * 4;
-            const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
-            if (p4 >= a1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
-            else if (p4 + 4 > a1k) {                         // the variant starts inside this lane's quad
-              const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) if (p4 + j >= a1k) g1k[p4 + j] = e[j];
-            }
-            ++nfl;
-          }
-        }
-        for (uint32_t p4 = nfl * 256 + lane * 4; p4 < end1k; p4 += 256) {   // tail (at most 2 passes)
-          const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
-          if (p4 >= a1k && p4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
-          else {
-            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (p4 + j >= a1k && p4 + j < end1k) g1k[p4 + j] = e[j];
-          }
-        }
-      }
+      expand_task<WIDE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, 0u, gt_words);
     }
   }
-  if (r.done_flag) {   // latency launches: completion mailbox
-    __syncthreads();
+  // ---- completion: the last block applies the literal dedup rule where needed, then posts the mailbox ----
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) {
+    if (any_slow && !over) {
+      __threadfence();   // the headers other blocks wrote
+      for (uint32_t q = threadIdx.x; q < n; q += blockDim.x)
+        if (r.q_flags[q] & kRegionSlow) dedup_region(im, r, q);
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1) {
-        *r.done_counter = 0;   // re-armed for the next launch on this stream
-        if (r.host_totals && r.dyn_totals)   // written by an earlier kernel of the stream: visible here
-          for (int i = 0; i < 4; ++i) r.host_totals[i] = r.dyn_totals[i];
-        __threadfence_system();
-        *r.done_flag = r.done_seq;
-      }
+      *r.done_counter = 0;   // re-armed for the next launch on this stream
+      r.host_totals[0] = A; r.host_totals[1] = S; r.host_totals[2] = any_slow ? 1 : 0; r.host_totals[3] = over ? 1 : 0;
+      __threadfence_system();
+      *r.done_flag = r.done_seq;
     }
   }
 }
