@@ -69,7 +69,7 @@ struct vs_index {
   uint64_t lat_seq = 0;
   std::vector<uint64_t> h_carpre;   // host copy of DevImage::s_carpre (arena prefix): sizes of the latency path's results
   uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path, batch totals
-  static constexpr size_t kPinTotals = 0;     // [0..3] latency path: slots, carriers, any-slow, overflow
+  static constexpr size_t kPinTotals = 0;     // [0..2] latency path, VS_LAT_DEBUG only: device-clock durations (kernel, bounds, tasks)
   static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
   static constexpr size_t kPinRegions = 8;    // [8 .. 8 + 2*512) latency path: the regions themselves
   static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path: slots and arena entries of the batch
@@ -222,9 +222,9 @@ static int build_device_image(vs_index* idx) {
   for (auto& e : idx->ev) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&idx->pinned, 16384, hipHostMallocCoherent | hipHostMallocMapped));
   memset(idx->pinned, 0, 16384);
-  HIP_TRY(hipMalloc((void**)&idx->done_counter, 8));
+  HIP_TRY(hipMalloc((void**)&idx->done_counter, 32));   // [0] blocks finished, [1..3] device time stamps of the latency kernel
   idx->image_allocs.push_back(idx->done_counter);
-  HIP_TRY(hipMemsetAsync(idx->done_counter, 0, 8, idx->stream));
+  HIP_TRY(hipMemsetAsync(idx->done_counter, 0, 32, idx->stream));
   d.ref_length = im.ref_length;
   d.nbits = (uint64_t)im.bits.size() * 64;
   d.num_samples = im.num_samples; d.wpc = im.wpc; d.use_bv = im.use_bit_vector;
@@ -705,6 +705,7 @@ static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64
 // spins on.  Returns 1 if the device found the slab too small (cannot happen unless host and device disagree; the
 // caller then takes the general path).
 static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
+  const auto host_enter = std::chrono::steady_clock::now();
   DevResult& d = r->d;
   d.Q = n;
   uint64_t capA = 0, capS = 0, ntasks = 0;
@@ -737,8 +738,10 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   d.done_counter = idx->done_counter;
   d.done_flag = idx->pinned + vs_index::kPinFlag;
   d.done_seq = ++idx->lat_seq;
-  d.host_totals = idx->pinned + vs_index::kPinTotals;
-  const auto host_t0 = std::chrono::steady_clock::now();   // no HIP events here: each one is a packet on the critical path
+  static const bool lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
+  d.host_totals = lat_debug ? idx->pinned + vs_index::kPinTotals : nullptr;
+  const auto host_prep = std::chrono::steady_clock::now();
+  const auto host_t0 = host_prep;   // no HIP events here: each one is a packet on the critical path
   {
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, (ntasks + 3) / 4);
     const uint32_t gt_words = fill_gt_words(idx);
@@ -759,12 +762,13 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     }
   }
   HIP_TRY(hipGetLastError());
+  const auto host_launched = std::chrono::steady_clock::now();
   {  // spin on the mailbox (the runtime's completion wait costs several microseconds more); a kernel that never posts
      // -- a fault -- is caught by the stream synchronisation after the deadline
     volatile uint64_t* flag = idx->pinned + vs_index::kPinFlag;
     const auto deadline = host_t0 + std::chrono::microseconds(300);
     bool posted = false;
-    while (!(posted = (*flag == d.done_seq))) {
+    while (!(posted = ((*flag & 0x3FFFFFFFFFFFFFFFull) == d.done_seq))) {
       __builtin_ia32_pause();
       if (std::chrono::steady_clock::now() > deadline) break;
     }
@@ -773,13 +777,21 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   }
   d.done_flag = nullptr;
   d.host_totals = nullptr;
+  const uint64_t posted_word = *(volatile uint64_t*)(idx->pinned + vs_index::kPinFlag);
+  if ((posted_word & 0x3FFFFFFFFFFFFFFFull) != d.done_seq) return fail(VS_ERR_INTERNAL, "the latency kernel finished without posting its completion word");
+  if (posted_word >> 63) return 1;  // the device wanted more than the host computed: nothing was written
+  // d.A / d.S keep the host's figures: the device arrived at the same ones or it would have said so
   const volatile uint64_t* tot = idx->pinned + vs_index::kPinTotals;
-  if (tot[3]) return 1;  // the device wanted more than the host computed: nothing was written
-  d.A = tot[0];
-  d.S = tot[1];
   vs_timing& t = idx->timing;
-  t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
-  t.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();   // submit -> completion, host clock
+  // latency path: host clock.  ms_bounds = sizing + slab, ms_scan = the launch call, ms_emit = waiting for the mailbox,
+  // ms_fill = the kernel's own duration by the device clock (first wave's start to the last block's post)
+  const auto host_done = std::chrono::steady_clock::now();
+  t.ms_bounds = std::chrono::duration<float, std::milli>(host_prep - host_enter).count();
+  t.ms_scan = std::chrono::duration<float, std::milli>(host_launched - host_prep).count();
+  t.ms_emit = std::chrono::duration<float, std::milli>(host_done - host_launched).count();
+  t.ms_fill = lat_debug ? (float)tot[0] * 1e-5f : 0.f;
+  if (lat_debug) fprintf(stderr, "latency kernel: %.2f us total, bounds %.2f us, tasks %.2f us\n", tot[0] * 0.01, tot[1] * 0.01, tot[2] * 0.01);
+  t.ms_total = std::chrono::duration<float, std::milli>(host_done - host_enter).count();   // call -> completion
   t.fill_launches = 1;
   return VS_OK;
 }

@@ -35,9 +35,6 @@
 #include <stdint.h>
 #include <type_traits>
 
-#ifndef VS_EARLY_NIB
-#define VS_EARLY_NIB 0
-#endif
 namespace vsamd {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -98,9 +95,9 @@ struct DevResult {
   uint64_t* r_gt0;
   void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
   uint32_t car_width, pad3_; // bytes per carrier word in the arena: 2 or 4
-  // latency path (k_query_small): the last block posts done_seq into mapped host memory (the host spins on it instead
-  // of waiting for the runtime's completion signal) after writing the batch totals {slots, arena entries, any region
-  // took the literal dedup rule, capacities exceeded} next to it -- one writer for the flag and the data it guards
+  // latency path (k_query_small): the last block posts done_seq | any-slow << 62 | capacities-exceeded << 63 into
+  // mapped host memory -- ONE word, one writer -- and the host spins on it instead of waiting for the runtime's
+  // completion signal.  host_totals is a debugging aid (VS_LAT_DEBUG: device-clock durations), NULL otherwise.
   unsigned long long* done_counter;
   volatile uint64_t* done_flag;
   uint64_t done_seq;
@@ -117,16 +114,34 @@ __global__ void __launch_bounds__(256) k_pad_counts(const uint32_t* in, uint32_t
 }
 
 // ones in bit positions [0, p): number of ref-node start indexes <= p
-__device__ __forceinline__ uint32_t rank1(const DevImage& im, uint64_t p) {
+// Branch-free: the whole 512-bit block comes in four independent 16-byte loads issued together with the block's
+// cumulative count (ONE memory latency instead of up to nine in a row); words beyond p are masked off.  p == nbits
+// (one past the last block) is served from the last block with all eight words counted.
+struct RankLoads { uint32_t base; uint4 q[4]; uint32_t full, rem; };
+__device__ __forceinline__ RankLoads rank1_issue(const DevImage& im, uint64_t p) {
   if (p > im.nbits) p = im.nbits;
-  const uint64_t blk = p >> 9;
-  uint32_t r = im.blk_rank[blk];
-  const uint64_t w1 = p >> 6;
-  for (uint64_t w = blk << 3; w < w1; ++w) r += __popcll(im.bits[w]);
-  const uint32_t rem = (uint32_t)(p & 63);
-  if (rem) r += __popcll(im.bits[w1] & ((1ULL << rem) - 1));
+  const uint64_t nblk = im.nbits >> 9;                      // bits holds a whole number of blocks (>= 1)
+  const uint64_t blk = (p >> 9) < nblk ? (p >> 9) : nblk - 1;
+  RankLoads l;
+  l.base = im.blk_rank[blk];
+  const uint4* b4 = reinterpret_cast<const uint4*>(im.bits + (blk << 3));
+  l.q[0] = b4[0]; l.q[1] = b4[1]; l.q[2] = b4[2]; l.q[3] = b4[3];
+  l.full = (uint32_t)((p >> 6) - (blk << 3));               // whole words below p inside the block: 0..8
+  l.rem = (uint32_t)(p & 63);
+  return l;
+}
+__device__ __forceinline__ uint32_t rank1_finish(const RankLoads& l) {
+  uint32_t r = l.base;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    const uint4& v = l.q[i >> 1];
+    const uint64_t w = (i & 1) ? (((uint64_t)v.w << 32) | v.z) : (((uint64_t)v.y << 32) | v.x);
+    const uint64_t m = i < l.full ? ~0ULL : (i == l.full ? ((1ULL << l.rem) - 1) : 0ULL);
+    r += __popcll(w & m);
+  }
   return r;
 }
+__device__ __forceinline__ uint32_t rank1(const DevImage& im, uint64_t p) { return rank1_finish(rank1_issue(im, p)); }
 
 // (a & mask) | c in one VOP3 instruction; the mask must sit in an SGPR (no literals in VOP3 on gfx9)
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask_sgpr, uint32_t c) {
@@ -221,39 +236,37 @@ struct RegionBounds {
   uint32_t g0, g1;   // site range [g0, g1)
   uint8_t flags;
 };
+// Index::is_empty (index.h:150-166), Index::find(x) (index.h:119-133) and the stop rule of the walk (query.h:312).
+// Written for memory-level parallelism: both ranks are requested together, every table is read on a clamped index
+// whether or not the reference's early-outs fire (they select the result at the end), so a region costs four
+// dependent memory levels -- ranks; select + slots; branch and dedup prefixes; (callers) arena prefixes.
 __device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uint64_t x, uint64_t y) {
-  uint8_t fl = 0;
-  uint32_t g0 = 0, g1 = 0;
-  if (x < 1) {
-    fl = kRegionInvalid;
-  } else {
-    // Index::is_empty, index.h:150-166
-    bool empty = false;
-    if (x > im.ref_length) empty = true;
-    else {
-      const uint32_t rx = rank1(im, x);           // >= 1 because a node starts at index 1
-      if (rx >= im.R) empty = true;               // select past the last one: defined as empty
-      else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
-    }
-    if (empty) fl = kRegionEmpty;
-    else if (x < y) {
-      // Index::find(x), index.h:119-133
-      const uint64_t rf = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;
-      const uint32_t s0 = im.rank_to_slot[rf];
-      // first slot whose node ends at or after y stops the walk (query.h:312);
-      // node ends tile the reference, so that is the slot before the first start >= y
-      const uint32_t ry = rank1(im, y - 1);
-      uint32_t s1 = im.rank_to_slot[ry] - 1;      // rank_to_slot[R] == P
-      if (s1 < s0) s1 = s0;
-      g0 = im.rp_cand_prefix[s0];
-      g1 = im.rp_cand_prefix[s1];
-      // can the "already seen" rule fire inside [g0,g1)?  (g0, g1 are slot boundaries: the list range is tabulated)
-      const uint32_t lo = im.rp_sus_prefix[s0], hi = im.rp_sus_prefix[s1];
-      for (uint32_t k = lo; k < hi; ++k) {
-        const uint32_t pv = im.sus_prev[k];
-        if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
-      }
-    }
+  const RankLoads lx = rank1_issue(im, x), ly = rank1_issue(im, y - 1);   // y == 0 wraps and is clamped: x < y fails then
+  const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
+  const uint32_t R = (uint32_t)im.R, P = (uint32_t)im.P;
+  const bool invalid = x < 1;                                            // the reference aborts (index.h:151-154)
+  const uint64_t sel = im.idx_pos[rx < R ? rx : R - 1];                  // select(rank(x) + 1)
+  // is_empty: x beyond the reference, select past the last one (defined as empty), or no node start in (.., y]
+  const bool empty = x > im.ref_length || rx >= R || !(sel - 1 <= y);
+  // find(x): rank(x) >= 1 for every x >= 1 because a node starts at index 1
+  uint64_t rf = (x >= im.ref_length) ? (uint64_t)R - 1 : (uint64_t)(rx ? rx - 1 : 0);
+  if (rf > (uint64_t)R - 1) rf = (uint64_t)R - 1;
+  const uint32_t s0 = im.rank_to_slot[rf];
+  // first slot whose node ends at or after y stops the walk; node ends tile the reference, so that is the slot before
+  // the first start >= y (rank_to_slot[R] == P)
+  const uint32_t s1raw = im.rank_to_slot[ry < R ? ry : R];
+  uint32_t s1 = s1raw ? s1raw - 1 : 0;
+  if (s1 < s0) s1 = s0;
+  if (s1 > P) s1 = P;
+  uint32_t g0 = im.rp_cand_prefix[s0], g1 = im.rp_cand_prefix[s1];
+  // can the "already seen" rule fire inside [g0,g1)?  (g0, g1 are slot boundaries: the list range is tabulated)
+  uint32_t lo = im.rp_sus_prefix[s0], hi = im.rp_sus_prefix[s1];
+  const bool walk = !invalid && !empty && x < y;
+  if (!walk) { g0 = 0; g1 = 0; lo = 0; hi = 0; }
+  uint8_t fl = invalid ? kRegionInvalid : (empty ? kRegionEmpty : 0);
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t pv = im.sus_prev[k];
+    if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
   }
   return RegionBounds{g0, g1, fl};
 }
@@ -591,7 +604,9 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
 // fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
 // one wave of occupancy -- is compiled out.
-template <bool WIDE>
+// EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
+// per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
+template <bool WIDE, bool EARLY_NIB>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
                                             uint64_t gt0, uint64_t cb, uint32_t ablate, uint32_t gt_words) {
   const uint32_t wpc = im.wpc;
@@ -626,7 +641,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
     const uint64_t gt0_0 = wave_bcast64(gt0, t0);
     if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
-    if (!lists || VS_EARLY_NIB) {
+    if (!lists || EARLY_NIB) {
       const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
       const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
       if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
@@ -743,7 +758,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   }
 
   if (dmask == 0) return;
-  if (lists && !VS_EARLY_NIB) {   // the first dense variant's nibbles (8 registers) are requested after the list phase: its peak register
+  if (lists && !EARLY_NIB) {   // the first dense variant's nibbles (8 registers) are requested after the list phase: its peak register
                  // demand decides how many waves a SIMD holds
     const int t0 = __builtin_ctzll(dmask);
     const uint32_t cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
@@ -964,7 +979,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = r.r_gt0[a];
       cb = r.r_car_begin[a];
     }
-    expand_task<WIDE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
@@ -996,6 +1011,7 @@ __global__ void __launch_bounds__(256) k_query_small(DevImage im, DevResult r, S
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t n = (uint32_t)r.Q;
+  if (r.host_totals && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&r.done_counter[1], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // VS_LAT_DEBUG: device clock, 100 MHz
   // ---- bounds of region `lane`, offsets of all regions ----
   RegionBounds b{0, 0, 0};
   uint64_t pre0 = 0, npad = 0, nkept = 0;
@@ -1012,6 +1028,7 @@ __global__ void __launch_bounds__(256) k_query_small(DevImage im, DevResult r, S
   const uint32_t T = __builtin_amdgcn_readlane(tend, 63);
   const bool any_slow = __ballot(b.flags & kRegionSlow) != 0;
   const bool over = A > cap_slots || S > cap_carriers;
+  if (r.host_totals && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&r.done_counter[2], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bounds and offsets done
   if (wave == 0 && !over) {   // the per-region arrays of the result
     if (lane < n) {
       r.q_flags[lane] = b.flags; r.q_g0[lane] = b.g0; r.q_nvar[lane] = nv;
@@ -1052,29 +1069,42 @@ __global__ void __launch_bounds__(256) k_query_small(DevImage im, DevResult r, S
         r.r_class[a] = cls;
         r.r_gt0[a] = gt0;
       }
-      expand_task<WIDE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, 0u, gt_words);
+      expand_task<WIDE, true>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, 0u, gt_words);
     }
   }
-  // ---- completion: the last block applies the literal dedup rule where needed, then posts the mailbox ----
+  // ---- completion: the last block applies the literal dedup rule where needed, then posts the mailbox.  The
+  //      flag word carries everything the host does not know yet: sequence number | any-slow << 62 | over << 63 (the
+  //      sizes are the host's own).  Without dedup work nobody reads another block's data inside this launch, so a
+  //      block only waits until its own stores are acknowledged (no L2 write-back) before it counts itself done. ----
   __shared__ uint32_t s_last;
+  if (r.host_totals && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&r.done_counter[3], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block 0's first wave is through
+  if (any_slow) __threadfence();
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1 ? 1u : 0u;
-  }
+  if (threadIdx.x == 0) s_last = atomicAdd(r.done_counter, 1ULL) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (s_last) {
     if (any_slow && !over) {
       __threadfence();   // the headers other blocks wrote
       for (uint32_t q = threadIdx.x; q < n; q += blockDim.x)
         if (r.q_flags[q] & kRegionSlow) dedup_region(im, r, q);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
     }
     if (threadIdx.x == 0) {
       *r.done_counter = 0;   // re-armed for the next launch on this stream
-      r.host_totals[0] = A; r.host_totals[1] = S; r.host_totals[2] = any_slow ? 1 : 0; r.host_totals[3] = over ? 1 : 0;
-      __threadfence_system();
-      *r.done_flag = r.done_seq;
+      if (r.host_totals) {   // VS_LAT_DEBUG: device-clock durations in 10 ns ticks {kernel, bounds + offsets, block 0's tasks}
+        const uint64_t t_end = wall_clock64();   // (the stamps come from another block, possibly another XCD: agent-scope loads)
+        const uint64_t t1 = __hip_atomic_load(&r.done_counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t2 = __hip_atomic_load(&r.done_counter[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t3 = __hip_atomic_load(&r.done_counter[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.host_totals[0] = t_end - t1;
+        r.host_totals[1] = t2 - t1;
+        r.host_totals[2] = t3 - t2;
+        __threadfence_system();
+      }
+      __hip_atomic_store(const_cast<uint64_t*>(r.done_flag), r.done_seq | (any_slow ? 1ULL << 62 : 0ULL) | (over ? 1ULL << 63 : 0ULL),
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
