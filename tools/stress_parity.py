@@ -32,6 +32,8 @@ for c in range(n_cohorts):
     if rng.random() < 0.3:
         names = [f"n{int(x)}" for x in rng.permutation(kw["n_samples"])]
         kw["sample_names"] = names
+    # the threshold between the list path and the row path of k_fill_carriers is fixed when an index is opened
+    os.environ["VS_LIST_MAX"] = str(int(rng.choice([0, 1, 7, 8, 9, 40, 200, 640])))
     with tempfile.TemporaryDirectory() as td:
         fasta, vcf, names = write_random_cohort(td, seed, **kw)
         try:
@@ -55,9 +57,9 @@ for c in range(n_cohorts):
                 bad += 1
                 print(f"MISMATCH t6 cohort {seed} region {x}:{y}\n--- gpu\n{res.region_text(q)}--- oracle\n{text}")
         slow_regions += int((flags["var_count"] != np.diff(flags["var_begin"].astype(np.int64))).sum())
-        # the same regions again through the small-batch paths (one launch in front of the fill kernel up to 8
-        # regions, the single-sync latency path up to 512)
-        for lo, hi in ((0, 1), (1, 4), (4, 12), (12, 20), (20, 21)):
+        # the same regions again through the single-launch latency path (up to 64 regions: kernel-argument forms of 8
+        # and 64 regions) and a 70-region batch through the general path
+        for lo, hi in ((0, 1), (1, 4), (4, 12), (12, 76), (20, 21), (30, 100)):
             sub_r = regions[lo:hi]
             rs = vs.get_var_in_ref(sub_r)
             for q, (x, y) in enumerate(sub_r):

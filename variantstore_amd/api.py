@@ -52,7 +52,7 @@ class QueryResult:
     def __init__(self, store, handle):
         self._store = store
         self._h = handle
-        self._lib = _lib.load()
+        self._lib = store._lib
 
     def close(self):
         if self._h:
@@ -166,6 +166,8 @@ class VariantStore:
     def __init__(self, handle, stats=None):
         self._h = handle
         self._lib = _lib.load()
+        # same symbol, raw-address prototype: passing a numpy buffer's address as an int skips ctypes' pointer objects
+        self._q6 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)(("vs_query_var_in_ref", self._lib))
         self.construct_stats = stats
 
     # ---- constructors -------------------------------------------------------
@@ -258,9 +260,16 @@ class VariantStore:
 
     def get_var_in_ref(self, regions) -> QueryResult:
         """Query type 6 over a batch of (pos_x, pos_y) regions (query.h:736-784)."""
-        arr, ptr, n = _regions_array(regions)
+        # (this is the call whose single-region latency the bench reports: a ready uint64 array is passed on as it is,
+        #  without the ctypes pointer objects of the general helper)
+        if type(regions) is np.ndarray and regions.dtype == np.uint64 and regions.flags.c_contiguous and regions.ndim == 2:
+            arr = regions
+        else:
+            arr = np.ascontiguousarray(np.asarray(regions, dtype=np.uint64).reshape(-1, 2))
         h = C.c_void_p()
-        _check(self._lib.vs_query_var_in_ref(self._h, ptr, n, C.byref(h)), "vs_query_var_in_ref")
+        rc = self._q6(self._h, arr.__array_interface__["data"][0], arr.shape[0], C.byref(h))
+        if rc != 0:
+            raise VariantStoreError(rc, "vs_query_var_in_ref")
         return QueryResult(self, h)
 
     def get_sample_var_in_ref(self, regions, sample) -> QueryResult:
