@@ -354,6 +354,42 @@ def test_latency_path_with_large_answers(tmp_path):
     assert _compare_t6(vs, orc, batch) == 512
 
 
+def test_resident_server_and_launch_forms_of_the_latency_path_agree(tmp_path, monkeypatch):
+    """Small batches are answered by the resident query server (no launch per request) while one is alive, by a single
+    launch otherwise: same text either way, across server expiry (it leaves 1 ms after the last request), restart, a
+    general-path batch in between, and requests too large for the server."""
+    import time
+    vs = VariantStore.synthetic(device=0, ref_length=400_000, num_variants=6000, num_samples=900, seed=93,
+                                first_pos=200, frac_ins=0.05, frac_del=0.05, frac_multi=0.03, max_indel=4,
+                                af_exponent=2.5)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(17)
+    singles = [[(int(s), int(s) + int(rng.integers(1, 3000)))] for s in rng.integers(1, 396_000, size=40)]
+    pairs = [[(int(s), int(s) + 900), (int(s) + 5000, int(s) + 5400), (3, 2)] for s in rng.integers(1, 390_000, size=10)]
+    want = {tuple(b): [orc.get_var_in_ref(x, y)[2] for x, y in b] for b in singles + pairs}
+
+    def check(batches):
+        for b in batches:
+            res = vs.get_var_in_ref(b)
+            assert [res.region_text(q) for q in range(len(b))] == want[tuple(b)], b
+            res.close()
+
+    check(singles[:20] + pairs[:5])                  # server starts with the first request and stays
+    time.sleep(0.01)                                 # ... leaves by its idle clock; the next request restarts it
+    check(singles[20:30])
+    big = [(int(s), int(s) + 700) for s in rng.integers(1, 398_000, size=300)]
+    assert _compare_t6(vs, orc, big) == 300          # general path while a server is alive
+    check(pairs[5:])
+    assert _compare_t6(vs, orc, [(1, 300_000)]) == 1  # too many tasks for the server: one launch sized for it
+    monkeypatch.setenv("VS_NO_SERVER", "1")
+    check(singles[30:] + pairs[:3])                  # launch form
+    monkeypatch.delenv("VS_NO_SERVER")
+    check(singles[:5])
+    vs.close()
+
+
 def _parse_rows(text):
     rows = []
     for line in text.split("\n")[1:-1]:

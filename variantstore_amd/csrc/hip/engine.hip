@@ -67,11 +67,19 @@ struct vs_index {
   bool close_pending = false;  // vs_index_close was called while results were alive
   unsigned long long* done_counter = nullptr;   // device word of the latency path's completion mailbox
   uint64_t lat_seq = 0;
+  // resident query server of the latency path (kernels.hip.h: k_query_server)
+  hipStream_t srv_stream = nullptr;
+  bool srv_alive = false;
+  std::chrono::steady_clock::time_point srv_started{}, srv_last{};
+  uint64_t srv_seq = 1;                          // sequence number of the next request
+  unsigned long long* srv_counter = nullptr;     // device word: blocks done with the current request
   std::vector<uint64_t> h_carpre;   // host copy of DevImage::s_carpre (arena prefix): sizes of the latency path's results
   uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path, batch totals
   static constexpr size_t kPinTotals = 0;     // [0..2] latency path, VS_LAT_DEBUG only: device-clock durations (kernel, bounds, tasks)
   static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
   static constexpr size_t kPinRegions = 8;    // [8 .. 8 + 2*512) latency path: the regions themselves
+  static constexpr size_t kPinSrvResp = 16;   // resident server: sequence number of the last request answered
+  static constexpr size_t kPinSrvReq = 256;   // [256 .. 256 + 136) resident server: the request (ServerRequest, 64-byte aligned)
   static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path: slots and arena entries of the batch
 };
 
@@ -700,6 +708,56 @@ static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64
   *arena_entries = idx->h_carpre[g1] - idx->h_carpre[g0];
 }
 
+// ---- resident query server (kernels.hip.h: k_query_server) ----
+constexpr unsigned kSrvBlocks = 16;                 // 64 waves share a request's 8-slot tasks
+constexpr uint64_t kSrvMaxTasks = 2 * kSrvBlocks * 4;   // larger requests are better off with a launch sized for them
+constexpr uint64_t kSrvLifeTicks = 2000000;         // device clock, 100 MHz: 20 ms, then the kernel leaves by itself
+constexpr uint64_t kSrvIdleTicks = 100000;          // ... or 1 ms after the last request
+constexpr auto kSrvHostLife = std::chrono::milliseconds(14);     // the host replaces a server older than this
+constexpr auto kSrvHostIdle = std::chrono::microseconds(600);    // ... and does not trust one that has been idle this long
+
+static ServerRequest* srv_request(vs_index* idx) { return reinterpret_cast<ServerRequest*>(idx->pinned + vs_index::kPinSrvReq); }
+
+static int server_stop(vs_index* idx) {
+  if (!idx->srv_stream) return VS_OK;
+  if (idx->srv_alive) {
+    volatile uint64_t* head = &srv_request(idx)->head;
+    *head = ~0ULL;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    idx->srv_alive = false;
+  }
+  HIP_TRY(hipStreamSynchronize(idx->srv_stream));   // bounded: the kernel leaves on the exit word, or by its own clock
+  return VS_OK;
+}
+
+static int server_ensure(vs_index* idx) {
+  const auto now = std::chrono::steady_clock::now();
+  if (idx->srv_alive && now - idx->srv_started < kSrvHostLife && now - idx->srv_last < kSrvHostIdle) return VS_OK;
+  if (!idx->srv_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&idx->srv_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&idx->srv_counter, 8));
+    idx->image_allocs.push_back(idx->srv_counter);
+  }
+  VS_TRY(server_stop(idx));
+  ServerRequest* rq = srv_request(idx);
+  memset(rq, 0, 64);
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  HIP_TRY(hipMemsetAsync(idx->srv_counter, 0, 8, idx->srv_stream));
+  const uint32_t gt_words = fill_gt_words(idx);
+  const size_t lds_bytes = fill_lds_bytes(idx);
+  volatile uint64_t* resp = idx->pinned + vs_index::kPinSrvResp;
+  if (idx->d.wpc <= 63)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<false>), dim3(kSrvBlocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
+                       (const ServerRequest*)rq, idx->srv_counter, resp, idx->srv_seq, gt_words, kSrvLifeTicks, kSrvIdleTicks);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<true>), dim3(kSrvBlocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
+                       (const ServerRequest*)rq, idx->srv_counter, resp, idx->srv_seq, gt_words, kSrvLifeTicks, kSrvIdleTicks);
+  HIP_TRY(hipGetLastError());
+  idx->srv_alive = true;
+  idx->srv_started = idx->srv_last = std::chrono::steady_clock::now();
+  return VS_OK;
+}
+
 // Latency path for type-6 batches of at most 64 regions: ONE launch (k_query_small), regions in the kernel arguments,
 // one exact-size pooled slab for the whole result, completion through a mailbox in mapped host memory the caller
 // spins on.  Returns 1 if the device found the slab too small (cannot happen unless host and device disagree; the
@@ -707,41 +765,76 @@ static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64
 static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
   const auto host_enter = std::chrono::steady_clock::now();
   DevResult& d = r->d;
-  d.Q = n;
   uint64_t capA = 0, capS = 0, ntasks = 0;
   for (uint64_t q = 0; q < n; ++q) {
     uint64_t a = 0, c = 0;
     host_region_size(idx, regions[q].x, regions[q].y, &a, &c);
     capA += a; capS += c; ntasks += (a + kFillChunkSmall - 1) / kFillChunkSmall;
   }
-  d.regions = nullptr;   // they travel in the kernel arguments
-  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  const uint32_t car_width = idx->d.wpc <= 63 ? 2 : 4;
+  uint8_t* slab = nullptr;
   {  // one pooled slab for everything (two dozen pool look-ups cost microseconds at this scale)
-    size_t off = 0;
-    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_flags = take(n), o_g0 = take(n * 4), o_nvar = take(n * 8), o_ncar = take(n * 8), o_vb = take((n + 1) * 8),
-                 o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_pos = take(capA * 8), o_ro = take(capA * 4),
-                 o_rl = take(capA * 4), o_ao = take(capA * 4), o_al = take(capA * 4), o_fl = take(capA * 4), o_cc = take(capA * 4),
-                 o_rg = take(capA * 4), o_cbg = take(capA * 8), o_cl = take(capA * 4), o_gt = take(capA * 8),
-                 o_car = take(capS * d.car_width + 16);
-    uint8_t* slab = nullptr;
-    VS_TRY(ralloc(r, off, &slab));
-    d.q_flags = slab + o_flags; d.q_g0 = (uint32_t*)(slab + o_g0); d.q_nvar = (uint64_t*)(slab + o_nvar);
-    d.q_ncar = (uint64_t*)(slab + o_ncar); d.var_begin = (uint64_t*)(slab + o_vb); d.car_base = (uint64_t*)(slab + o_cb);
-    d.var_count = (uint64_t*)(slab + o_vc);
-    d.r_pos = (uint64_t*)(slab + o_pos); d.r_ref_off = (uint32_t*)(slab + o_ro); d.r_ref_len = (uint32_t*)(slab + o_rl);
-    d.r_alt_off = (uint32_t*)(slab + o_ao); d.r_alt_len = (uint32_t*)(slab + o_al); d.r_flags = (uint32_t*)(slab + o_fl);
-    d.r_car_count = (uint32_t*)(slab + o_cc); d.r_region = (uint32_t*)(slab + o_rg); d.r_car_begin = (uint64_t*)(slab + o_cbg);
-    d.r_class = (uint32_t*)(slab + o_cl); d.r_gt0 = (uint64_t*)(slab + o_gt); d.carriers = slab + o_car;
+    DevResult probe{};
+    const size_t bytes = small_result_layout(probe, nullptr, n, capA, capS, car_width);
+    VS_TRY(ralloc(r, bytes, &slab));
+    small_result_layout(d, slab, n, capA, capS, car_width);
   }
-  d.A = capA; d.S = capS;
+  static const bool lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
+  const bool no_server = getenv("VS_NO_SERVER") != nullptr;   // read per call: tests switch between the two forms
+  vs_timing& t = idx->timing;
+  const auto host_prep = std::chrono::steady_clock::now();
+
+  // ---- resident server: no launch at all (requests small enough for its 64 waves) ----
+  if (!no_server && ntasks <= kSrvMaxTasks) {
+    VS_TRY(server_ensure(idx));
+    ServerRequest* rq = srv_request(idx);
+    const uint64_t seq = idx->srv_seq;
+    volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(rq);
+    if (n > 1) memcpy((void*)rq->xy, regions, n * 16);
+    w[1] = (uint64_t)slab; w[2] = capA; w[3] = capS; w[4] = n | (lat_debug ? 1ull << 16 : 0ull) | ((uint64_t)car_width << 32);
+    w[5] = regions[0].x; w[6] = regions[0].y;
+    std::atomic_thread_fence(std::memory_order_release);
+    w[7] = seq;                                   // tail, then head: a reader that sees both has the whole line
+    std::atomic_thread_fence(std::memory_order_release);
+    w[0] = seq;
+    const auto posted_at = std::chrono::steady_clock::now();
+    volatile uint64_t* resp = idx->pinned + vs_index::kPinSrvResp;
+    const auto deadline = posted_at + std::chrono::microseconds(400);
+    bool answered = false;
+    while (!(answered = ((*resp & 0x3FFFFFFFFFFFFFFFull) == seq))) {
+      __builtin_ia32_pause();
+      if (std::chrono::steady_clock::now() > deadline) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (answered) {
+      idx->srv_seq = seq + 1;
+      const auto host_done = std::chrono::steady_clock::now();
+      idx->srv_last = host_done;
+      if (*resp >> 63) return 1;   // the device wanted more than the host computed: nothing was written
+      if (lat_debug)
+        fprintf(stderr, "server request: seen -> tasks done %.2f us, release fence %.2f us, -> last block posts %.2f us (wait on host %.2f us)\n",
+                (resp[2] - resp[1]) * 0.01, (resp[3] - resp[2]) * 0.01, (double)(int64_t)(resp[4] - resp[3]) * 0.01,
+                std::chrono::duration<double, std::micro>(host_done - posted_at).count());
+      t.ms_bounds = std::chrono::duration<float, std::milli>(host_prep - host_enter).count();
+      t.ms_scan = std::chrono::duration<float, std::milli>(posted_at - host_prep).count();
+      t.ms_emit = std::chrono::duration<float, std::milli>(host_done - posted_at).count();
+      t.ms_fill = 0.f;
+      t.ms_total = std::chrono::duration<float, std::milli>(host_done - host_enter).count();
+      t.fill_launches = 0;
+      return VS_OK;
+    }
+    // Not answered in time: the server left between the host's check and the request (its own clock), or some of its
+    // blocks did.  Whatever a block wrote is what the launch below writes again; make sure the server is gone first.
+    VS_TRY(server_stop(idx));
+    idx->srv_seq = seq + 1;   // a sequence number is never reused
+  }
+
+  // ---- one launch ----
   d.done_counter = idx->done_counter;
   d.done_flag = idx->pinned + vs_index::kPinFlag;
   d.done_seq = ++idx->lat_seq;
-  static const bool lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
   d.host_totals = lat_debug ? idx->pinned + vs_index::kPinTotals : nullptr;
-  const auto host_prep = std::chrono::steady_clock::now();
-  const auto host_t0 = host_prep;   // no HIP events here: each one is a packet on the critical path
+  const auto host_t0 = std::chrono::steady_clock::now();   // no HIP events here: each one is a packet on the critical path
   {
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, (ntasks + 3) / 4);
     const uint32_t gt_words = fill_gt_words(idx);
@@ -782,12 +875,11 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
   if (posted_word >> 63) return 1;  // the device wanted more than the host computed: nothing was written
   // d.A / d.S keep the host's figures: the device arrived at the same ones or it would have said so
   const volatile uint64_t* tot = idx->pinned + vs_index::kPinTotals;
-  vs_timing& t = idx->timing;
-  // latency path: host clock.  ms_bounds = sizing + slab, ms_scan = the launch call, ms_emit = waiting for the mailbox,
-  // ms_fill = the kernel's own duration by the device clock (first wave's start to the last block's post)
+  // latency path: host clock.  ms_bounds = sizing + slab, ms_scan = the launch call (or posting the request), ms_emit =
+  // waiting for the mailbox, ms_fill = the kernel's own duration by the device clock (VS_LAT_DEBUG only)
   const auto host_done = std::chrono::steady_clock::now();
   t.ms_bounds = std::chrono::duration<float, std::milli>(host_prep - host_enter).count();
-  t.ms_scan = std::chrono::duration<float, std::milli>(host_launched - host_prep).count();
+  t.ms_scan = std::chrono::duration<float, std::milli>(host_launched - host_t0).count();
   t.ms_emit = std::chrono::duration<float, std::milli>(host_done - host_launched).count();
   t.ms_fill = lat_debug ? (float)tot[0] * 1e-5f : 0.f;
   if (lat_debug) fprintf(stderr, "latency kernel: %.2f us total, bounds %.2f us, tasks %.2f us\n", tot[0] * 0.01, tot[1] * 0.01, tot[2] * 0.01);
@@ -830,6 +922,8 @@ void vs_index_close(vs_index* idx) {
   }
   if (idx->device >= 0) {
     (void)hipSetDevice(idx->device);
+    (void)server_stop(idx);
+    if (idx->srv_stream) (void)hipStreamDestroy(idx->srv_stream);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     for (auto p : idx->image_allocs) (void)hipFree(p);
     for (auto& b : idx->pool) (void)hipFree(b.p);
