@@ -111,7 +111,9 @@ int vs_index_export_plain(const vs_index* idx, const char* path);
 int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, uint64_t cap);
 
 /* ---- queries ------------------------------------------------------------ */
-/* type 6: get_var_in_ref for each of the n regions (query.h:736-784) */
+/* type 6: get_var_in_ref for each of the n regions (query.h:736-784).  Batches of at most 64 regions take the latency
+ * path: one kernel for the whole query, or -- while the handle's resident query server is alive -- no launch at all
+ * (VS_NO_SERVER=1 in the environment keeps it to one launch per call). */
 int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out);
 /* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
@@ -210,11 +212,16 @@ int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_rec
                            uint64_t* n_records);
 void vs_result_free(vs_result* r);
 
-/* ---- timing of the last batch on this handle (HIP events on the engine's stream) ---- */
+/* ---- timing of the last batch on this handle ----
+ * Batches of more than 64 regions and every other query type: HIP events on the engine's stream.
+ * Type-6 batches of at most 64 regions (latency path: no events on the critical path): host clock --
+ *   ms_total call -> result resident, ms_bounds sizing + result slab, ms_scan posting the request / the launch call,
+ *   ms_emit waiting for the completion word, ms_fill 0 (the kernel's duration by the device clock under VS_LAT_DEBUG),
+ *   fill_launches 0 when the resident query server answered, 1 when a kernel was launched for the call. */
 typedef struct {
-  float ms_total;    /* first launch to last kernel completion (small type-6 batches: host clock, submit -> done) */
+  float ms_total;    /* first launch to last kernel completion */
   float ms_bounds;   /* rank / region-bounds kernel            */
-  float ms_scan;     /* offset scans + dedup                   */
+  float ms_scan;     /* offset scan (+ the host round trip for the sizes) */
   float ms_emit;     /* variant-header kernel                  */
   float ms_fill;     /* carrier-expansion kernel (dominant)    */
   uint64_t fill_launches;

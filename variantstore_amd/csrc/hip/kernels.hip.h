@@ -19,8 +19,11 @@
 //                       that contain a repeated (pos, alt)
 // k_fill_carriers       get_samples -> get_sample_id / get_sample_phasing
 //                       (query.h:268-285, variant_graph.h:875-942): expansion of
-//                       a class bit row + genotype bits into carrier lists.
-//                       This is the dominant kernel.
+//                       decoded class id lists / class bit rows + genotype bits into
+//                       carrier lists.  This is the dominant kernel.
+// k_query_small         a whole get_var_in_ref batch of <= 64 regions in one launch
+//                       (bounds, offsets, headers, carriers, dedup): the latency path
+// k_query_server        the same, resident: polls requests in mapped host memory
 // k_point_bounds        one next_variant_in_ref call from a position (query.h:297-436)
 //                       as used by closest_var (query.h:441-483, type 1) and
 //                       samples_has_var (query.h:792-823, type 7)
