@@ -133,6 +133,12 @@ def cpu_baseline_all_cores(sub, plain, td, budget_s=10.0):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner through C stdio when a
+    # process group is created) must not be able to add to it: file descriptor 1 is pointed at stderr for the whole
+    # run and the JSON line goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -388,7 +394,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -440,6 +440,8 @@ __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult&
     const uint32_t g = g0 + (uint32_t)j;
     const uint32_t fl = im.s_flags[g];
     kept += im.s_ncar[g];
+    // (plain stores: non-temporal ones made this kernel slower -- its pieces of 256 bytes per array and pass only
+    //  become whole lines in the L2)
     r.r_pos[a] = im.s_pos[g];
     r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
     r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
@@ -541,6 +543,12 @@ __host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
   return w < 384 ? 384 : w;                  // the sparse phase keeps 6 x 64 words at the start of the region
 }
 constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
+
+// one 16-byte arena group, written once and not read again by this kernel
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_group_nt(uint4* p, uint4 v) {
+  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+}
 
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
   uint64_t v;
@@ -710,7 +718,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
           v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
           v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
-          arena_groups[dst0] = v;
+          store_group_nt(&arena_groups[dst0], v);
         }
         if (two) {
           const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
@@ -719,7 +727,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
           v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
           v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
-          arena_groups[dst1] = v;
+          store_group_nt(&arena_groups[dst1], v);
         }
       }
     }
@@ -878,7 +886,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
           v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
           v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
-          *reinterpret_cast<uint4*>(g1k + q8) = v;   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+          store_group_nt(reinterpret_cast<uint4*>(g1k + q8), v);   // a1k is a multiple of 8 and the range owns its padding (pad_car)
         }
         if (round == 0) {
           // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
@@ -976,11 +984,11 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
     const uint64_t a = wave * CH + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
-    if (a < A && lane < CH) {
-      cnt = r.r_car_count[a];
-      cls = r.r_class[a];
-      gt0 = r.r_gt0[a];
-      cb = r.r_car_begin[a];
+    if (a < A && lane < CH) {   // read once
+      cnt = __builtin_nontemporal_load(&r.r_car_count[a]);
+      cls = __builtin_nontemporal_load(&r.r_class[a]);
+      gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
+      cb = __builtin_nontemporal_load(&r.r_car_begin[a]);
     }
     expand_task<WIDE, false>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
