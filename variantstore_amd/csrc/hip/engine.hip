@@ -251,6 +251,13 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.v_ridx, &d.v_ridx));
   VS_TRY(upload_image(idx, im.v_class, &d.v_class));
   VS_TRY(upload_image(idx, im.v_src, &d.v_src));
+  {
+    const uint32_t *wv = nullptr, *we = nullptr;
+    VS_TRY(upload_image(idx, im.w_vertex, &wv));
+    VS_TRY(upload_image(idx, im.w_edge, &we));
+    d.w_vertex = reinterpret_cast<const uint4*>(wv);
+    d.w_edge = reinterpret_cast<const uint4*>(we);
+  }
   VS_TRY(upload_image(idx, im.v_ncar, &d.v_ncar));
   VS_TRY(upload_image(idx, im.v_nri, &d.v_nri));
   VS_TRY(upload_image(idx, im.v_car_begin, &d.v_car_begin));

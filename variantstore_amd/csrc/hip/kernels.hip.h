@@ -58,6 +58,8 @@ struct DevImage {
   const uint32_t* row_ptr;
   const uint32_t* col;
   const uint32_t *v_off, *v_len, *v_ridx, *v_class, *v_ncar, *v_nri;
+  const uint4* w_vertex;   // walk records, 2 x uint4 per vertex {row_begin, degree, ref index, offset | length, class, #carriers, 0}
+  const uint4* w_edge;     // 1 x uint4 per CSR entry {neighbour, its ref index, its class, 0}
   const uint32_t* v_src;   // per vertex: group index of its class's 16-bit id list (<= list_max carriers) or its class id (row)
   const uint64_t* v_car_begin;
   const uint64_t* class_rows;
@@ -1292,6 +1294,28 @@ __device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v
   return false;
 }
 
+// Walk records (device_image.hpp): one step of a path walk reads the current vertex in one 32-byte record and each
+// neighbour in one 16-byte edge record instead of gathering a dozen 4-byte fields from as many arrays.
+struct WalkVertex { uint32_t row_begin, deg, ridx, off, len, cls, ncar; };
+__device__ __forceinline__ WalkVertex walk_vertex(const DevImage& im, uint32_t v) {
+  const uint4 a = im.w_vertex[2 * (uint64_t)v], b = im.w_vertex[2 * (uint64_t)v + 1];
+  return WalkVertex{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+}
+struct WalkEdge { uint32_t nbr, ridx, cls; };
+__device__ __forceinline__ WalkEdge walk_edge(const DevImage& im, uint32_t e) {
+  const uint4 a = im.w_edge[e];
+  return WalkEdge{a.x, a.y, a.z};
+}
+// vertex_has_sample on what a record already holds (class rows; explicit-id cohorts fall back to the carrier pool)
+__device__ __forceinline__ bool record_has_sample(const DevImage& im, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t sid) {
+  if (im.use_bv) return (im.class_rows[(uint64_t)cls * im.wpc + (sid >> 6)] >> (sid & 63)) & 1;
+  if (sid == 0) return ridx != 0;
+  const uint64_t b = im.v_car_begin[v];
+  for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
+    if (im.car_sid[b + i] == sid) return true;
+  return false;
+}
+
 // MODE 0 counts, MODE 1 writes the variant headers at the scanned offsets (a second walk), MODE 2 walks ONCE:
 // it records every reported vertex in a scratch list whose per-region capacity is the region's type-6 slot count
 // (a sample's variants are branches of the same ref-path range) and flags an overflow instead of writing past it;
@@ -1332,42 +1356,46 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
         const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
         if (rank <= 1) { ref_pos = 1; start_v = v; break; }
         bool found = false;
-        for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) {
-          const uint32_t n = im.col[e];
-          if (im.v_ridx[n]) ref_pos = im.v_ridx[n];
-          if (vertex_has_sample(im, n, sid)) { start_v = n; found = true; }
+        const WalkVertex wv = walk_vertex(im, v);
+        for (uint32_t e = wv.row_begin; e < wv.row_begin + wv.deg; ++e) {
+          const WalkEdge ed = walk_edge(im, e);
+          if (ed.ridx) ref_pos = ed.ridx;
+          if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; }
           rank = rank ? rank - 1 : 0;  // the reference's unsigned counter would wrap here: clamped
         }
         if (found) break;
       }
       // ---- walk the sample's path ----
       uint32_t cur = start_v;
-      uint32_t cur_ref_off = 0, cur_ref_len = 0;  // cur_ref: sequence of the last ref neighbour of the previous vertex
+      uint32_t cur_ref_v = kNone;  // cur_ref: the last ref neighbour of the previous vertex (its sequence; none = empty string)
       bool done = false;
       const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
       const uint64_t cb = EMIT ? r.car_base[q] : 0;
       while (!done) {
         if (ref_pos >= y) break;
-        uint64_t next_ref_pos = ref_pos + im.v_len[cur];
-        uint32_t next_ref_off = 0, next_ref_len = 0;
+        const WalkVertex wc = walk_vertex(im, cur);   // one record instead of seven scattered fields
+        // (jumping over runs of forced, empty ref-path vertices was tried: in SNP-dense cohorts such runs are one
+        //  vertex long -- the 1-bp ref allele between two branching nodes -- and the two extra look-ups cost more)
+        uint64_t next_ref_pos = ref_pos + wc.len;
+        uint32_t next_ref_v = kNone;   // the last ref neighbour: its sequence becomes cur_ref (read only when a substitution is emitted)
         uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
         bool nxt_by_sample = false;
-        for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
-          const uint32_t n = im.col[e];
-          const uint32_t nr = im.v_ridx[n];
-          if (nr) { next_ref_pos = nr; next_ref_off = im.v_off[n]; next_ref_len = im.v_len[n]; }  // last ref neighbour wins
+        for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+          const WalkEdge ed = walk_edge(im, e);     // neighbour, its ref index and its class in one record
+          const uint32_t n = ed.nbr, nr = ed.ridx;
+          if (nr) { next_ref_pos = nr; next_ref_v = n; }  // last ref neighbour wins
           if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
-            if (sid != 0 && vertex_has_sample(im, n, sid)) { nxt = n; nxt_by_sample = true; }
+            if (sid != 0 && record_has_sample(im, n, nr, ed.cls, sid)) { nxt = n; nxt_by_sample = true; }
             else if (nr && min_idx > nr) { nxt = n; min_idx = nr; }
           }
         }
-        if (ref_pos >= x && vertex_has_sample(im, cur, sid)) {
+        if (ref_pos >= x && record_has_sample(im, cur, wc.ridx, wc.cls, sid)) {
           uint64_t pos;
           uint32_t ro, rl, ao, al;
           bool ok = true;
           if (ref_pos == next_ref_pos) {  // insertion
-            pos = ref_pos - 1; ro = 0; rl = 0; ao = im.v_off[cur]; al = im.v_len[cur];
-          } else if (im.v_ridx[cur]) {   // deletion: ref = sequence of find(ref_pos - 1)
+            pos = ref_pos - 1; ro = 0; rl = 0; ao = wc.off; al = wc.len;
+          } else if (wc.ridx) {   // deletion: ref = sequence of find(ref_pos - 1)
             const uint64_t p = ref_pos - 1;
             uint32_t fv;
             if (p < 1) { ok = false; fv = 0; }
@@ -1376,11 +1404,12 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
               fv = im.rp_vid[im.rank_to_slot[rf]];
             }
             pos = im.v_ridx[fv]; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
-          } else {                        // substitution
-            pos = ref_pos; ro = cur_ref_off; rl = cur_ref_len; ao = im.v_off[cur]; al = im.v_len[cur];
+          } else {                        // substitution: ref = sequence of the previous step's last ref neighbour
+            pos = ref_pos; ro = 0; rl = 0; ao = wc.off; al = wc.len;
+            if (cur_ref_v != kNone) { const WalkVertex wr = walk_vertex(im, cur_ref_v); ro = wr.off; rl = wr.len; }
           }
           if (ok) {
-            const uint32_t c = im.v_ncar[cur];
+            const uint32_t c = wc.ncar;
             if (EMIT) {
               const uint64_t a = a0 + nvar;
               r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
@@ -1398,7 +1427,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
             nvar++; ncar += pad_car(c); ncar_kept += c;
           }
         }
-        cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
+        cur_ref_v = next_ref_v;
         ref_pos = next_ref_pos;
         if (nxt == 0) done = true;  // no neighbour: the path iterator is done
         cur = nxt;
@@ -1576,38 +1605,42 @@ __global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r,
 // get_sample_from_vertex_if_exists(v, sample, out) -> out.index (variant_graph.h:1296-1339).  The s_info
 // entry of a sample is found by its position in the class's ascending id list (bit-vector mode) or by a
 // linear search (explicit ids); the carrier pool holds the non-ref entries in s_info order.
-__device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {
+// (ridx, cls: the vertex's ref index and class, which the caller already holds in a walk record)
+__device__ __forceinline__ bool sample_entry_rec(const DevImage& im, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t sid, uint32_t& index) {
   if (sid == 0) {
-    if (!im.v_ridx[v]) return false;
-    index = im.v_ridx[v];
+    if (!ridx) return false;
+    index = ridx;
     return true;
   }
-  const uint64_t b = im.v_car_begin[v];
   if (im.use_bv) {
-    const uint64_t* row = im.class_rows + (uint64_t)im.v_class[v] * im.wpc;
+    const uint64_t* row = im.class_rows + (uint64_t)cls * im.wpc;
     const uint32_t w = sid >> 6, bit = sid & 63;
     const uint64_t word = row[w];
     if (!((word >> bit) & 1)) return false;
     uint32_t rank = __popcll(word & ((1ULL << bit) - 1));
     for (uint32_t i = 0; i < w; ++i) rank += __popcll(row[i]);
     rank -= (uint32_t)(row[0] & 1);  // the ref entry is not part of the pool
-    index = im.car_index[b + rank];
+    index = im.car_index[im.v_car_begin[v] + rank];
     return true;
   }
+  const uint64_t b = im.v_car_begin[v];
   for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
     if (im.car_sid[b + i] == sid) { index = im.car_index[b + i]; return true; }
   return false;
+}
+__device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {
+  return sample_entry_rec(im, v, im.v_ridx[v], im.use_bv ? im.v_class[v] : 0u, sid, index);
 }
 
 // get_neighbor_vertex (variant_graph.h:1402-1451): first out-neighbour holding the sample, else the ref
 // neighbour with the smallest ref index; 0 = none (the path iterator is done)
 __device__ __forceinline__ uint32_t next_on_path(const DevImage& im, uint32_t cur, uint32_t sid) {
   uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
-  for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
-    const uint32_t n = im.col[e];
-    if (sid != 0 && vertex_has_sample(im, n, sid)) return n;
-    const uint32_t nr = im.v_ridx[n];
-    if (nr && min_idx > nr) { nxt = n; min_idx = nr; }
+  const uint4 wc = im.w_vertex[2 * (uint64_t)cur];   // {row_begin, degree, ..}
+  for (uint32_t e = wc.x; e < wc.x + wc.y; ++e) {
+    const WalkEdge ed = walk_edge(im, e);
+    if (sid != 0 && record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) return ed.nbr;
+    if (ed.ridx && min_idx > ed.ridx) { nxt = ed.nbr; min_idx = ed.ridx; }
   }
   return nxt;
 }
@@ -1623,11 +1656,12 @@ __device__ __forceinline__ uint32_t prev_vertex_with_sample(const DevImage& im, 
     const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
     if (rank <= 1) { ref_pos = 1; v_find = v; sample_pos = im.v_ridx[v]; break; }
     bool found = false;
-    for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e) {
-      const uint32_t n = im.col[e];
-      if (im.v_ridx[n]) ref_pos = im.v_ridx[n];
+    const uint4 wv = im.w_vertex[2 * (uint64_t)v];   // {row_begin, degree, ..}
+    for (uint32_t e = wv.x; e < wv.x + wv.y; ++e) {
+      const WalkEdge ed = walk_edge(im, e);
+      if (ed.ridx) ref_pos = ed.ridx;
       uint32_t idx;
-      if (sample_entry(im, n, sid, idx)) { v_find = n; found = true; sample_pos = idx; }
+      if (sample_entry_rec(im, ed.nbr, ed.ridx, ed.cls, sid, idx)) { v_find = ed.nbr; found = true; sample_pos = idx; }
       rank = rank ? rank - 1 : 0;  // unsigned wrap in the reference: clamped
     }
     if (found) break;
@@ -1683,32 +1717,40 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
       sample_pos -= seq_len;
     }
     uint32_t cur = closest_v;
-    uint32_t cur_ref_off = 0, cur_ref_len = 0;
+    uint32_t cur_ref_v = kNone;
     bool done = false;
     const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
     const uint64_t cb = EMIT ? r.car_base[q] : 0;
     while (!done) {
       if (sample_pos >= y) break;
-      const uint32_t l = im.v_len[cur];
+      const WalkVertex wc = walk_vertex(im, cur);   // one record per vertex, one per neighbour; ONE pass over the edges
+      const uint32_t l = wc.len;
       uint64_t next_ref_pos = ref_pos + l;
-      uint32_t next_ref_off = 0, next_ref_len = 0;
-      for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
-        const uint32_t n = im.col[e];
-        if (im.v_ridx[n]) { next_ref_pos = im.v_ridx[n]; next_ref_off = im.v_off[n]; next_ref_len = im.v_len[n]; }
+      uint32_t next_ref_v = kNone;                  // the last ref neighbour (its sequence becomes cur_ref)
+      uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;      // get_neighbor_vertex (next_on_path) in the same pass
+      bool nxt_by_sample = false;
+      for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+        const WalkEdge ed = walk_edge(im, e);
+        if (ed.ridx) { next_ref_pos = ed.ridx; next_ref_v = ed.nbr; }
+        if (!nxt_by_sample) {
+          if (sid != 0 && record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { nxt = ed.nbr; nxt_by_sample = true; }
+          else if (ed.ridx && min_idx > ed.ridx) { nxt = ed.nbr; min_idx = ed.ridx; }
+        }
       }
       uint32_t sidx = 0;
-      if (sample_pos > x && sample_entry(im, cur, sid, sidx)) {
+      if (sample_pos > x && sample_entry_rec(im, cur, wc.ridx, wc.cls, sid, sidx)) {
         uint64_t pos;
         uint32_t ro, rl, ao, al;
         if (ref_pos == next_ref_pos) {        // insertion
-          pos = ref_pos; ro = 0; rl = 0; ao = im.v_off[cur]; al = l;
-        } else if (im.v_ridx[cur]) {          // deletion: ref = sequence of find(ref_pos - 1)
+          pos = ref_pos; ro = 0; rl = 0; ao = wc.off; al = l;
+        } else if (wc.ridx) {                 // deletion: ref = sequence of find(ref_pos - 1)
           const uint32_t fv = im.rp_vid[slot_of_find(im, ref_pos - 1)];
           pos = sidx; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
-        } else {                              // substitution
-          pos = sidx; ro = cur_ref_off; rl = cur_ref_len; ao = im.v_off[cur]; al = l;
+        } else {                              // substitution: ref = sequence of the previous step's last ref neighbour
+          pos = sidx; ro = 0; rl = 0; ao = wc.off; al = l;
+          if (cur_ref_v != kNone) { const WalkVertex wr = walk_vertex(im, cur_ref_v); ro = wr.off; rl = wr.len; }
         }
-        const uint32_t c = im.v_ncar[cur];
+        const uint32_t c = wc.ncar;
         if (EMIT) {
           const uint64_t a = a0 + nvar;
           r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
@@ -1726,10 +1768,9 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
         nvar++; ncar += pad_car(c); ncar_kept += c;
         // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
       }
-      cur_ref_off = next_ref_off; cur_ref_len = next_ref_len;
+      cur_ref_v = next_ref_v;
       ref_pos = next_ref_pos;
       sample_pos += l;
-      const uint32_t nxt = next_on_path(im, cur, sid);
       if (nxt == 0) done = true;
       cur = nxt;
     }
@@ -1816,13 +1857,14 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
   else {
     bool record = false, done = false;
     while (!done) {
-      const uint32_t off = im.v_off[cur];
-      const uint64_t l = im.v_len[cur];
+      const WalkVertex wc = walk_vertex(im, cur);
+      const uint32_t off = wc.off;
+      const uint64_t l = wc.len;
       int st;
       if (MODE == 2) {
         uint64_t next_ref_pos = ref_pos + l;
-        for (uint32_t e = im.row_ptr[cur]; e < im.row_ptr[cur + 1]; ++e) {
-          const uint32_t nr = im.v_ridx[im.col[e]];
+        for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+          const uint32_t nr = walk_edge(im, e).ridx;
           if (nr) { next_ref_pos = nr; break; }  // the FIRST ref neighbour here (query.h:150-153)
         }
         st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, l, ref_pos, next_ref_pos, x, y);
