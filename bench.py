@@ -181,9 +181,14 @@ def main():
     info = vs.info()
     regions = make_regions(w, rank, nreg)
     region_base = rank * nreg
+    # the batch's input is resident in HBM before the timed region starts (uploaded once); VS_BENCH_HOST_REGIONS=1 hands
+    # the host array over in every step instead (the PCIe-inclusive rate quoted in DESIGN.md, never `value`)
+    host_regions = os.environ.get("VS_BENCH_HOST_REGIONS") == "1"
+    regions_dev = torch.from_numpy(regions.astype(np.int64)).to(torch.device("cuda", local_rank)).contiguous()
+    torch.cuda.synchronize()
 
     def step():
-        res = vs.get_var_in_ref(regions)
+        res = vs.get_var_in_ref(regions) if host_regions else vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
         gathered = None
         if use_dist:
             # every rank answers nreg regions: the record counts are known without asking
@@ -367,7 +372,8 @@ def main():
             "config": {
                 "workload": f"{args.workload}: {w['ref_length']} bp, {w['num_variants']} sites, "
                             f"{w['num_samples']} samples, {nreg} random {w['region_len']} bp regions per GPU, "
-                            "query type 6 (get_var_in_ref), index + regions resident in HBM, results left in HBM",
+                            "query type 6 (get_var_in_ref), index + regions resident in HBM, results left in HBM"
+                            + (" [regions handed over as a host array in every step]" if host_regions else ""),
                 "regions_per_gpu": nreg, "region_len": w["region_len"],
                 "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
                 "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),

@@ -115,6 +115,9 @@ int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, u
  * path: one kernel for the whole query, or -- while the handle's resident query server is alive -- no launch at all
  * (VS_NO_SERVER=1 in the environment keeps it to one launch per call). */
 int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out);
+/* The same with the regions already in DEVICE memory of the handle's GPU (e.g. produced there, or uploaded once and
+ * queried repeatedly): no host buffer crosses PCIe inside the call.  Always the batch pipeline, whatever n. */
+int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, uint64_t n, vs_result** out);
 /* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
                                vs_result** out);

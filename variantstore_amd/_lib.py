@@ -69,6 +69,7 @@ SYMBOLS = {
     "vs_index_export_plain": (C.c_int, [_P, C.c_char_p]),
     "vs_index_out_neighbors": (C.c_int64, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64]),
     "vs_query_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(_P)]),
+    "vs_query_var_in_ref_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
     "vs_query_sample_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "vs_query_samples_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(_P)]),
     "vs_query_closest_var": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(_P)]),

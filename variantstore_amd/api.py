@@ -272,6 +272,14 @@ class VariantStore:
             raise VariantStoreError(rc, "vs_query_var_in_ref")
         return QueryResult(self, h)
 
+    def get_var_in_ref_device(self, device_ptr, n) -> QueryResult:
+        """Query type 6 over n (pos_x, pos_y) uint64 pairs that already live in this GPU's memory (`device_ptr`: an
+        address, e.g. `tensor.data_ptr()` of a contiguous int64/uint64 CUDA tensor of shape (n, 2))."""
+        h = C.c_void_p()
+        _check(self._lib.vs_query_var_in_ref_device(self._h, C.c_void_p(int(device_ptr)), int(n), C.byref(h)),
+               "vs_query_var_in_ref_device")
+        return QueryResult(self, h)
+
     def get_sample_var_in_ref(self, regions, sample) -> QueryResult:
         """Query type 4 for one sample over a batch of regions (query.h:618-729)."""
         arr, ptr, n = _regions_array(regions)

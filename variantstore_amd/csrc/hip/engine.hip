@@ -381,7 +381,7 @@ static size_t fill_lds_bytes(const vs_index* idx) {
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
                           const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
-                          int walk_mode = 4) {
+                          int walk_mode = 4, bool regions_on_device = false) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
   uint32_t* dsids = nullptr;
   DevResult& d = r->d;
@@ -397,7 +397,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
-  if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
+  if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
   if (sample_ids && n) {
     VS_TRY(ralloc(r, n, &dsids));
     HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
@@ -1096,6 +1096,19 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
     }
   }
   if (rc == 1) rc = run_var_in_ref(idx, regions, n, r);
+  if (rc != VS_OK) return drop_result(r, rc);
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, uint64_t n, vs_result** out) {
+  if (!idx || !out || (n && !device_regions)) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  const int rc = run_var_in_ref(idx, device_regions, n, r, kNone, nullptr, 0, nullptr, 4, /*regions_on_device=*/true);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
