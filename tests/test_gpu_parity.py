@@ -282,7 +282,7 @@ def test_list_threshold_sweep(list_max, n_samples, tmp_path, monkeypatch):
     if list_max * 4 < n_samples:
         assert (cc > list_max).sum() > 20, "the row path must be exercised"
     assert _compare_t6(vs, orc, regions) == len(regions)
-    assert _compare_t6(vs, orc, regions[:3]) == 3          # latency path (8-slot tasks)
+    assert _compare_t6(vs, orc, regions[:3]) == 3          # latency path (4-slot tasks)
     name = vs.sample_name(1 + n_samples // 2)
     assert _compare_t4(vs, orc, regions[:12], name) == 12
     vs.close()

@@ -716,7 +716,7 @@ static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64
 }
 
 // ---- resident query server (kernels.hip.h: k_query_server) ----
-constexpr unsigned kSrvBlocks = 16;                 // 64 waves share a request's 8-slot tasks
+constexpr unsigned kSrvBlocks = 16;                 // 64 waves share a request's 4-slot tasks
 constexpr uint64_t kSrvMaxTasks = 2 * kSrvBlocks * 4;   // larger requests are better off with a launch sized for them
 constexpr uint64_t kSrvLifeTicks = 2000000;         // device clock, 100 MHz: 20 ms, then the kernel leaves by itself
 constexpr uint64_t kSrvIdleTicks = 100000;          // ... or 1 ms after the last request
@@ -1090,7 +1090,7 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
   int rc = 1;
   if (n > 0 && n <= 64) {
     rc = run_small_type6(idx, regions, n, r);
-    if (rc == 1) {  // speculative buffers too small
+    if (rc == 1) {  // the device asked for more than the host had sized (host and device disagree: should not happen)
       release_bufs(idx, r->bufs);
       r->d = DevResult{};
     }

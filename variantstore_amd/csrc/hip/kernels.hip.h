@@ -500,22 +500,24 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 }
 
 // ---------------------------------------------------------------------------
-// Carrier expansion (k_fill_carriers).  One wave owns CH consecutive variant slots (64; 8 in latency launches);
-// every lane first gathers the metadata of "its" slot, then the wave works through the task in two regimes:
+// Carrier expansion (expand_task: k_fill_carriers, k_query_small, k_query_server).  One wave owns CH consecutive
+// variant slots (64; 4 in latency launches); every lane first gathers the parameters of "its" slot, then the wave
+// works through the task:
 //
-//  sparse  (<= kSparseMax carriers, and every short list of an explicit-id cohort): LANE PER CARRIER.  The
-//          carriers of all sparse variants of the task form one list; a DPP prefix sum over the counts gives
-//          every variant its slice, a lane takes list entry e, finds its variant by bisection over the 64
-//          offsets (LDS), and expands that one carrier (id from the class's decoded id list or the explicit id
-//          pool, genotype nibble from the pool).
-//  others  WAVE PER VARIANT.  WIDE=false (cohorts of at most 4032 samples): LANE PER SLICE -- 64 lanes x wpc bits
-//          is the whole class row, every lane peels its own wpc bits into a 16-bit id list in LDS at its
-//          prefix-sum position; the list leaves in 1 KiB-aligned blocks, one 16-byte store per lane (8 carriers
-//          of 16 bits: id | gt << 13), genotypes merged from the raw nibble stream on the way out.  The next
-//          variant's row and nibbles are requested before the current one is expanded.
-//          WIDE=true (wider cohorts): the round-1 code -- medium variants lane per row word with an LDS id list,
-//          dense ones bit per lane (exec = row word, v_mbcnt rank) through a 512-entry LDS ring, 32-bit carrier
-//          words (id | gt << 29); rows wider than one wave take the out-of-line generic path.
+//  cohorts of at most 4032 samples with class rows (WIDE=false, use_bv) -- the main case:
+//    listed  (<= list_max = 640 carriers): LANE PER GROUP of 8 carriers from the class's decoded 16-bit id list; the
+//            groups of all listed variants of the task form one list, a lane finds its variant by bisection over the
+//            64 offsets (LDS) and produces one finished 16-byte arena group.
+//    denser  WAVE PER VARIANT, two rounds of half a row: every lane peels its own ceil(wpc / 2) bits into a 16-bit id
+//            list in LDS at its prefix-sum position; the complete groups leave in 128-byte-aligned blocks, one
+//            16-byte store per lane (8 carriers of 16 bits: id | gt << 13), genotypes merged from the raw nibble
+//            stream on the way out.  Rows are requested two variants ahead, nibbles one.
+//  cohorts above 4032 samples (WIDE=true) and explicit-id cohorts -- the round-1 code:
+//    sparse  (<= kSparseMax carriers, and every short list of an explicit-id cohort): LANE PER CARRIER (id from the
+//            class's decoded 32-bit id list or the explicit id pool, genotype nibble from the pool).
+//    others  WAVE PER VARIANT: medium variants lane per row word with an LDS id list, dense ones bit per lane (exec =
+//            row word, v_mbcnt rank) through a 512-entry LDS ring, 32-bit carrier words (id | gt << 29); rows wider
+//            than one wave take the out-of-line generic path.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSparseMax = 64;
 constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
@@ -999,7 +1001,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
 // ---------------------------------------------------------------------------
 // Latency path: a batch of at most 64 regions in ONE launch.  Every wave works the region bounds out for itself (lane
 // q takes region q: the same dozen loads in every wave, L2 hits after the first), a wave prefix sum lays the slot,
-// arena and task offsets out, and the wave then takes 8-slot tasks straight from the site table: it writes their
+// arena and task offsets out, and the wave then takes 4-slot tasks straight from the site table: it writes their
 // variant headers and expands their carriers (expand_task) -- no header kernel, no kernel-to-kernel dependency, no
 // host round trip.  The regions travel in the kernel arguments.  The result buffers were sized on the host from the
 // same arithmetic (engine.hip: host_region_size); should the device ever need more it writes nothing and says so.
