@@ -303,6 +303,14 @@ static int build_device_image(vs_index* idx) {
     if (G) hipLaunchKernelGGL(k_pad_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, (const uint32_t*)d.s_ncar, (uint32_t*)padded, G);
     VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)padded, G, d.s_carpre, &scratch.bufs));
     VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)d.s_ncar, G, d.s_kpre, &scratch.bufs));
+    {
+      uint64_t *rc = nullptr, *rk = nullptr;
+      VS_TRY(alloc_image(idx, im.P + 1, &rc));
+      VS_TRY(alloc_image(idx, im.P + 1, &rk));
+      hipLaunchKernelGGL(k_slot_prefixes, dim3((unsigned)((im.P + 256) / 256)), dim3(256), 0, idx->stream, d, rc, rk);
+      HIP_TRY(hipGetLastError());
+      d.rp_carpre = rc; d.rp_kpre = rk;
+    }
     idx->h_carpre.resize(G + 1);
     HIP_TRY(hipMemcpyAsync(idx->h_carpre.data(), d.s_carpre, (G + 1) * 8, hipMemcpyDeviceToHost, idx->stream));
   }
@@ -753,11 +761,12 @@ static int server_ensure(vs_index* idx) {
   const uint32_t gt_words = fill_gt_words(idx);
   const size_t lds_bytes = fill_lds_bytes(idx);
   volatile uint64_t* resp = idx->pinned + vs_index::kPinSrvResp;
+  const unsigned srv_blocks = getenv("VS_SRV_BLOCKS") ? (unsigned)atoi(getenv("VS_SRV_BLOCKS")) : kSrvBlocks;   // tuning aid
   if (idx->d.wpc <= 63)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<false>), dim3(kSrvBlocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<false>), dim3(srv_blocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
                        (const ServerRequest*)rq, idx->srv_counter, resp, idx->srv_seq, gt_words, kSrvLifeTicks, kSrvIdleTicks);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<true>), dim3(kSrvBlocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<true>), dim3(srv_blocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
                        (const ServerRequest*)rq, idx->srv_counter, resp, idx->srv_seq, gt_words, kSrvLifeTicks, kSrvIdleTicks);
   HIP_TRY(hipGetLastError());
   idx->srv_alive = true;

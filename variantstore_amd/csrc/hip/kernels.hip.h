@@ -78,6 +78,8 @@ struct DevImage {
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
   const uint32_t* rp_sus_prefix;  // [P+1] suspicious sites before each ref-path slot's first site (no bisection per query)
+  const uint64_t* rp_carpre;      // [P+1] s_carpre[rp_cand_prefix[slot]]: arena prefix at a slot's first site
+  const uint64_t* rp_kpre;        // [P+1] s_kpre likewise
   uint32_t n_sus, has_car_index;
   uint32_t list_max, pad2_;
 };
@@ -214,6 +216,15 @@ __global__ void __launch_bounds__(256) k_build_sites(DevImage im, uint64_t slot_
   }
 }
 
+// per-slot copies of the two site-table prefixes (one memory level less in every region-bounds computation)
+__global__ void __launch_bounds__(256) k_slot_prefixes(DevImage im, uint64_t* rp_carpre, uint64_t* rp_kpre) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > im.P) return;
+  const uint32_t g = im.rp_cand_prefix[i];
+  rp_carpre[i] = im.s_carpre[g];
+  rp_kpre[i] = im.s_kpre[g];
+}
+
 // nearest earlier site with the same (pos, alt); positions are sorted up to an
 // off-by-one (an insertion reports end-1, everything else end), so the backward
 // scan stops at the first site whose pos < p-1.
@@ -240,11 +251,14 @@ __global__ void __launch_bounds__(256) k_mark_dups(DevImage im) {
 struct RegionBounds {
   uint32_t g0, g1;   // site range [g0, g1)
   uint8_t flags;
+  uint64_t pre0;     // arena prefix at g0 (s_carpre[g0]), padded arena entries and reported carriers of the range --
+  uint64_t npad;     //   read through per-slot copies (rp_carpre / rp_kpre) at the same memory level as g0 and g1,
+  uint64_t nkept;    //   not one level later through the site table
 };
 // Index::is_empty (index.h:150-166), Index::find(x) (index.h:119-133) and the stop rule of the walk (query.h:312).
 // Written for memory-level parallelism: both ranks are requested together, every table is read on a clamped index
 // whether or not the reference's early-outs fire (they select the result at the end), so a region costs four
-// dependent memory levels -- ranks; select + slots; branch and dedup prefixes; (callers) arena prefixes.
+// dependent memory levels -- ranks; select + slots; branch, dedup and arena prefixes of the two slots.
 __device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uint64_t x, uint64_t y) {
   const RankLoads lx = rank1_issue(im, x), ly = rank1_issue(im, y - 1);   // y == 0 wraps and is clamped: x < y fails then
   const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
@@ -266,14 +280,15 @@ __device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uin
   uint32_t g0 = im.rp_cand_prefix[s0], g1 = im.rp_cand_prefix[s1];
   // can the "already seen" rule fire inside [g0,g1)?  (g0, g1 are slot boundaries: the list range is tabulated)
   uint32_t lo = im.rp_sus_prefix[s0], hi = im.rp_sus_prefix[s1];
+  uint64_t pre0 = im.rp_carpre[s0], npad = im.rp_carpre[s1] - pre0, nkept = im.rp_kpre[s1] - im.rp_kpre[s0];
   const bool walk = !invalid && !empty && x < y;
-  if (!walk) { g0 = 0; g1 = 0; lo = 0; hi = 0; }
+  if (!walk) { g0 = 0; g1 = 0; lo = 0; hi = 0; pre0 = 0; npad = 0; nkept = 0; }
   uint8_t fl = invalid ? kRegionInvalid : (empty ? kRegionEmpty : 0);
   for (uint32_t k = lo; k < hi; ++k) {
     const uint32_t pv = im.sus_prev[k];
     if (pv == kNone || pv >= g0) { fl |= kRegionSlow; break; }
   }
-  return RegionBounds{g0, g1, fl};
+  return RegionBounds{g0, g1, fl, pre0, npad, nkept};
 }
 
 __device__ __forceinline__ void region_bounds(const DevImage& im, const DevResult& r, uint64_t q) {
@@ -281,7 +296,7 @@ __device__ __forceinline__ void region_bounds(const DevImage& im, const DevResul
   r.q_flags[q] = b.flags;
   r.q_g0[q] = b.g0;
   r.q_nvar[q] = b.g1 - b.g0;
-  r.q_ncar[q] = im.s_carpre[b.g1] - im.s_carpre[b.g0];
+  r.q_ncar[q] = b.npad;
 }
 
 __global__ void __launch_bounds__(256) k_region_bounds(DevImage im, DevResult r) {
@@ -1051,14 +1066,9 @@ __device__ __forceinline__ uint32_t small_batch_wave(const DevImage& im, const D
   constexpr uint32_t CH = kFillChunkSmall;
   const uint32_t lane = threadIdx.x & 63;
   // ---- bounds of region `lane`, offsets of all regions ----
-  RegionBounds b{0, 0, 0};
-  uint64_t pre0 = 0, npad = 0, nkept = 0;
-  if (lane < n) {
-    b = region_bounds_of(im, x, y);
-    pre0 = im.s_carpre[b.g0];
-    npad = im.s_carpre[b.g1] - pre0;
-    nkept = im.s_kpre[b.g1] - im.s_kpre[b.g0];
-  }
+  RegionBounds b{0, 0, 0, 0, 0, 0};
+  if (lane < n) b = region_bounds_of(im, x, y);
+  const uint64_t pre0 = b.pre0, npad = b.npad, nkept = b.nkept;
   const uint32_t nv = b.g1 - b.g0, ntask = (nv + CH - 1) / CH;
   const uint64_t vend = wave_inclusive_scan64(nv, lane), cend = wave_inclusive_scan64(npad, lane);
   const uint32_t tend = wave_inclusive_scan(ntask);
