@@ -257,7 +257,7 @@ struct RegionBounds {
 };
 // Index::is_empty (index.h:150-166), Index::find(x) (index.h:119-133) and the stop rule of the walk (query.h:312).
 // Written for memory-level parallelism: both ranks are requested together, every table is read on a clamped index
-// whether or not the reference's early-outs fire (they select the result at the end), so a region costs four
+// whether or not the reference's early-outs fire (they select the result at the end), so a region costs three
 // dependent memory levels -- ranks; select + slots; branch, dedup and arena prefixes of the two slots.
 __device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uint64_t x, uint64_t y) {
   const RankLoads lx = rank1_issue(im, x), ly = rank1_issue(im, y - 1);   // y == 0 wraps and is clamped: x < y fails then
