@@ -59,7 +59,7 @@ struct DevImage {
   const uint32_t* col;
   const uint32_t *v_off, *v_len, *v_ridx, *v_class, *v_ncar, *v_nri;
   const uint4* w_vertex;   // walk records, 2 x uint4 per vertex {row_begin, degree, ref index, offset | length, class, #carriers, 0}
-  const uint4* w_edge;     // 1 x uint4 per CSR entry {neighbour, its ref index, its class, 0}
+  const uint4* w_edge;     // 2 x uint4 per CSR entry {neighbour, its ref index, its class, its row_begin | degree, offset, length, #carriers}
   const uint32_t* v_src;   // per vertex: group index of its class's 16-bit id list (<= list_max carriers) or its class id (row)
   const uint64_t* v_car_begin;
   const uint64_t* class_rows;
@@ -1315,7 +1315,13 @@ __device__ __forceinline__ WalkVertex walk_vertex(const DevImage& im, uint32_t v
 }
 struct WalkEdge { uint32_t nbr, ridx, cls; };
 __device__ __forceinline__ WalkEdge walk_edge(const DevImage& im, uint32_t e) {
-  const uint4 a = im.w_edge[e];
+  const uint4 a = im.w_edge[2 * (uint64_t)e];
+  return WalkEdge{a.x, a.y, a.z};
+}
+// the whole edge record: the neighbour and the neighbour's own vertex record (stepping onto it needs no look-up)
+__device__ __forceinline__ WalkEdge walk_edge_full(const DevImage& im, uint32_t e, WalkVertex& nv) {
+  const uint4 a = im.w_edge[2 * (uint64_t)e], b = im.w_edge[2 * (uint64_t)e + 1];
+  nv = WalkVertex{a.w, b.x, a.y, b.y, b.z, a.z, b.w};
   return WalkEdge{a.x, a.y, a.z};
 }
 // vertex_has_sample on what a record already holds (class rows; explicit-id cohorts fall back to the carrier pool)
@@ -1383,22 +1389,24 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       bool done = false;
       const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
       const uint64_t cb = EMIT ? r.car_base[q] : 0;
+      WalkVertex wc = walk_vertex(im, cur);   // afterwards the record of a vertex arrives with the edge the walk takes to it
       while (!done) {
         if (ref_pos >= y) break;
-        const WalkVertex wc = walk_vertex(im, cur);   // one record instead of seven scattered fields
         // (jumping over runs of forced, empty ref-path vertices was tried: in SNP-dense cohorts such runs are one
         //  vertex long -- the 1-bp ref allele between two branching nodes -- and the two extra look-ups cost more)
         uint64_t next_ref_pos = ref_pos + wc.len;
         uint32_t next_ref_v = kNone;   // the last ref neighbour: its sequence becomes cur_ref (read only when a substitution is emitted)
         uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+        WalkVertex wn{};               // vertex record of nxt
         bool nxt_by_sample = false;
         for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
-          const WalkEdge ed = walk_edge(im, e);     // neighbour, its ref index and its class in one record
+          WalkVertex nv;
+          const WalkEdge ed = walk_edge_full(im, e, nv);   // neighbour, its ref index, its class, and its own record
           const uint32_t n = ed.nbr, nr = ed.ridx;
           if (nr) { next_ref_pos = nr; next_ref_v = n; }  // last ref neighbour wins
           if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
-            if (sid != 0 && record_has_sample(im, n, nr, ed.cls, sid)) { nxt = n; nxt_by_sample = true; }
-            else if (nr && min_idx > nr) { nxt = n; min_idx = nr; }
+            if (sid != 0 && record_has_sample(im, n, nr, ed.cls, sid)) { nxt = n; wn = nv; nxt_by_sample = true; }
+            else if (nr && min_idx > nr) { nxt = n; wn = nv; min_idx = nr; }
           }
         }
         if (ref_pos >= x && record_has_sample(im, cur, wc.ridx, wc.cls, sid)) {
@@ -1443,6 +1451,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
         ref_pos = next_ref_pos;
         if (nxt == 0) done = true;  // no neighbour: the path iterator is done
         cur = nxt;
+        wc = wn;
       }
     }
   }

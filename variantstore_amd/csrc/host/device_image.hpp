@@ -77,10 +77,12 @@ struct HostImage {
   std::vector<uint32_t> v_src;
   // Walk records (query types 4, 5, 2, 3 step along a sample's path vertex by vertex): everything one step reads about
   // the current vertex in ONE 32-byte record {row_begin, degree, ref index, offset, length, class, #carriers, 0}, and
-  // everything it reads about a neighbour in ONE 16-byte edge record {neighbour, its ref index, its class, 0} in CSR
-  // order -- three or four memory accesses per step instead of a dozen scattered 4-byte reads.
+  // everything it reads about a neighbour in ONE 32-byte edge record in CSR order {neighbour, its ref index, its class,
+  // its row_begin | its degree, offset, length, #carriers}: the first half answers the tests of a step, the second
+  // half IS the neighbour's vertex record, so stepping onto it needs no further look-up -- two or three memory
+  // accesses per step instead of a dozen scattered 4-byte reads.
   std::vector<uint32_t> w_vertex;   // 8 words per vertex
-  std::vector<uint32_t> w_edge;     // 4 words per CSR entry
+  std::vector<uint32_t> w_edge;     // 8 words per CSR entry
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
   std::vector<uint32_t> car_index;   // sample-coordinate index per carrier record (query types 2/3/5); may be empty
@@ -316,11 +318,12 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     w[0] = im.row_ptr[v]; w[1] = im.row_ptr[v + 1] - im.row_ptr[v]; w[2] = im.v_ridx[v]; w[3] = im.v_off[v];
     w[4] = im.v_len[v]; w[5] = im.v_class[v]; w[6] = im.v_ncar[v];
   }
-  im.w_edge.assign(im.E * 4, 0);
+  im.w_edge.assign(im.E * 8, 0);
   for (uint64_t e = 0; e < im.E; ++e) {
     const uint32_t n = im.col[e];
-    uint32_t* w = &im.w_edge[e * 4];
-    w[0] = n; w[1] = im.v_ridx[n]; w[2] = im.v_class[n];
+    uint32_t* w = &im.w_edge[e * 8];
+    w[0] = n; w[1] = im.v_ridx[n]; w[2] = im.v_class[n]; w[3] = im.row_ptr[n];
+    w[4] = im.row_ptr[n + 1] - im.row_ptr[n]; w[5] = im.v_off[n]; w[6] = im.v_len[n]; w[7] = im.v_ncar[n];
   }
 }
 
