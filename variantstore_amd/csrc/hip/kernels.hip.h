@@ -649,13 +649,59 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
   asm volatile("" : "+s"(m_lo), "+s"(m_hi));
   const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
-  if (explicit_ids && cnt > kSparseMax) {
-    // long lists are rare in this mode: a plain copy, lane per variant (short ones go lane per carrier below)
-    for (uint32_t k = 0; k < cnt; ++k) {
-      const uint64_t c = gt0 + k;
-      const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
-      carriers[cb + k] = (CT)(im.car_sid[c] | (nib << kGtShift));
+  if (explicit_ids) {
+    // Explicit-id cohorts (somatic-like: a handful of carriers per variant, ids in the carrier pool): LANE PER GROUP of
+    // 8 carriers for every variant whatever its size, exactly like the list path below -- the groups of the task form
+    // one list, a lane finds its variant by bisection, loads the 8 ids (32 bytes of car_sid) and their 32 genotype bits
+    // and stores one finished group (16 bytes of 16-bit words, or 32 bytes of 32-bit words above 4032 samples).  The
+    // last group of a variant reads up to 7 ids of the next one: they land in the padding the range owns.
+    uint32_t* s_off = lds_wave;
+    const uint32_t c = cnt && !(ablate & 1) ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t L = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_off[L + step] <= e) L += step;
+        const uint32_t k8 = (e - s_off[L]) * kCarAlign;
+        const uint64_t g = s_gt0[L] + k8;                        // carrier record of the group's first entry
+        uint4 ia, ib;
+        __builtin_memcpy(&ia, im.car_sid + g, 16);
+        __builtin_memcpy(&ib, im.car_sid + g + 4, 16);
+        uint2 nw;
+        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
+        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        const uint32_t id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        CT* dst = carriers + (s_cb[L] + k8);
+        if constexpr (WIDE) {
+          uint4 lo, hi;
+          lo.x = id[0] | (((n >> 0) & 7u) << 29); lo.y = id[1] | (((n >> 4) & 7u) << 29);
+          lo.z = id[2] | (((n >> 8) & 7u) << 29); lo.w = id[3] | (((n >> 12) & 7u) << 29);
+          hi.x = id[4] | (((n >> 16) & 7u) << 29); hi.y = id[5] | (((n >> 20) & 7u) << 29);
+          hi.z = id[6] | (((n >> 24) & 7u) << 29); hi.w = id[7] | (((n >> 28) & 7u) << 29);
+          store_group_nt(reinterpret_cast<uint4*>(dst), lo);
+          store_group_nt(reinterpret_cast<uint4*>(dst) + 1, hi);
+        } else {
+          // (every word of car_sid is a valid sample id < 4032 or zero padding: 13 bits, nothing to mask)
+          uint4 v;
+          const uint32_t p0 = id[0] | (id[1] << 16), p1 = id[2] | (id[3] << 16), p2 = id[4] | (id[5] << 16), p3 = id[6] | (id[7] << 16);
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, p0));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, p1));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, p2));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, p3));
+          store_group_nt(reinterpret_cast<uint4*>(dst), v);
+        }
+      }
     }
+    return;
   }
 
   const bool lists = !WIDE && !explicit_ids;

@@ -309,6 +309,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   for (uint64_t c = 0; c < g.car_flags.size(); ++c)
     im.gt_nibbles[c >> 1] |= (uint8_t)((g.car_flags[c] & 7) << ((c & 1) * 4));
   im.car_sid = g.car_sid;
+  im.car_sid.resize(im.car_sid.size() + 8, 0);   // a group of 8 ids is read whole: the last variant's may run past its records
   im.car_index = g.car_index;
   im.seq_codes = g.seq;
 
