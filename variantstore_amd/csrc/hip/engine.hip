@@ -117,7 +117,7 @@ static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf
   int best = -1;
   for (size_t i = 0; i < idx->pool.size(); ++i)
     if (idx->pool[i].cap >= bytes && (best < 0 || idx->pool[i].cap < idx->pool[best].cap)) best = (int)i;
-  if (best >= 0 && idx->pool[best].cap <= 2 * bytes + (1 << 20)) {
+  if (best >= 0 && idx->pool[best].cap <= 2 * bytes + (256 << 10)) {   // never more than twice (+256 KiB) what was asked for
     DevBuf b = idx->pool[best];
     idx->pool.erase(idx->pool.begin() + best);
     *out = b.p;
