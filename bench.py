@@ -232,17 +232,17 @@ def main():
     car_word = 2 if info.num_samples <= 4032 else 4
     # Dominant kernel k_fill_carriers.  ALGORITHMIC BYTES of one launch = the bytes this kernel's data layout obliges it
     # to move: per variant slot 24 B of slot parameters (count, class, genotype offset, arena
-    # offset); per variant of at most list_max carriers its decoded 16-bit id list, rounded up to whole 16-byte groups,
-    # plus the 4-byte list offset; per denser variant its class bit row (W bytes); half a byte of genotype per carrier
+    # offset); per variant of at most list_max carriers its decoded id list, rounded up to whole groups of 8 entries;
+    # per denser variant its class bit row (W bytes); half a byte of genotype per carrier
     # in; one carrier word (2 B: id | gt << 13; 4 B above 4032 samples) per ARENA entry out -- every variant's range
     # is padded to a multiple of 8 entries and the kernel writes whole groups.  roofline.achieved = that / the
     # kernel's mean launch time, so roofline.frac can never exceed what the HBM pins carried.
     padded = (cc + 7) // 8 * 8
-    if info.list_max:
+    if info.use_bit_vector:
         listed = cc <= info.list_max
-        id_bytes = int((padded[listed] * 2 + 4).sum()) + int((~listed).sum()) * W
-    else:  # explicit sample ids (4 B per carrier record) or a cohort above 4032 samples (rows; lists up to 64 carriers)
-        id_bytes = int(4 * cc.sum()) if not info.use_bit_vector else int(np.where(cc <= 64, 4 * cc + 4, W).sum())
+        id_bytes = int((padded[listed] * car_word).sum()) + int((~listed).sum()) * W   # list entries are as wide as carrier words
+    else:  # explicit sample ids: 4 B per carrier record, read in whole groups of 8
+        id_bytes = int(4 * padded.sum())
     fill_bytes_layout = int(len(cc)) * 24 + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
     # SURVEY.md section 8(d)'s implementation-independent formula, restricted to the terms this kernel owns: per
     # variant its class row (W) + car_begin word (8), per carrier 3 genotype bits in and 4 + 1 bytes out.  It prices

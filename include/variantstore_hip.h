@@ -95,8 +95,8 @@ typedef struct {
   uint64_t device_bytes;     /* HBM held by the image */
   int device;
   uint64_t num_topology_keys; /* Graph::get_num_vertices(): vertices with an adjacency entry (graph.h:318-320) */
-  uint32_t list_max;         /* classes of at most this many carriers are expanded from decoded 16-bit id lists, denser
-                              * ones from their bit row (0 when the cohort has no such lists: explicit ids, > 4032 samples) */
+  uint32_t list_max;         /* classes of at most this many carriers are expanded from decoded id lists (16-bit entries up
+                              * to 4032 samples, else 32-bit), denser ones from their bit row; 0: explicit-id cohort   */
   uint32_t reserved_;
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);

@@ -1036,7 +1036,7 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   info->device = idx->device;
   info->num_topology_keys = 0;
   for (uint32_t v : idx->g.topo_val) info->num_topology_keys += v != 0;
-  info->list_max = (idx->im.use_bit_vector && idx->im.wpc <= 63) ? idx->im.list_max : 0;
+  info->list_max = idx->im.use_bit_vector ? idx->im.list_max : 0;
   info->reserved_ = 0;
   return VS_OK;
 }

@@ -527,14 +527,12 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 //            list in LDS at its prefix-sum position; the complete groups leave in 128-byte-aligned blocks, one
 //            16-byte store per lane (8 carriers of 16 bits: id | gt << 13), genotypes merged from the raw nibble
 //            stream on the way out.  Rows are requested two variants ahead, nibbles one.
-//  cohorts above 4032 samples (WIDE=true) and explicit-id cohorts -- the round-1 code:
-//    sparse  (<= kSparseMax carriers, and every short list of an explicit-id cohort): LANE PER CARRIER (id from the
-//            class's decoded 32-bit id list or the explicit id pool, genotype nibble from the pool).
-//    others  WAVE PER VARIANT: medium variants lane per row word with an LDS id list, dense ones bit per lane (exec =
-//            row word, v_mbcnt rank) through a 512-entry LDS ring, 32-bit carrier words (id | gt << 29); rows wider
-//            than one wave take the out-of-line generic path.
+//  explicit-id cohorts: LANE PER GROUP for every variant (ids from the carrier pool).
+//  cohorts above 4032 samples with class rows (WIDE=true): the list path with 32-bit entries and 32-bit carrier words
+//    (id | gt << 29); denser variants keep the round-1 row code -- medium ones lane per row word with an LDS id
+//    list, dense ones bit per lane (exec = row word, v_mbcnt rank) through a 512-entry LDS ring; rows wider than one
+//    wave take the out-of-line generic path.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kSparseMax = 64;
 constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
 constexpr uint32_t kFillChunkSmall = 4;      // latency launches (a handful of regions): more waves per region
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
@@ -644,7 +642,6 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
   // carrier word in the arena: 16 bits when every sample id fits 13 bits (the non-WIDE instantiation), else 32
   using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
-  constexpr uint32_t kGtShift = WIDE ? 29 : 13;
   CT* __restrict__ carriers = reinterpret_cast<CT*>(arena);
   uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
   asm volatile("" : "+s"(m_lo), "+s"(m_hi));
@@ -704,8 +701,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     return;
   }
 
-  const bool lists = !WIDE && !explicit_ids;
-  const uint32_t list_max = lists ? im.list_max : kSparseMax;
+  const bool lists = true;   // (explicit-id cohorts returned above) every class of at most list_max carriers has a decoded id list
+  const uint32_t list_max = im.list_max;
 
   // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
   //                  list phase runs in the shadow of that memory latency ----------------
@@ -738,7 +735,45 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   // genotype bits that go with them (one 8-byte load of the nibble pool), and stores one finished 16-byte group.
   // No bit row is read, nothing is staged, no lane idles: a rare variant is one group, a 640-carrier one is 80.
   // Two entries per lane and pass, so that four independent loads are in flight per lane.
-  if (lists) {
+  if constexpr (WIDE) {
+    // the same with 32-bit list entries and 32-bit carrier words (id | gt << 29): a group is two loads and two stores
+    uint32_t* s_off = lds_wave;
+    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint32_t* s_idb = s_off + 64;
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list_ids);
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t L = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_off[L + step] <= e) L += step;
+        const uint32_t k = e - s_off[L];
+        const uint64_t g = s_gt0[L] + (uint64_t)k * kCarAlign;
+        const uint4 ia = list_groups[2 * ((uint64_t)s_idb[L] + k)], ib = list_groups[2 * ((uint64_t)s_idb[L] + k) + 1];
+        uint2 nw;
+        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
+        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        uint4 lo, hi;
+        lo.x = ia.x | (((n >> 0) & 7u) << 29); lo.y = ia.y | (((n >> 4) & 7u) << 29);
+        lo.z = ia.z | (((n >> 8) & 7u) << 29); lo.w = ia.w | (((n >> 12) & 7u) << 29);
+        hi.x = ib.x | (((n >> 16) & 7u) << 29); hi.y = ib.y | (((n >> 20) & 7u) << 29);
+        hi.z = ib.z | (((n >> 24) & 7u) << 29); hi.w = ib.w | (((n >> 28) & 7u) << 29);
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(arena) + (s_cb[L] + (uint64_t)k * kCarAlign));
+        store_group_nt(dst, lo);
+        store_group_nt(dst + 1, hi);
+      }
+    }
+  } else {
     uint32_t* s_off = lds_wave;   // aliases the genotype staging area
     const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
     const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
@@ -794,41 +829,6 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
           store_group_nt(&arena_groups[dst1], v);
         }
-      }
-    }
-  } else {
-    // ---------------- explicit-id cohorts and cohorts above 4032 samples: sparse variants lane per CARRIER ----------------
-    // The carriers of all sparse variants of the chunk (typically ~120 of them, one to three per variant)
-    // form one list: an in-wave prefix sum over the counts gives every variant its slice, a lane takes list
-    // entry e, finds its variant by bisection over the 64 offsets (LDS), and expands that one carrier: id from
-    // the class's decoded id list (built once at load), genotype nibble from the pool.
-    uint32_t* s_off = lds_wave;   // aliases the genotype staging area
-    const bool sp = cnt > 0 && cnt <= kSparseMax && !(ablate & 1);
-    const uint32_t c = sp ? cnt : 0u;
-    const uint32_t incl = wave_inclusive_scan(c);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    if (total) {
-      // per-variant parameters go through LDS (not lane shuffles: in the last pass the owning lane may be idle)
-      uint32_t* s_idb = s_off + 64;
-      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
-      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
-      s_off[lane] = incl - c;
-      s_idb[lane] = (sp && !explicit_ids) ? im.cls_list_begin[cls] : 0u;
-      s_gt0[lane] = gt0;
-      s_cb[lane] = cb;
-      for (uint32_t e = lane; e < total; e += 64) {
-        uint32_t L = 0;
-#pragma unroll
-        for (uint32_t step = 32; step; step >>= 1)
-          if (s_off[L + step] <= e) L += step;
-        const uint32_t k = e - s_off[L];
-        const uint32_t idb_L = s_idb[L];
-        const uint64_t gt0_L = s_gt0[L];
-        const uint64_t cb_L = s_cb[L];
-        const uint64_t g = gt0_L + k;
-        const uint32_t nib = ((uint32_t)gtp[g >> 1] >> ((g & 1) * 4)) & 7u;
-        const uint32_t id = explicit_ids ? im.car_sid[g] : im.cls_list_ids[idb_L + k];
-        carriers[cb_L + k] = (CT)(id | (nib << kGtShift));
       }
     }
   }

@@ -30,7 +30,6 @@
 namespace vsamd {
 
 constexpr uint32_t VS_NONE = 0xFFFFFFFFu;
-constexpr uint32_t kSparseClassMax = 64;  // must equal kSparseMax in kernels.hip.h
 constexpr uint32_t kListGroup = 8;        // must equal kCarAlign in kernels.hip.h: carriers per 16-byte arena group
 constexpr uint32_t kListMaxDefault = 640; // classes with at most this many carriers also get a decoded 16-bit id list
 
@@ -64,12 +63,12 @@ struct HostImage {
   // sparse classes (<= kSparseClassMax carriers) also decoded once into explicit id lists, so the
   // expansion of a rare variant reads a few ids instead of scanning a whole bit row
   std::vector<uint32_t> cls_list_begin;  // [C+2]
-  std::vector<uint32_t> cls_list_ids;    // ascending sample ids (ref excluded), padded  (cohorts above 4032 samples)
-  // Cohorts of at most 4032 samples (16-bit carrier words): the lists are 16-bit, every list starts on a multiple of
-  // 8 entries (one 16-byte load = one arena group) and is zero-padded to the next one, and they exist for every class
-  // of at most list_max carriers -- k_fill_carriers expands those lane-per-GROUP straight from the list, only denser
-  // classes go through their bit row.
-  std::vector<uint16_t> cls_list16;
+  // Every class of at most list_max carriers is also decoded into an ascending id list (ref excluded); every list
+  // starts on a multiple of 8 entries (one arena group) and is zero-padded to the next one.  k_fill_carriers expands
+  // those variants lane-per-GROUP straight from the list, only denser classes go through their bit row.  Entries are
+  // 16-bit for cohorts of at most 4032 samples (16-bit carrier words: one 16-byte load per group), else 32-bit.
+  std::vector<uint32_t> cls_list_ids;    // cohorts above 4032 samples
+  std::vector<uint16_t> cls_list16;      // cohorts of at most 4032 samples
   uint32_t list_max = kListMaxDefault;
   // What k_fill_carriers needs to find a vertex's carrier ids, resolved once here so that the kernel has no dependent
   // look-up in front of its first id load: for a listed vertex (<= list_max carriers, 16-bit lists in use) the GROUP
@@ -287,13 +286,15 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
           }
           im.cls_list16.resize((im.cls_list16.size() + kListGroup - 1) / kListGroup * kListGroup, 0);
         }
-      } else {
+      } else {   // cohorts above 4032 samples: the same lists with 32-bit entries (a group of 8 = two 16-byte loads)
+        if (im.cls_list_ids.size() > 0xFFFFFFF0ull - im.num_samples) throw std::runtime_error("decoded class lists exceed 2^32 entries");
         im.cls_list_begin[c] = (uint32_t)im.cls_list_ids.size();
-        if (pc <= kSparseClassMax) {
+        if (pc <= im.list_max) {
           for (uint32_t w = 0; w < im.wpc; ++w) {
             uint64_t x = w == 0 ? (row[w] & ~1ULL) : row[w];
             while (x) { im.cls_list_ids.push_back(w * 64 + __builtin_ctzll(x)); x &= x - 1; }
           }
+          im.cls_list_ids.resize((im.cls_list_ids.size() + kListGroup - 1) / kListGroup * kListGroup, 0);
         }
       }
     }
@@ -302,7 +303,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   im.cls_list_ids.resize(im.cls_list_ids.size() + 8, 0);  // 16-byte reads may run past the last list
   im.cls_list16.resize(im.cls_list16.size() + 8, 0);
   im.v_src = im.v_class;
-  if (g.use_bit_vector && narrow)
+  if (g.use_bit_vector)
     for (uint64_t v = 0; v < V; ++v)
       if (im.v_ncar[v] <= im.list_max) im.v_src[v] = im.cls_list_begin[im.v_class[v]] / kListGroup;
   im.gt_nibbles.assign((g.car_flags.size() + 1) / 2 + 32, 0);  // windowed 64-bit reads run up to 24 bytes past a list
