@@ -486,7 +486,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, ws);
+    if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {

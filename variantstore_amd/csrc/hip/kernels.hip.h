@@ -1506,22 +1506,43 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
 }
 
 // Headers of a type-4 batch from the scratch list of the single walk (one thread per region; ~10 variants each)
-__global__ void __launch_bounds__(64) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= r.Q) return;
-  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], s0 = ws.cap_begin[q];
-  uint64_t cb = r.car_base[q], kept = 0;
-  for (uint64_t i = 0; i < n; ++i) {
+// 16 lanes per region (a sample has ~10 variants in a 10 kb region): coalesced reads of the walk's record and coalesced
+// header writes; the arena offsets are a prefix sum inside each 16-lane row (four DPP steps).
+__global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const uint32_t l16 = threadIdx.x & 15u, row_last = (threadIdx.x & 63u) | 15u;
+  const bool live = q < r.Q;
+  const uint64_t n = live ? r.q_nvar[q] : 0, a0 = live ? r.var_begin[q] : 0, s0 = live ? ws.cap_begin[q] : 0;
+  uint64_t cb = live ? r.car_base[q] : 0, kept = 0;
+  const uint64_t n_max = __shfl(n, 0, 16) ;   // (uniform per row already; rows of one wave may differ)
+  // all four rows of the wave iterate together: the DPP steps need every lane of the wave in the same instruction
+  uint64_t rounds = (n_max + 15) / 16;
+  for (int d = 16; d < 64; d <<= 1) { const uint64_t o = __shfl_xor(rounds, d, 64); rounds = o > rounds ? o : rounds; }
+  for (uint64_t base = 0; base < rounds * 16; base += 16) {
+    const uint64_t i = base + l16;
+    const bool on = i < n;
     const uint64_t a = a0 + i, s = s0 + i;
-    const uint32_t cur = ws.cur[s], c = im.v_ncar[cur];
-    r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
-    r.r_flags[a] = 0; r.r_car_begin[a] = cb; r.r_car_count[a] = c;
-    r.r_region[a] = (uint32_t)q;
-    r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
-    cb += pad_car(c); kept += c;
+    const uint32_t cur = on ? ws.cur[s] : 0u, c = on ? im.v_ncar[cur] : 0u;
+    uint32_t incl = pad_car(c);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);   // row_shr:1 .. 8: prefix inside the row
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+    uint32_t csum = c;
+    csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x111, 0xF, 0xF, true);
+    csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x112, 0xF, 0xF, true);
+    csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x114, 0xF, 0xF, true);
+    csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x118, 0xF, 0xF, true);
+    if (on) {
+      r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
+      r.r_flags[a] = 0; r.r_car_begin[a] = cb + (incl - pad_car(c)); r.r_car_count[a] = c;
+      r.r_region[a] = (uint32_t)q;
+      r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+    }
+    cb += (uint32_t)__shfl((int)incl, (int)row_last, 64);
+    kept += (uint32_t)__shfl((int)csum, (int)row_last, 64);
   }
-  r.var_count[q] = n;
-  r.q_ncar[q] = kept;
+  if (live && l16 == 0) { r.var_count[q] = n; r.q_ncar[q] = kept; }
 }
 
 // Compact hit lists for a collective: the index (and so the site table) is replicated on every rank,
