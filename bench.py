@@ -3,8 +3,14 @@
 
 One "step" = one pass of the hot path (vs_query_var_in_ref) over one batch of
 synthetic regions on a resident index; with N > 1 every rank owns its own shard
-of the batch (weak scaling: the per-GPU batch is fixed) and the step ends with
-the RCCL all-gatherv of the hit lists the north star asks for.
+of the batch and the step ends with the RCCL all-gatherv of the hit lists the
+north star asks for.  `--scaling weak` (default): every rank runs its own batch of
+the workload's size.  `--scaling strong`: ONE sorted batch (BASELINE.json configs[3]:
+1,000,000 regions) is cut into contiguous shards, one per rank.
+
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset)
+starts the N ranks itself: a `python -m torch.distributed.run` child, spawned before
+this process has touched the GPU.
 
 Workloads (BASELINE.json `configs`):
   chr1-2504   [default]  249,250,621 bp, 5,000,000 sites (90% SNP / 5% ins / 5% del, 1% two-ALT),
@@ -40,6 +46,7 @@ WORKLOADS = {
                      regions=100_000, region_len=10_000, region_seed=3),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FILL_SLOT_BYTES = 24    # slot parameters k_fill_carriers reads per variant slot: count 4, source handle 4, genotype offset 8, arena offset 8
 
 
 def make_regions(w, rank, n):
@@ -56,10 +63,14 @@ def synth_kwargs(w):
                               "frac_del", "frac_multi", "max_indel", "af_exponent", "max_af") if k in w}
 
 
-def cpu_baseline(w, budget_s=20.0):
+def cpu_baseline(w, device, budget_s=20.0, parity_regions=600):
     """The CPU oracle (literal restatement of the reference path, 1 thread) on a bounded sample of the same
     workload: same generator, same cohort size, same variant density and region length, on a 1/25-length
-    slice of the chromosome so that building + loading it stays within the bench's time budget."""
+    slice of the chromosome so that building + loading it stays within the bench's time budget.
+
+    The SAME slice is opened on the GPU and the regions the oracle was timed on go through the HIP path too: the
+    first `parity_regions` of them are compared as text, row for row (types 6 and 4), so that the line this run
+    prints carries its own parity stamp.  A mismatch is an error, not a number."""
     import tempfile
     from oracle.oracle import Oracle
     from variantstore_amd import VariantStore
@@ -68,13 +79,12 @@ def cpu_baseline(w, budget_s=20.0):
     kw["ref_length"] = max(200_000, w["ref_length"] // scale)
     kw["num_variants"] = max(1000, w["num_variants"] // scale)
     kw["first_pos"] = min(w["first_pos"], kw["ref_length"] // 10) if scale > 1 else w["first_pos"]
-    vs = VariantStore.synthetic(device=-1, **kw)
+    vs = VariantStore.synthetic(device=device, **kw)
     sub = dict(w, **kw)
     regions = make_regions(sub, 12345, 4000)
     with tempfile.TemporaryDirectory() as td:
         plain = os.path.join(td, "slice.plain")
         vs.export_plain(plain)
-        vs.close()
         orc = Oracle(plain)
         done = nvar = 0
         t0 = time.perf_counter()
@@ -85,6 +95,27 @@ def cpu_baseline(w, budget_s=20.0):
             if done >= 20 and time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
+        # ---- parity stamp: the HIP path on the same slice, the same regions ----
+        npar = min(done, parity_regions)
+        ns = vs.info().num_samples
+        sids16 = [1 + (i * 157) % (ns - 1) for i in range(16)]
+        names16 = [vs.sample_name(sid) for sid in sids16]
+        g6 = vs.get_var_in_ref(regions[:done])
+        per_region = [sids16[i % 16] for i in range(npar)]
+        g4 = vs.get_sample_var_in_ref(regions[:npar], per_region)
+        rows = 0
+        for q in range(npar):
+            x, y = int(regions[q, 0]), int(regions[q, 1])
+            n6, _, t6 = orc.get_var_in_ref(x, y)
+            n4, _, t4 = orc.get_sample_var_in_ref(x, y, names16[q % 16])
+            if g6.region_text(q) != t6 or g4.region_text(q) != t4:
+                raise SystemExit(f"PARITY FAILURE: region {q} ({x}:{y}) of the bench cohort slice differs from the CPU oracle")
+            rows += n6 + n4
+        if g6.totals()[1] != nvar:
+            raise SystemExit(f"PARITY FAILURE: {g6.totals()[1]} variants on the GPU, {nvar} from the oracle over {done} regions")
+        g6.close()
+        g4.close()
+        vs.close()
         orc.close()
         all_cores = cpu_baseline_all_cores(sub, plain, td) if os.environ.get("VS_BENCH_SKIP_ALLCORES") != "1" else None
     out = {"value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
@@ -93,7 +124,9 @@ def cpu_baseline(w, budget_s=20.0):
                      f"{w['num_samples']} samples), CPU oracle, {dt:.1f} s"}
     if all_cores:
         out["all_cores"] = all_cores
-    return out
+    parity = {"parity_checked_regions": npar, "parity_checked_rows": rows, "parity_variant_count_regions": done,
+              "parity": "text-exact vs oracle/ (types 6 and 4) on the cpu_baseline slice, same regions"}
+    return out, parity
 
 
 def cpu_baseline_all_cores(sub, plain, td, budget_s=10.0):
@@ -132,25 +165,86 @@ def cpu_baseline_all_cores(sub, plain, td, budget_s=10.0):
             "sample": f"{done} regions over {cores} processes, {wall:.1f} s"}
 
 
+def git_blob_hash(path):
+    """`git hash-object` of a file without needing git: sha1("blob <len>\0" + content)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+KERNEL_SOURCE = os.path.join(ROOT, "variantstore_amd", "csrc", "hip", "kernels.hip.h")
+
+
+def committed_traffic(workload, nreg_matches):
+    """HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/traffic_<workload>.json, written by
+    tools/make_traffic_json.py).  Counters cannot be read from inside a run, so the figure is only attached when the
+    kernels it was measured on are the kernels of THIS tree (git blob hash of kernels.hip.h) and the batch is the
+    workload's own; otherwise every traffic field is null."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    if not (os.path.exists(tpath) and nreg_matches):
+        return None
+    with open(tpath) as tf:
+        t = json.load(tf)
+    if t.get("kernels_blob") != git_blob_hash(KERNEL_SOURCE):
+        return None
+    return t
+
+
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a torch.distributed.run child and
+    relay its JSON line.  Nothing in THIS process has touched the GPU yet (device_count() does not initialise it)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < ngpus:
+        raise SystemExit(f"bench.py --gpus {ngpus}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(proc.returncode or 1)
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != ngpus:
+        raise SystemExit(f"bench.py --gpus {ngpus}: only {out.get('n_gpus')} rank(s) came up")
+    print(lines[-1], flush=True)
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("VS_BENCH_WORKLOAD", "chr1-2504"), choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own batch of the workload's size; strong: one sorted batch "
+                         "(default 1,000,000 regions, BASELINE configs[3]) cut into one contiguous shard per rank")
+    ap.add_argument("--regions", type=int, default=0, help="regions per GPU and step (weak) or in the whole batch (strong)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-samples", type=int, default=200)
+    ap.add_argument("--extras", default=os.environ.get("VS_BENCH_EXTRAS", "all"),
+                    help="comma list of the untimed legs to run: t4,points,sc,delivery,cli | all | none")
+    ap.add_argument("--skip-extras", action="store_true", help="same as --extras none")
+    args = ap.parse_args()
+    if args.skip_extras or os.environ.get("VS_BENCH_SKIP_T4") == "1":
+        args.extras = "none"
+    extras = {"t4", "points", "sc", "delivery", "cli"} if args.extras == "all" else set(filter(None, args.extras.split(","))) - {"none"}
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner through C stdio when a
     # process group is created) must not be able to add to it: file descriptor 1 is pointed at stderr for the whole
     # run and the JSON line goes to a private duplicate of the real stdout.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("VS_BENCH_WORKLOAD", "chr1-2504"), choices=sorted(WORKLOADS))
-    ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (default: the workload's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency-samples", type=int, default=200)
-    ap.add_argument("--skip-extras", action="store_true", help="only the headline batch (no type 4 / point / sample-coordinate legs)")
-    args = ap.parse_args()
-    if args.skip_extras:
-        os.environ["VS_BENCH_SKIP_T4"] = "1"
 
     import numpy as np
     import torch
@@ -159,8 +253,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1 and args.gpus == 1:
+            args.gpus = world          # launched by torchrun without --gpus
+        else:
+            raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the query path has no CPU implementation")
     torch.cuda.set_device(local_rank)
@@ -171,16 +268,27 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from variantstore_amd import VariantStore
-    from variantstore_amd.parallel import allgather_hit_lists
+    from variantstore_amd.parallel import allgather_hit_lists, shard_bounds
 
     w = WORKLOADS[args.workload]
-    nreg = args.regions or w["regions"]
+    strong = args.scaling == "strong"
+    if strong:
+        total_regions = args.regions or 1_000_000
+        whole = make_regions(dict(w, region_seed=3), 0, total_regions)    # configs[3]: one sorted batch, seed 3
+        lo, hi = shard_bounds(total_regions, rank, world)
+        regions = np.ascontiguousarray(whole[lo:hi])
+        nreg, region_base = hi - lo, lo
+        counts = [shard_bounds(total_regions, r, world)[1] - shard_bounds(total_regions, r, world)[0] for r in range(world)]
+    else:
+        nreg = args.regions or w["regions"]
+        regions = make_regions(w, rank, nreg)
+        region_base = rank * nreg
+        total_regions = world * nreg
+        counts = [nreg] * world
     t_build = time.perf_counter()
     vs = VariantStore.synthetic(device=local_rank, **synth_kwargs(w))
     t_build = time.perf_counter() - t_build
     info = vs.info()
-    regions = make_regions(w, rank, nreg)
-    region_base = rank * nreg
     # the batch's input is resident in HBM before the timed region starts (uploaded once); VS_BENCH_HOST_REGIONS=1 hands
     # the host array over in every step instead (the PCIe-inclusive rate quoted in DESIGN.md, never `value`)
     host_regions = os.environ.get("VS_BENCH_HOST_REGIONS") == "1"
@@ -191,9 +299,8 @@ def main():
         res = vs.get_var_in_ref(regions) if host_regions else vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
         gathered = None
         if use_dist:
-            # every rank answers nreg regions: the record counts are known without asking
-            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True,
-                                           counts=[nreg] * world)
+            # the shard sizes are known to every rank without asking (shard_bounds / the fixed per-rank batch)
+            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True, counts=counts)
         return res, gathered
 
     def fence():
@@ -206,13 +313,14 @@ def main():
         res, _g = step()
         res.close()
     fence()
-    fill_ms = tot_ms = 0.0
+    fill_ms = tot_ms = emit_ms = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         res, _g = step()
         t = vs.last_timing()
         fill_ms += t.ms_fill
         tot_ms += t.ms_total
+        emit_ms += t.ms_emit
         if i != args.steps - 1:
             res.close()
     fence()
@@ -226,43 +334,44 @@ def main():
     nq, nvar, ncar, nbases = res.totals()
     digest = res.digest()
     v = res.view(with_carriers=False)
-    kept = (v["var_flags"] & 1) == 0
-    cc = v["car_count"][kept].astype(np.int64)
+    cc = v["car_count"][(v["var_flags"] & 1) == 0].astype(np.int64)   # carriers per reported variant
+    del v
     W = ((info.num_samples + 63) // 64) * 8
     car_word = 2 if info.num_samples <= 4032 else 4
-    # Dominant kernel k_fill_carriers.  ALGORITHMIC BYTES of one launch = the bytes this kernel's data layout obliges it
-    # to move: per variant slot 24 B of slot parameters (count, class, genotype offset, arena
-    # offset); per variant of at most list_max carriers its decoded id list, rounded up to whole groups of 8 entries;
-    # per denser variant its class bit row (W bytes); half a byte of genotype per carrier
-    # in; one carrier word (2 B: id | gt << 13; 4 B above 4032 samples) per ARENA entry out -- every variant's range
-    # is padded to a multiple of 8 entries and the kernel writes whole groups.  roofline.achieved = that / the
-    # kernel's mean launch time, so roofline.frac can never exceed what the HBM pins carried.
+    # Dominant kernel k_fill_carriers.  LAYOUT BYTES of one launch = the bytes this kernel's data layout obliges it
+    # to move: per variant slot its slot parameters (kFillSlotBytes); per variant of at most
+    # list_max carriers its decoded id list, rounded up to whole groups of 8 entries; per denser variant its class bit
+    # row (W bytes); half a byte of genotype per carrier in; one carrier word (2 B: id | gt << 13; 4 B above 4032
+    # samples) per ARENA entry out -- every variant's range is padded to a multiple of 8 entries and the kernel
+    # writes whole groups.
     padded = (cc + 7) // 8 * 8
     if info.use_bit_vector:
         listed = cc <= info.list_max
         id_bytes = int((padded[listed] * car_word).sum()) + int((~listed).sum()) * W   # list entries are as wide as carrier words
     else:  # explicit sample ids: 4 B per carrier record, read in whole groups of 8
         id_bytes = int(4 * padded.sum())
-    fill_bytes_layout = int(len(cc)) * 24 + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
+    n_slots = res.num_header_records()
+    fill_bytes_layout = n_slots * FILL_SLOT_BYTES + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
     # SURVEY.md section 8(d)'s implementation-independent formula, restricted to the terms this kernel owns: per
     # variant its class row (W) + car_begin word (8), per carrier 3 genotype bits in and 4 + 1 bytes out.  It prices
     # bytes this layout never moves (5 B per carrier written where the arena holds 2), so it is reported for
     # comparison only, under its own key, and is NOT the roofline fraction.
     fill_bytes_survey = nvar * (W + 8) + (3 * ncar + 7) // 8 + 5 * ncar
     fill_s = fill_ms / args.steps / 1e3
-    achieved = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
+    layout_gbps = fill_bytes_layout / fill_s / 1e9 if fill_s > 0 else 0.0
     survey_gbps = fill_bytes_survey / fill_s / 1e9 if fill_s > 0 else 0.0
     res.close()
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
-    # (counters cannot be read from inside the run); the committed measurement is attached when it is for
-    # this workload, otherwise the field stays null.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.exists(tpath) and nreg == w["regions"]:
-        with open(tpath) as tf:
-            traffic = json.load(tf).get("traffic_bytes_per_launch")
+    # roofline.achieved: what crossed the HBM pins per launch (PMC counters of THESE kernels, committed under
+    # profiles/) over the launch time measured live here; without matching counters, the layout bytes.
+    tj = committed_traffic(args.workload, (not strong) and nreg == w["regions"])
+    traffic = tj["kernels"]["k_fill_carriers"]["traffic_bytes_per_launch"] if tj else None
+    if traffic and fill_s > 0:
+        achieved, basis = traffic / fill_s / 1e9, "pmc_traffic"
+    else:
+        achieved, basis = layout_gbps, "layout_bytes"
 
-    # ---- p50 single-region latency (submit -> result resident), outside the timed region ----
+    # ---- p50 single-region latency (submit -> result resident), outside the timed region: a client that asks again
+    #      the moment it has its answer (the resident server's case), and one paced at 1 query per millisecond ----
     lat = []
     for i in range(args.latency_samples):
         one = regions[(i * 7919) % nreg: (i * 7919) % nreg + 1]
@@ -271,30 +380,45 @@ def main():
         lat.append(time.perf_counter() - a)
         r1.close()
     p50 = float(np.median(lat)) * 1e6 if lat else None
+    lat_paced = []
+    for i in range(min(args.latency_samples, 100)):
+        one = regions[(i * 7919) % nreg: (i * 7919) % nreg + 1]
+        time.sleep(0.001)
+        a = time.perf_counter()
+        r1 = vs.get_var_in_ref(one)
+        lat_paced.append(time.perf_counter() - a)
+        r1.close()
+    p50_paced = float(np.median(lat_paced)) * 1e6 if lat_paced else None
 
     # ---- query type 4 on the same index (BASELINE.json configs[2] names types 4+6): 16 fixed samples,
     #      one sub-batch each, outside the timed region of the headline metric ----
     t4 = None
-    if os.environ.get("VS_BENCH_SKIP_T4") != "1":
+    if "t4" in extras:
         sids16 = [1 + (i * 157) % (info.num_samples - 1) for i in range(16)]
         per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)   # round-robin over 16 samples
         r4 = vs.get_sample_var_in_ref(regions, per_region)  # warm-up
-        nv4 = r4.totals()[1]
+        nv4, nc4 = r4.totals()[1:3]
         r4.close()
         torch.cuda.synchronize()
         a4 = time.perf_counter()
-        for _k in range(3):
+        walk_ms = 0.0
+        for _k in range(5):
             r4 = vs.get_sample_var_in_ref(regions, per_region)
+            walk_ms += vs.last_timing().ms_bounds
             r4.close()
         torch.cuda.synchronize()
-        t4 = {"queries_per_s": 3 * nreg / (time.perf_counter() - a4), "regions_per_batch": nreg, "samples": 16,
-              "variants_per_region": nv4 / nreg}
+        t4 = {"queries_per_s": 5 * nreg / (time.perf_counter() - a4), "regions_per_batch": nreg, "samples": 16,
+              "variants_per_region": nv4 / nreg, "carriers_per_variant": nc4 / max(nv4, 1), "walk_phase_ms": walk_ms / 5}
+        tw = tj["kernels"].get("k_sample_walk") if tj else None
+        if tw and walk_ms > 0:   # the walk kernel's own pin traffic (PMC) over the walk phase (capacity bounds + scan + walk) timed here
+            t4["walk_traffic_bytes"] = tw["traffic_bytes_per_launch"]
+            t4["walk_traffic_GBps"] = tw["traffic_bytes_per_launch"] / (walk_ms / 5 * 1e-3) / 1e9
 
     # ---- point queries (types 1 and 7) on the same index, outside the timed region:
     #      1M random positions; type 7 asks for an A>C substitution everywhere (nearly always "no such variant",
     #      which costs the same walk) ----
     t17 = None
-    if os.environ.get("VS_BENCH_SKIP_T4") != "1":
+    if "points" in extras:
         npos = 1_000_000
         prng = np.random.default_rng(17)
         positions = prng.integers(1, w["ref_length"], size=npos, dtype=np.uint64)
@@ -322,7 +446,7 @@ def main():
     # ---- sample-coordinate queries (types 2, 3 and 5), outside the timed region, on a
     #      1/12.5-length cohort of the same shape built WITH sample coordinates (4 B per carrier record) ----
     tsc = None
-    if os.environ.get("VS_BENCH_SKIP_T4") != "1" and rank == 0:
+    if "sc" in extras and rank == 0:
         kw = synth_kwargs(w)
         kw["ref_length"] = max(200_000, w["ref_length"] * 2 // 25)
         kw["num_variants"] = max(1000, w["num_variants"] * 2 // 25)
@@ -355,51 +479,65 @@ def main():
                 tsc["type5_variants_per_region"] = tot[1] / nsc
         vsc.close()
 
+    delivery = None   # (filled by the delivery legs)
+
     if rank == 0:
+        shard_note = (f"one sorted batch of {total_regions} regions cut into {world} contiguous shard(s)" if strong
+                      else f"{nreg} random {w['region_len']} bp regions per GPU")
         out = {
             "metric": "region-queries/sec (batch, query-type 6)",
-            "value": world * nreg * args.steps / elapsed,
+            "value": total_regions * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {w['ref_length']} bp, {w['num_variants']} sites, "
-                            f"{w['num_samples']} samples, {nreg} random {w['region_len']} bp regions per GPU, "
+                            f"{w['num_samples']} samples, {shard_note}, "
                             "query type 6 (get_var_in_ref), index + regions resident in HBM, results left in HBM"
                             + (" [regions handed over as a host array in every step]" if host_regions else ""),
-                "regions_per_gpu": nreg, "region_len": w["region_len"],
+                "regions_per_gpu": nreg, "regions_total": total_regions, "region_len": w["region_len"],
                 "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
                 "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,
                           "hbm_image_bytes": info.device_bytes, "build_s": round(t_build, 1)},
             },
+            # achieved = bytes that crossed the HBM pins per launch of the dominant kernel (rocprofv3 --pmc passes of this
+            # command on THESE kernels, profiles/traffic_<workload>.json; FETCH_SIZE corrected per MI355X_MICROARCH.md) /
+            # the kernel's mean launch time measured live here with HIP events on the engine's stream.  When the tree's
+            # kernels are not the profiled ones, traffic is null and achieved falls back to the layout bytes (basis says which).
             "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "bytes_per_launch": fill_bytes_layout, "avg_launch_ms": fill_ms / args.steps,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
+                         "avg_launch_ms": fill_ms / args.steps,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
-                         # what crossed the HBM pins (PMC, profiles/traffic_<workload>.json) over the same launch time
-                         "traffic_GBps": (traffic / fill_s / 1e9) if (traffic and fill_s > 0) else None,
-                         "traffic_frac": (traffic / fill_s / 1e9 / HBM_PEAK_GBPS) if (traffic and fill_s > 0) else None,
+                         "layout": {"bytes_per_launch": fill_bytes_layout, "GBps": layout_gbps, "frac": layout_gbps / HBM_PEAK_GBPS,
+                                    "note": "bytes the data layout obliges the kernel to move (DESIGN.md section 5)"},
                          "survey_formula": {"bytes_per_launch": fill_bytes_survey, "GBps": survey_gbps,
                                             "note": "SURVEY 8(d) terms of this kernel; prices 5 B per carrier written where "
                                                     "the arena holds 2 -- a time-per-algorithmic-unit figure, not pin traffic"},
-                         "pipeline_ms": tot_ms / args.steps},
+                         "emit_kernel_ms": emit_ms / args.steps,
+                         "pipeline_ms": tot_ms / args.steps,
+                         "other_kernels": ({k: v for k, v in tj["kernels"].items() if k != "k_fill_carriers"} if tj else None),
+                         "kernels_blob": git_blob_hash(KERNEL_SOURCE)},
             "p50_latency_us": p50,
+            "p50_latency_paced_1ms_us": p50_paced,
             "type4": t4,
             "point_queries": t17,
             "sample_coordinate_queries": tsc,
+            "delivery": delivery,
             "result_digest": f"{digest:016x}",
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+            vs.close()   # (the slice index of the baseline leg takes its place on the GPU)
+            out["cpu_baseline"], parity = cpu_baseline(w, local_rank)
+            out.update(parity)
         print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.barrier()

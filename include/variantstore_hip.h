@@ -113,11 +113,17 @@ int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, u
 /* ---- queries ------------------------------------------------------------ */
 /* type 6: get_var_in_ref for each of the n regions (query.h:736-784).  Batches of at most 64 regions take the latency
  * path: one kernel for the whole query, or -- while the handle's resident query server is alive -- no launch at all
- * (VS_NO_SERVER=1 in the environment keeps it to one launch per call). */
+ * (by default only for back-to-back streaks of small queries -- vs_index_set_option
+ * "latency_server"; VS_NO_SERVER=1 in the environment when the handle is opened keeps it to one launch per call). */
 int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out);
 /* The same with the regions already in DEVICE memory of the handle's GPU (e.g. produced there, or uploaded once and
  * queried repeatedly): no host buffer crosses PCIe inside the call.  Always the batch pipeline, whatever n. */
 int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, uint64_t n, vs_result** out);
+/* The receiving side of the hit-list collective (vs_result_pack_regions below): n compact region records in DEVICE
+ * memory -- this rank's own or gathered from other ranks holding the same index -- expanded into a full type-6 result
+ * (variant rows + carrier lists), exactly what the producing rank holds.  Records whose site range does not fit this
+ * index come back as VS_REGION_INVALID. */
+int vs_query_expand_site_ranges(vs_index* idx, const void* device_records, uint64_t n, vs_result** out);
 /* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
                                vs_result** out);
@@ -208,12 +214,20 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
                            uint64_t* n_records);
 /* Compact hit lists (query type 6): because every rank holds the same index, a region's variant list is
  * its range of the position-ordered site table.  n_regions records of 4 x uint64 in DEVICE memory:
- *   {region_base+q, first_site | region_flags<<32 | has_dropped<<40, variants reported, carriers}.
- * (A region with has_dropped set lost entries to the reference's duplicate rule; its exact rows are in
- * the full records of vs_result_pack_headers.)  device_dst == NULL only reports the record count. */
+ *   {region_base+q, first_site | region_flags<<32 | has_dropped<<40, sites | variants reported<<32, carriers}.
+ * (A region with has_dropped set lost entries to the reference's duplicate rule: fewer variants reported than
+ * sites; vs_query_expand_site_ranges applies the rule again.)  device_dst == NULL only reports the record count. */
 int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records);
 void vs_result_free(vs_result* r);
+
+/* ---- switches of one handle (tests and tuning; nothing here is needed in production) ----
+ * The environment is read once when a handle is opened; afterwards only this call changes a
+ * switch.  Keys: "latency_server" 0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first
+ * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
+ * form the event bitmaps shortcut); "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
+int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 
 /* ---- timing of the last batch on this handle ----
  * Batches of more than 64 regions and every other query type: HIP events on the engine's stream.

@@ -1,0 +1,73 @@
+"""The multi-GPU path's data round trip on ONE GPU: a real result -> vs_result_pack_regions -> the RCCL all-gather of
+variantstore_amd.parallel (backend "nccl", world size 1) -> vs_query_expand_site_ranges on the gathered tensor -> the
+same rows as the local result and as the CPU oracle.  (The world-size-2 plumbing -- shard bounds, counts, padding --
+runs on CPU with gloo in test_parallel_gloo.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import random_regions, write_random_cohort
+from oracle.oracle import Oracle
+from variantstore_amd import VariantStore
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_gathered_site_ranges_expand_to_the_local_result(nccl_world1, tmp_path):
+    import torch
+    from variantstore_amd.parallel import allgather_hit_lists, shard_bounds, shard_regions, unpack_region_records
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 411, n_rows=400, ref_len=6000, n_samples=90, carrier_p=0.35,
+                                        p_near=0.6, p_multi=0.25)
+    vs = VariantStore.from_vcf(fasta, vcf, device=0)
+    plain = os.path.join(tmp_path, "plain.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    regions = sorted(random_regions(np.random.default_rng(5), vs.info().ref_length, 500))
+    dev = torch.device("cuda", 0)
+    # rank 0 of 1: its shard is the whole sorted batch
+    mine, lo = shard_regions(regions, 0, 1)
+    assert (lo, len(mine)) == (0, len(regions)) and shard_bounds(len(regions), 0, 1) == (0, len(regions))
+    local = vs.get_var_in_ref(mine)
+    for counts in (None, [len(regions)]):             # with and without the count all-gather
+        gathered, cnt = allgather_hit_lists(local, lo, dev, compact=True, counts=counts)
+        assert gathered.shape == (1, len(regions), 4) and int(cnt[0]) == len(regions)
+        rec = unpack_region_records(gathered, cnt)[0]
+        assert np.array_equal(rec["region"], np.arange(len(regions), dtype=np.uint64))
+        assert int(rec["variants"].sum()) == local.totals()[1] and int(rec["carriers"].sum()) == local.totals()[2]
+        back = vs.expand_site_ranges(gathered[0].contiguous().data_ptr(), len(regions))
+        assert back.totals() == local.totals() and back.digest() == local.digest()
+        dropped_somewhere = False
+        for q, (x, y) in enumerate(regions):
+            n, _, text = orc.get_var_in_ref(x, y)
+            if n < 0:
+                continue
+            assert back.region_text(q) == local.region_text(q) == text, (q, x, y)
+            dropped_somewhere |= bool(rec["has_dropped"][q])
+        assert dropped_somewhere          # the crowded cohort exercises the duplicate rule on the receiving side too
+        back.close()
+    # per-variant records through the same collective
+    full, cnt = allgather_hit_lists(local, lo, dev, compact=False)
+    v = local.view(False)
+    from variantstore_amd.parallel import unpack_records
+    rows = unpack_records(full, cnt)[0]
+    assert np.array_equal(rows["pos"], v["pos"]) and np.array_equal(rows["car_count"], v["car_count"])
+    local.close()
+    vs.close()

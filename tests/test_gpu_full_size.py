@@ -106,3 +106,35 @@ def test_type4_agrees_with_type6_on_membership(big):
     assert total4 > 50
     r6.close()
     r4.close()
+
+
+def test_one_million_region_batch_on_one_gpu(big):
+    """BASELINE.json configs[3]'s batch (1,000,000 sorted 10 kb regions, seed 3) as ONE single-GPU batch: 200 M
+    variant rows and 28 G carriers (56 GB of arena).  Totals equal the sum over ten 100 k-region pieces, a region's
+    rows do not depend on the batch it travels in, two runs give one digest, and the batch's compact hit-list
+    records (what an 8-GPU run all-gathers) expand back into a result with the same digest."""
+    import torch
+    vs, _ = big
+    rng = np.random.default_rng(3000)
+    starts = np.sort(rng.integers(1, KW["ref_length"] - 10_000, size=1_000_000))
+    regions = np.stack([starts, starts + 10_000], axis=1).astype(np.uint64)
+    a = vs.get_var_in_ref(regions)
+    ta, da = a.totals(), a.digest()
+    assert ta[0] == 1_000_000 and ta[1] > 150_000_000 and ta[2] > 20_000_000_000
+    texts = {q: a.region_text(q) for q in (0, 123_456, 500_000, 999_999)}
+    recs = torch.empty((1_000_000, 4), dtype=torch.int64, device="cuda")
+    assert a.pack_regions_into(recs.data_ptr(), 1_000_000, 0) == 1_000_000
+    a.close()
+    sums = [0, 0, 0, 0]
+    for i in range(10):
+        p = vs.get_var_in_ref(regions[i * 100_000:(i + 1) * 100_000])
+        for k, t in enumerate(p.totals()):
+            sums[k] += t
+        for q, text in texts.items():
+            if i * 100_000 <= q < (i + 1) * 100_000:
+                assert p.region_text(q - i * 100_000) == text
+        p.close()
+    assert tuple(sums) == ta
+    b = vs.expand_site_ranges(recs.data_ptr(), 1_000_000)
+    assert (b.totals(), b.digest()) == (ta, da)
+    b.close()

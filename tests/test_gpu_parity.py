@@ -334,7 +334,8 @@ def test_hit_list_records_for_the_collective(tmp_path):
     assert res.pack_regions_into(rbuf.data_ptr(), q, region_base=7) == q
     rr = rbuf.cpu().numpy().view(np.uint64)
     assert np.array_equal(rr[:, 0], np.arange(q, dtype=np.uint64) + np.uint64(7))
-    assert np.array_equal(rr[:, 2], v["var_count"])
+    assert np.array_equal(rr[:, 2] >> np.uint64(32), v["var_count"])
+    assert np.array_equal(rr[:, 2] & np.uint64(0xFFFFFFFF), np.diff(vb).astype(np.uint64))
     car_per_region = np.add.reduceat(np.concatenate([v["car_count"], [0]]).astype(np.uint64), np.minimum(vb[:-1], len(v["car_count"])))
     car_per_region[np.diff(vb) == 0] = 0
     assert np.array_equal(rr[:, 3], car_per_region)
@@ -348,6 +349,28 @@ def test_hit_list_records_for_the_collective(tmp_path):
         for b in range(a + 1, min(q, a + 4)):
             if first[a] == first[b] and rr[a, 2] == rr[b, 2] and not has_dropped[a] and not has_dropped[b] and rr[a, 2] > 0:
                 assert res.region_text(a) == res.region_text(b)
+    # ... and the receiving side of the collective expands the records back into the very same result
+    back = vs.expand_site_ranges(rbuf.data_ptr(), q)
+    assert back.totals() == res.totals()
+    for a in range(q):
+        assert back.region_text(a) == res.region_text(a), a
+    vb_back = back.view(False)
+    assert np.array_equal(vb_back["var_count"], v["var_count"]) and np.array_equal(vb_back["region_flags"], v["region_flags"])
+    # records of two shards of the batch, concatenated as an all-gather would deliver them (region_base = shard offset)
+    half = q // 2
+    both = torch.zeros((q, 4), dtype=torch.int64, device="cuda")
+    ra, rb = vs.get_var_in_ref(regions[:half]), vs.get_var_in_ref(regions[half:])
+    ra.pack_regions_into(both.data_ptr(), half, region_base=0)
+    rb.pack_regions_into(both[half:].data_ptr(), q - half, region_base=half)
+    assert np.array_equal(both.cpu().numpy().view(np.uint64)[:, 0], np.arange(q, dtype=np.uint64))
+    merged = vs.expand_site_ranges(both.data_ptr(), q)
+    assert merged.digest() == res.digest() and merged.totals() == res.totals()
+    # a record that does not fit this index's site table is refused, not followed
+    bad = rbuf.clone()
+    bad[0, 1] = int(vs.info().num_sites)          # first site == G with a non-zero count
+    bad[0, 2] = 5
+    worst = vs.expand_site_ranges(bad.data_ptr(), q)
+    assert worst.view(False)["region_flags"][0] & 2 and worst.region_text(1) == res.region_text(1)
 
 
 def test_latency_path_with_large_answers(tmp_path):
@@ -374,7 +397,7 @@ def test_latency_path_with_large_answers(tmp_path):
     assert _compare_t6(vs, orc, batch) == 512
 
 
-def test_resident_server_and_launch_forms_of_the_latency_path_agree(tmp_path, monkeypatch):
+def test_resident_server_and_launch_forms_of_the_latency_path_agree(tmp_path):
     """Small batches are answered by the resident query server (no launch per request) while one is alive, by a single
     launch otherwise: same text either way, across server expiry (it leaves 1 ms after the last request), restart, a
     general-path batch in between, and requests too large for the server."""
@@ -396,17 +419,34 @@ def test_resident_server_and_launch_forms_of_the_latency_path_agree(tmp_path, mo
             assert [res.region_text(q) for q in range(len(b))] == want[tuple(b)], b
             res.close()
 
-    check(singles[:20] + pairs[:5])                  # server starts with the first request and stays
+    vs.set_option("latency_server", 2)               # the server starts with the first small request and stays
+    check(singles[:20] + pairs[:5])
+    assert vs.last_timing().fill_launches == 0       # ... and answers without a launch
     time.sleep(0.01)                                 # ... leaves by its idle clock; the next request restarts it
     check(singles[20:30])
     big = [(int(s), int(s) + 700) for s in rng.integers(1, 398_000, size=300)]
-    assert _compare_t6(vs, orc, big) == 300          # general path while a server is alive
+    assert _compare_t6(vs, orc, big) == 300          # general path (stops a live server first)
     check(pairs[5:])
     assert _compare_t6(vs, orc, [(1, 300_000)]) == 1  # too many tasks for the server: one launch sized for it
-    monkeypatch.setenv("VS_NO_SERVER", "1")
+    vs.set_option("latency_server", 0)
     check(singles[30:] + pairs[:3])                  # launch form
-    monkeypatch.delenv("VS_NO_SERVER")
-    check(singles[:5])
+    assert vs.last_timing().fill_launches == 1
+    vs.set_option("latency_server", 1)               # default: only a back-to-back streak of small queries starts it
+    check(singles[:2])
+    assert vs.last_timing().fill_launches == 1
+    for _ in range(3):                               # (back to back as seen from C: keep Python out of the gaps)
+        fast = [np.asarray(b, dtype=np.uint64).reshape(-1, 2) for b in singles[:12]]
+        answered_by_server = 0
+        for arr in fast:
+            vs.get_var_in_ref(arr).close()
+            answered_by_server += vs.last_timing().fill_launches == 0
+        if answered_by_server:
+            break
+    assert answered_by_server > 0
+    check(singles[:12])
+    time.sleep(0.002)                                # a caller that pauses goes back to the single launch
+    check(singles[5:6])
+    assert vs.last_timing().fill_launches == 1
     vs.close()
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Same-process experiments on the type-6 throughput path: one index build, many configurations (env toggles are read
-per call by the engine).  python tools/exp_fill.py [config ...]; a config is NAME:ENV=VAL,ENV=VAL[,len=N]"""
+"""Same-process experiments on the type-6 throughput path: one index build, many configurations.
+python tools/exp_fill.py [config ...]; a config is NAME:option=VAL,...[,len=N][,lm=N] where option is a key of
+vs_index_set_option (fill_ablate / fill_lds_pad need a tuning build: VS_BUILD_TUNING=1 python -m variantstore_amd.build --force)."""
 import os
 import sys
 import time
@@ -29,13 +30,15 @@ def reopen(lm):
         os.environ["VS_LIST_MAX"] = str(lm)
     vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
     cur_lm = lm
-TOGGLES = ("VS_FILL_ABLATE", "VS_FILL_BLOCKS", "VS_T6_HEADER_KERNEL", "VS_FILL_MODE")
+OPTIONS = {"fill_ablate": 0, "fill_lds_pad": 0}   # the switches an experiment may set, with their defaults
 
 
 def run(name, env, rlen, steps=8):
-    for k in TOGGLES:
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    unknown = set(env) - set(OPTIONS)
+    if unknown:
+        raise SystemExit(f"unknown option(s) in config {name}: {sorted(unknown)}")
+    for k, dflt in OPTIONS.items():
+        vs.set_option(k, int(env.get(k, dflt)))
     ww = dict(w, region_len=rlen)
     regions = bench.make_regions(ww, 0, w["regions"])
     for _ in range(2):

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/traffic_<workload>.json from the rocprofv3 --pmc passes of tools/profile_round.sh:
+
+   python tools/make_traffic_json.py <workload> <tag> gpurun_out/pmc_<tag>_1 gpurun_out/pmc_<tag>_2 ...
+
+Per kernel (fill, header, walk, ...): mean FETCH_SIZE / WRITE_SIZE per launch, the corrected HBM traffic
+(2 x FETCH_SIZE + WRITE_SIZE: this image's rocprofv3 reports half the bytes of wide coalesced reads on gfx950,
+MI355X_MICROARCH.md "HBM"), TCC hit rate and the SQ counters of the same passes.  The file records the git blob
+hash of kernels.hip.h: bench.py only attaches these figures to a run whose kernels are the profiled ones."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+workload, tag, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+raw = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs))
+SHORT = {"k_fill_carriers": "k_fill_carriers", "k_emit_headers": "k_emit_headers", "k_sample_walk": "k_sample_walk",
+         "k_emit_from_walk": "k_emit_from_walk", "k_region_bounds": "k_region_bounds"}
+kernels = {}
+for name, ctr in raw.items():
+    short = next((v for k, v in SHORT.items() if k in name), None)
+    if short is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
+        continue
+    if short in kernels and kernels[short]["_launches"] >= ctr["_launches"]:
+        continue  # (template instantiations: keep the one that ran most)
+    fetch, write = ctr["FETCH_SIZE"] * 1024, ctr["WRITE_SIZE"] * 1024
+    e = {"full_name": name, "_launches": ctr["_launches"], "FETCH_SIZE_KiB": ctr["FETCH_SIZE"], "WRITE_SIZE_KiB": ctr["WRITE_SIZE"],
+         "traffic_bytes_per_launch": int(2 * fetch + write), "traffic_bytes_per_launch_uncorrected": int(fetch + write)}
+    hit, miss = ctr.get("TCC_HIT_sum", ctr.get("TCC_HIT")), ctr.get("TCC_MISS_sum", ctr.get("TCC_MISS"))
+    if hit is not None and miss is not None and hit + miss > 0:
+        e["tcc_hit_rate"] = hit / (hit + miss)
+    for k, v in ctr.items():
+        if k.startswith("SQ_") or k.startswith("GRBM_"):
+            e[k] = v
+    kernels[short] = e
+out = {"workload": workload, "tag": tag, "kernels_blob": bench.git_blob_hash(bench.KERNEL_SOURCE),
+       "note": "separate rocprofv3 --pmc passes of `python3 bench.py --steps 6 --warmup 2 --extras t4` (tools/profile_round.sh); "
+               "means over all launches of a kernel; traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; an "
+               "upper bound where reads are narrow)",
+       "kernels": kernels}
+path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+with open(path, "w") as f:
+    json.dump(out, f, indent=1)
+print(path, {k: v["traffic_bytes_per_launch"] for k, v in kernels.items()})

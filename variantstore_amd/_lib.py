@@ -70,6 +70,7 @@ SYMBOLS = {
     "vs_index_out_neighbors": (C.c_int64, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64]),
     "vs_query_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(_P)]),
     "vs_query_var_in_ref_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
+    "vs_query_expand_site_ranges": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
     "vs_query_sample_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "vs_query_samples_var_in_ref": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(_P)]),
     "vs_query_closest_var": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(_P)]),
@@ -90,6 +91,7 @@ SYMBOLS = {
     "vs_result_pack_regions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vs_result_free": (None, [_P]),
     "vs_index_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+    "vs_index_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
 }
 
 _lib = None

@@ -249,6 +249,10 @@ class VariantStore:
         _check(self._lib.vs_index_last_timing(self._h, C.byref(t)), "vs_index_last_timing")
         return t
 
+    def set_option(self, key, value):
+        """Test / tuning switches of this handle (include/variantstore_hip.h: vs_index_set_option)."""
+        _check(self._lib.vs_index_set_option(self._h, key.encode(), int(value)), "vs_index_set_option")
+
     # ---- queries ------------------------------------------------------------
     def find(self, positions: Sequence[int]):
         """Index::find for a batch of positions (index.h:119-133)."""
@@ -262,7 +266,8 @@ class VariantStore:
         """Query type 6 over a batch of (pos_x, pos_y) regions (query.h:736-784)."""
         # (this is the call whose single-region latency the bench reports: a ready uint64 array is passed on as it is,
         #  without the ctypes pointer objects of the general helper)
-        if type(regions) is np.ndarray and regions.dtype == np.uint64 and regions.flags.c_contiguous and regions.ndim == 2:
+        if (type(regions) is np.ndarray and regions.dtype == np.uint64 and regions.flags.c_contiguous and regions.ndim == 2
+                and regions.shape[1] == 2):
             arr = regions
         else:
             arr = np.ascontiguousarray(np.asarray(regions, dtype=np.uint64).reshape(-1, 2))
@@ -278,6 +283,14 @@ class VariantStore:
         h = C.c_void_p()
         _check(self._lib.vs_query_var_in_ref_device(self._h, C.c_void_p(int(device_ptr)), int(n), C.byref(h)),
                "vs_query_var_in_ref_device")
+        return QueryResult(self, h)
+
+    def expand_site_ranges(self, device_ptr, n) -> QueryResult:
+        """The receiving side of the hit-list collective: n compact region records (QueryResult.pack_regions_into, own or
+        gathered from ranks holding the same index) in this GPU's memory -> the full type-6 result they describe."""
+        h = C.c_void_p()
+        _check(self._lib.vs_query_expand_site_ranges(self._h, C.c_void_p(int(device_ptr)), int(n), C.byref(h)),
+               "vs_query_expand_site_ranges")
         return QueryResult(self, h)
 
     def get_sample_var_in_ref(self, regions, sample) -> QueryResult:

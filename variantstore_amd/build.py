@@ -42,6 +42,8 @@ def build_engine(force=False, verbose=True):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", LIB, os.path.join(PKG, "csrc", "hip", "engine.hip"), "-lz"]
+    if os.environ.get("VS_BUILD_TUNING") == "1":   # ablation / occupancy switches of k_fill_carriers (tools/exp_fill.py)
+        cmd.insert(1, "-DVS_TUNING")
     if verbose:
         print("+", " ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=ROOT)

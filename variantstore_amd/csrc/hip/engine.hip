@@ -49,6 +49,20 @@ static int fail(int code, const char* fmt, ...) {
 
 struct DevBuf { void* p; size_t cap; };
 
+// Switches of one handle.  The environment is read ONCE, when the handle is opened (read_env_opts); afterwards only
+// vs_index_set_option changes them -- no getenv on any query path.
+struct EngineOpts {
+  int server = 1;               // latency path: 0 never use the resident server, 1 start it for a back-to-back streak of
+                                // small queries only (default), 2 start it with the first small query
+  unsigned srv_blocks = 16;     // grid of the resident server (>= 1)
+  bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
+  bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
+  bool seq_two_walks = false;   // the same for types 2 / 3
+  bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
+  uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
+  size_t fill_lds_pad = 0;      // tuning builds only: pad the fill kernel's LDS block (occupancy experiments)
+};
+
 struct vs_index {
   HostGraph g;
   HostImage im;
@@ -74,11 +88,14 @@ struct vs_index {
   uint64_t srv_seq = 1;                          // sequence number of the next request
   unsigned long long* srv_counter = nullptr;     // device word: blocks done with the current request
   std::vector<uint64_t> h_carpre;   // host copy of DevImage::s_carpre (arena prefix): sizes of the latency path's results
-  uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory: totals + regions of the latency path, batch totals
-  static constexpr size_t kPinTotals = 0;     // [0..2] latency path, VS_LAT_DEBUG only: device-clock durations (kernel, bounds, tasks)
+  EngineOpts opts;
+  // back-to-back detection for opts.server == 1: small queries that followed the previous one within kSrvStreakGap
+  uint32_t small_streak = 0;
+  std::chrono::steady_clock::time_point last_small_done{};
+  uint64_t* pinned = nullptr;  // 16 KiB of mapped host memory (uint64 words): latency-path mailboxes, server request, batch totals
+  static constexpr size_t kPinTotals = 0;     // [0..2] latency path, lat_debug only: device-clock durations (kernel, bounds, tasks)
   static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
-  static constexpr size_t kPinRegions = 8;    // [8 .. 8 + 2*512) latency path: the regions themselves
-  static constexpr size_t kPinSrvResp = 16;   // resident server: sequence number of the last request answered
+  static constexpr size_t kPinSrvResp = 16;   // [16..20] resident server: sequence number of the last request answered (+ debug stamps)
   static constexpr size_t kPinSrvReq = 256;   // [256 .. 256 + 136) resident server: the request (ServerRequest, 64-byte aligned)
   static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path: slots and arena entries of the batch
 };
@@ -97,6 +114,11 @@ struct vs_result {
   bool have_totals = false;
   std::string text;
   std::vector<uint32_t> slice_carriers;
+  // per-region arrays alone (flags, slot and arena offsets, counts): all that totals and single-region formatting need
+  bool have_meta = false;
+  // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
+  std::vector<uint64_t> sl_pos, sl_car_begin;
+  std::vector<uint32_t> sl_ref_off, sl_ref_len, sl_alt_off, sl_alt_len, sl_vflags, sl_car_count;
   int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line); 2 / 3: sequences
   // sequence results (query types 2 and 3)
   DevSeqResult sq{};
@@ -110,6 +132,9 @@ struct vs_result {
   if ((r)->kind == 2 || (r)->kind == 3) return fail(VS_ERR_ARG, "a sequence result (query types 2/3) has no variant table; use vs_result_get_sequences")
 
 // ------------------------------------------------------------------ helpers
+static int server_stop(vs_index* idx);   // the resident latency server must be gone before anything that synchronises the
+                                         // whole device (hipFree does): it would otherwise wait for the server's idle clock
+
 static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf>* owner) {
   if (bytes == 0) bytes = 8;
   bytes = (bytes + 255) & ~(size_t)255;
@@ -128,6 +153,7 @@ static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     // release the pool and retry once
+    (void)server_stop(idx);
     for (auto& b : idx->pool) (void)hipFree(b.p);
     idx->pool.clear();
     e = hipMalloc(&p, bytes);
@@ -194,6 +220,7 @@ static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
   for (auto& b : bufs) idx->pool.push_back(b);
   bufs.clear();
   // keep the pool bounded: drop the smallest buffers beyond 64 entries
+  if (idx->pool.size() > 64) (void)server_stop(idx);
   while (idx->pool.size() > 64) {
     size_t k = 0;
     for (size_t i = 1; i < idx->pool.size(); ++i)
@@ -344,9 +371,22 @@ static int build_device_image(vs_index* idx) {
   return VS_OK;
 }
 
+// The environment switches of DESIGN.md section 7a, read once per handle.
+static void read_env_opts(vs_index* idx) {
+  EngineOpts& o = idx->opts;
+  if (getenv("VS_NO_SERVER")) o.server = 0;
+  else if (const char* sv = getenv("VS_SERVER")) o.server = std::max(0, std::min(2, atoi(sv)));
+  if (const char* sb = getenv("VS_SRV_BLOCKS")) o.srv_blocks = (unsigned)std::max(1, std::min(64, atoi(sb)));
+  o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
+  o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
+  o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
+  if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
+  if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
+}
+
 static int finish_open(vs_index* idx, int device) {
   try {
-    if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
+    read_env_opts(idx);
     build_host_image(idx->g, idx->im);
   } catch (const std::exception& e) {
     return fail(VS_ERR_FORMAT, "%s", e.what());
@@ -389,8 +429,9 @@ static size_t fill_lds_bytes(const vs_index* idx) {
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
                           const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
-                          int walk_mode = 4, bool regions_on_device = false) {
+                          int walk_mode = 4, bool regions_on_device = false, const uint64_t* site_records = nullptr) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
+  if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
   uint32_t* dsids = nullptr;
   DevResult& d = r->d;
   d.Q = n;
@@ -405,7 +446,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
-  if (n) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
+  if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
+  else if (n) HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
   if (sample_ids && n) {
     VS_TRY(ralloc(r, n, &dsids));
     HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
@@ -417,7 +459,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
   WalkScratch ws{};
   bool single_walk = false;
-  if (n && t4 && getenv("VS_T4_TWO_WALKS") == nullptr) {
+  if (n && t4 && !idx->opts.t4_two_walks) {
     if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     uint64_t* cap_begin = nullptr;
@@ -446,6 +488,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
+    else if (site_records) hipLaunchKernelGGL(k_bounds_from_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, site_records);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     HIP_TRY(hipGetLastError());
   }
@@ -510,18 +553,25 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (d.A) {
     {
       const uint64_t nchunks = (d.A + 63) / 64;
-      const uint32_t ablate = getenv("VS_FILL_ABLATE") ? (uint32_t)atoi(getenv("VS_FILL_ABLATE")) : 0u;          // profiling aids
       // one 64-slot task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
       // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time)
       const uint64_t blocks = (nchunks + 3) / 4;
       if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
       const uint32_t gt_words = fill_gt_words(idx);
-      const size_t lds_bytes = fill_lds_bytes(idx) + (getenv("VS_FILL_LDS_PAD") ? (size_t)atoll(getenv("VS_FILL_LDS_PAD")) : 0);   // occupancy experiments
+#ifdef VS_TUNING   // tuning builds: one regime of the kernel can be skipped, the LDS block padded (tools/exp_fill.py)
+      const size_t lds_bytes = fill_lds_bytes(idx) + std::min<size_t>(idx->opts.fill_lds_pad, 96 << 10);
+      const uint32_t ablate = idx->opts.fill_ablate;
+      constexpr bool kTune = true;
+#else
+      const size_t lds_bytes = fill_lds_bytes(idx);
+      const uint32_t ablate = 0;
+      constexpr bool kTune = false;
+#endif
       if (idx->d.wpc <= 63)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunk>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -566,8 +616,9 @@ static int fetch_carriers(vs_result* r, uint64_t first, uint64_t n, std::vector<
   return VS_OK;
 }
 
-static int fetch_headers(vs_result* r) {
-  if (r->have_headers) return VS_OK;
+// the per-region arrays (Q-sized: a few MB for the largest batches)
+static int fetch_region_meta(vs_result* r) {
+  if (r->have_meta) return VS_OK;
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
   const DevResult& d = r->d;
@@ -575,6 +626,17 @@ static int fetch_headers(vs_result* r) {
   VS_TRY(fetch(idx, r->h_var_begin, (const uint64_t*)d.var_begin, d.Q + 1));
   VS_TRY(fetch(idx, r->h_car_base, (const uint64_t*)d.car_base, d.Q + 1));
   VS_TRY(fetch(idx, r->h_var_count, (const uint64_t*)d.var_count, d.Q));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
+  r->have_meta = true;
+  return VS_OK;
+}
+
+static int fetch_headers(vs_result* r) {
+  if (r->have_headers) return VS_OK;
+  vs_index* idx = r->idx;
+  VS_TRY(fetch_region_meta(r));
+  const DevResult& d = r->d;
   VS_TRY(fetch(idx, r->h_pos, (const uint64_t*)d.r_pos, d.A));
   VS_TRY(fetch(idx, r->h_ref_off, (const uint32_t*)d.r_ref_off, d.A));
   VS_TRY(fetch(idx, r->h_ref_len, (const uint32_t*)d.r_ref_len, d.A));
@@ -590,7 +652,6 @@ static int fetch_headers(vs_result* r) {
     for (uint64_t a = 0; a < d.A; ++a) { r->h_car_begin_view[a] = acc; acc += r->h_car_count[a]; }
     r->n_view_carriers = acc;
   }
-  for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
   r->have_headers = true;
   return VS_OK;
 }
@@ -598,6 +659,7 @@ static int fetch_headers(vs_result* r) {
 // Query types 2 and 3: count pieces and bytes per region, scan, emit the piece list, decode it.
 static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r) {
   DevSeqResult& q = r->sq;
+  if (idx->srv_alive) VS_TRY(server_stop(idx));
   q.Q = n;
   r->d.Q = n;
   uint64_t* dreg = nullptr;
@@ -620,7 +682,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   uint64_t totals[2] = {0, 0};
   // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
   // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
-  bool single_walk = n > 0 && getenv("VS_SEQ_TWO_WALKS") == nullptr;
+  bool single_walk = n > 0 && !idx->opts.seq_two_walks;
   if (single_walk) {
     VS_TRY(ralloc(r, 1, &q.overflow));
     HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
@@ -724,8 +786,10 @@ static void host_region_size(const vs_index* idx, uint64_t x, uint64_t y, uint64
 }
 
 // ---- resident query server (kernels.hip.h: k_query_server) ----
-constexpr unsigned kSrvBlocks = 16;                 // 64 waves share a request's 4-slot tasks
-constexpr uint64_t kSrvMaxTasks = 2 * kSrvBlocks * 4;   // larger requests are better off with a launch sized for them
+constexpr uint64_t kSrvMaxTasks = 2 * 16 * 4;       // (16 blocks = 64 waves share a request's 4-slot tasks) larger requests are better
+                                                    // off with a launch sized for them
+constexpr uint32_t kSrvStreak = 4;                  // opts.server == 1: this many small queries back to back start the server
+constexpr auto kSrvStreakGap = std::chrono::microseconds(150);   // "back to back": the caller came back within this of the last answer
 constexpr uint64_t kSrvLifeTicks = 2000000;         // device clock, 100 MHz: 20 ms, then the kernel leaves by itself
 constexpr uint64_t kSrvIdleTicks = 100000;          // ... or 1 ms after the last request
 constexpr auto kSrvHostLife = std::chrono::milliseconds(14);     // the host replaces a server older than this
@@ -761,7 +825,7 @@ static int server_ensure(vs_index* idx) {
   const uint32_t gt_words = fill_gt_words(idx);
   const size_t lds_bytes = fill_lds_bytes(idx);
   volatile uint64_t* resp = idx->pinned + vs_index::kPinSrvResp;
-  const unsigned srv_blocks = getenv("VS_SRV_BLOCKS") ? (unsigned)atoi(getenv("VS_SRV_BLOCKS")) : kSrvBlocks;   // tuning aid
+  const unsigned srv_blocks = std::max(1u, idx->opts.srv_blocks);
   if (idx->d.wpc <= 63)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_server<false>), dim3(srv_blocks), dim3(256), lds_bytes, idx->srv_stream, idx->d,
                        (const ServerRequest*)rq, idx->srv_counter, resp, idx->srv_seq, gt_words, kSrvLifeTicks, kSrvIdleTicks);
@@ -795,23 +859,35 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     VS_TRY(ralloc(r, bytes, &slab));
     small_result_layout(d, slab, n, capA, capS, car_width);
   }
-  static const bool lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
-  const bool no_server = getenv("VS_NO_SERVER") != nullptr;   // read per call: tests switch between the two forms
+  const bool lat_debug = idx->opts.lat_debug;
   vs_timing& t = idx->timing;
   const auto host_prep = std::chrono::steady_clock::now();
+  // The resident server pays off for a client that asks again the moment it has its answer, and costs everybody else
+  // (it holds CUs for up to 1 ms after a request; a caller slower than its idle clock pays stop + restart).  So by
+  // default (opts.server == 1) it is started only once kSrvStreak small queries have arrived back to back, and a
+  // caller that pauses for longer than kSrvStreakGap goes back to the single launch.
+  if (idx->small_streak && host_enter - idx->last_small_done > kSrvStreakGap) idx->small_streak = 0;
+  idx->small_streak++;
+  const bool use_server = idx->opts.server == 2 || (idx->opts.server == 1 && idx->small_streak > kSrvStreak);
+  struct StreakStamp {   // every exit of this function is "the last small query was answered now"
+    vs_index* i;
+    ~StreakStamp() { i->last_small_done = std::chrono::steady_clock::now(); }
+  } streak_stamp{idx};
+  if (!use_server && idx->srv_alive) VS_TRY(server_stop(idx));
 
   // ---- resident server: no launch at all (requests small enough for its 64 waves) ----
-  if (!no_server && ntasks <= kSrvMaxTasks) {
+  if (use_server && ntasks <= kSrvMaxTasks) {
     VS_TRY(server_ensure(idx));
     ServerRequest* rq = srv_request(idx);
     const uint64_t seq = idx->srv_seq;
     volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(rq);
     if (n > 1) memcpy((void*)rq->xy, regions, n * 16);
-    w[1] = (uint64_t)slab; w[2] = capA; w[3] = capS; w[4] = n | (lat_debug ? 1ull << 16 : 0ull) | ((uint64_t)car_width << 32);
-    w[5] = regions[0].x; w[6] = regions[0].y;
+    const uint64_t body[6] = {(uint64_t)slab, capA, capS, n | (lat_debug ? 1ull << 16 : 0ull) | ((uint64_t)car_width << 32),
+                              regions[0].x, regions[0].y};
+    for (int i = 0; i < 6; ++i) w[1 + i] = body[i];
     std::atomic_thread_fence(std::memory_order_release);
-    w[7] = seq;                                   // tail, then head: a reader that sees both has the whole line
-    std::atomic_thread_fence(std::memory_order_release);
+    w[7] = server_request_tail(seq, body);        // the tail seals the body (sequence number ^ checksum): a reader that
+    std::atomic_thread_fence(std::memory_order_release);   // caught a half-written line sees a tail that does not match
     w[0] = seq;
     const auto posted_at = std::chrono::steady_clock::now();
     volatile uint64_t* resp = idx->pinned + vs_index::kPinSrvResp;
@@ -1071,6 +1147,33 @@ int64_t vs_index_out_neighbors(const vs_index* idx, uint32_t v, uint32_t* out, u
   return (int64_t)(e - b);
 }
 
+int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
+  if (!idx || !key) return fail(VS_ERR_ARG, "null argument");
+  EngineOpts& o = idx->opts;
+  const std::string k(key);
+  if (k == "latency_server") {
+    if (value < 0 || value > 2) return fail(VS_ERR_ARG, "latency_server takes 0 (never), 1 (back-to-back streaks) or 2 (always)");
+    if (idx->device >= 0 && idx->srv_alive) { HIP_TRY(hipSetDevice(idx->device)); VS_TRY(server_stop(idx)); }
+    o.server = (int)value; idx->small_streak = 0;
+  } else if (k == "server_blocks") {
+    if (value < 1 || value > 64) return fail(VS_ERR_ARG, "server_blocks takes 1..64");
+    if (idx->device >= 0 && idx->srv_alive) { HIP_TRY(hipSetDevice(idx->device)); VS_TRY(server_stop(idx)); }
+    o.srv_blocks = (unsigned)value;
+  } else if (k == "lat_debug") o.lat_debug = value != 0;
+  else if (k == "t4_two_walks") o.t4_two_walks = value != 0;
+  else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
+  else if (k == "t4_skip") o.t4_skip = value != 0;
+  else if (k == "fill_ablate" || k == "fill_lds_pad") {
+#ifdef VS_TUNING
+    if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
+    if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u; else o.fill_lds_pad = (size_t)value;
+#else
+    return fail(VS_ERR_UNSUPPORTED, "%s exists in tuning builds only (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force)", key);
+#endif
+  } else return fail(VS_ERR_ARG, "unknown option %s", key);
+  return VS_OK;
+}
+
 int vs_index_last_timing(const vs_index* idx, vs_timing* t) {
   if (!idx || !t) return fail(VS_ERR_ARG, "null argument");
   *t = idx->timing;
@@ -1118,6 +1221,19 @@ int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, u
   r->idx = idx;
   idx->live_results++;
   const int rc = run_var_in_ref(idx, device_regions, n, r, kNone, nullptr, 0, nullptr, 4, /*regions_on_device=*/true);
+  if (rc != VS_OK) return drop_result(r, rc);
+  *out = r;
+  return VS_OK;
+}
+
+int vs_query_expand_site_ranges(vs_index* idx, const void* device_records, uint64_t n, vs_result** out) {
+  if (!idx || !out || (n && !device_records)) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  HIP_TRY(hipSetDevice(idx->device));
+  vs_result* r = new vs_result();
+  r->idx = idx;
+  idx->live_results++;
+  const int rc = run_var_in_ref(idx, nullptr, n, r, kNone, nullptr, 0, nullptr, 4, false, (const uint64_t*)device_records);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1321,14 +1437,23 @@ int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_varia
     if (n_bases) *n_bases = r->seq_bytes;
     return VS_OK;
   }
-  VS_TRY(fetch_headers(r));
-  if (!r->have_totals) {
-    uint64_t nv = 0, nc = 0, nb = 0;
-    for (uint64_t a = 0; a < r->d.A; ++a) {
-      if (r->h_vflags[a] & kVarDropped) continue;
-      nv++; nc += r->h_car_count[a]; nb += r->h_ref_len[a] + r->h_alt_len[a];
+  if (!r->have_totals) {   // reduced on the device: nothing but three words crosses PCIe
+    vs_index* idx = r->idx;
+    HIP_TRY(hipSetDevice(idx->device));
+    ScratchBufs tmp(idx);
+    void* dt = nullptr;
+    VS_TRY(dev_alloc(idx, 24, &dt, &tmp.bufs));
+    HIP_TRY(hipMemsetAsync(dt, 0, 24, idx->stream));
+    if (r->d.A) {
+      const uint64_t blocks = std::min<uint64_t>((r->d.A + 255) / 256, 4096);
+      hipLaunchKernelGGL(k_result_totals, dim3((unsigned)blocks), dim3(256), 0, idx->stream, r->d, (unsigned long long*)dt);
+      HIP_TRY(hipGetLastError());
     }
-    r->n_variants = nv; r->n_carriers_kept = nc; r->n_bases = nb; r->have_totals = true;
+    uint64_t h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, dt, 24, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    tmp.release();
+    r->n_variants = h[0]; r->n_carriers_kept = h[1]; r->n_bases = h[2]; r->have_totals = true;
   }
   if (n_regions) *n_regions = r->d.Q;
   if (n_variants) *n_variants = r->n_variants;
@@ -1351,13 +1476,35 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
     if (len) *len = r->text.size();
     return VS_OK;
   }
-  VS_TRY(fetch_headers(r));
+  VS_TRY(fetch_region_meta(r));
   if (q >= r->d.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
   vs_index* idx = r->idx;
   const uint64_t a0 = r->h_var_begin[q], a1 = r->h_var_begin[q + 1];
   const uint64_t c0 = r->h_car_base[q], c1 = r->h_car_base[q + 1];
   const uint32_t* car = nullptr;
   const bool from_view = r->have_carriers;
+  // the rows: the whole table when a view has already brought it over, otherwise this region's slice of it
+  const uint64_t *h_pos, *h_car_begin;
+  const uint32_t *h_ref_off, *h_ref_len, *h_alt_off, *h_alt_len, *h_vflags, *h_car_count;
+  if (r->have_headers) {
+    h_pos = r->h_pos.data(); h_car_begin = r->h_car_begin.data(); h_ref_off = r->h_ref_off.data(); h_ref_len = r->h_ref_len.data();
+    h_alt_off = r->h_alt_off.data(); h_alt_len = r->h_alt_len.data(); h_vflags = r->h_vflags.data(); h_car_count = r->h_car_count.data();
+  } else {
+    const DevResult& d = r->d;
+    const size_t na = a1 - a0;
+    VS_TRY(fetch(idx, r->sl_pos, (const uint64_t*)d.r_pos + a0, na));
+    VS_TRY(fetch(idx, r->sl_car_begin, (const uint64_t*)d.r_car_begin + a0, na));
+    VS_TRY(fetch(idx, r->sl_ref_off, (const uint32_t*)d.r_ref_off + a0, na));
+    VS_TRY(fetch(idx, r->sl_ref_len, (const uint32_t*)d.r_ref_len + a0, na));
+    VS_TRY(fetch(idx, r->sl_alt_off, (const uint32_t*)d.r_alt_off + a0, na));
+    VS_TRY(fetch(idx, r->sl_alt_len, (const uint32_t*)d.r_alt_len + a0, na));
+    VS_TRY(fetch(idx, r->sl_vflags, (const uint32_t*)d.r_flags + a0, na));
+    VS_TRY(fetch(idx, r->sl_car_count, (const uint32_t*)d.r_car_count + a0, na));
+    if (na == 0) HIP_TRY(hipStreamSynchronize(idx->stream));   // (fetch_carriers below synchronises otherwise)
+    h_pos = r->sl_pos.data(); h_car_begin = r->sl_car_begin.data(); h_ref_off = r->sl_ref_off.data(); h_ref_len = r->sl_ref_len.data();
+    h_alt_off = r->sl_alt_off.data(); h_alt_len = r->sl_alt_len.data(); h_vflags = r->sl_vflags.data(); h_car_count = r->sl_car_count.data();
+  }
+  const uint64_t ob = r->have_headers ? 0 : a0;   // index base of the row arrays above
   if (!from_view) {
     VS_TRY(fetch_carriers(r, c0, c1 - c0, r->slice_carriers));
     car = r->slice_carriers.data();
@@ -1366,9 +1513,9 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   out.clear();
   if (r->kind == 7) {  // samples_has_var's output line, query.h:811-816: `name gt` pairs with nothing between them
     for (uint64_t a = a0; a < a1; ++a) {
-      if (r->h_vflags[a] & kVarDropped) continue;
-      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (r->h_car_begin[a] - c0);
-      for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
+      if (h_vflags[a - ob] & kVarDropped) continue;
+      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (h_car_begin[a - ob] - c0);
+      for (uint32_t k = 0; k < h_car_count[a - ob]; ++k) {
         const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
         out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
         out += ' ';
@@ -1389,15 +1536,15 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   }
   out += "Pos\tRef\tAlt\tSamples\n";  // print_header, query.h:38-41
   for (uint64_t a = a0; a < a1; ++a) {
-    if (r->h_vflags[a] & kVarDropped) continue;
-    out += std::to_string(r->h_pos[a]);  // print_var, query.h:43-50
+    if (h_vflags[a - ob] & kVarDropped) continue;
+    out += std::to_string(h_pos[a - ob]);  // print_var, query.h:43-50
     out += '\t';
-    out.append(idx->seq_chars, r->h_ref_off[a], r->h_ref_len[a]);
+    out.append(idx->seq_chars, h_ref_off[a - ob], h_ref_len[a - ob]);
     out += '\t';
-    out.append(idx->seq_chars, r->h_alt_off[a], r->h_alt_len[a]);
+    out.append(idx->seq_chars, h_alt_off[a - ob], h_alt_len[a - ob]);
     out += '\t';
-    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (r->h_car_begin[a] - c0);
-    for (uint32_t k = 0; k < r->h_car_count[a]; ++k) {
+    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (h_car_begin[a - ob] - c0);
+    for (uint32_t k = 0; k < h_car_count[a - ob]; ++k) {
       const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
       out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
       out += '(';

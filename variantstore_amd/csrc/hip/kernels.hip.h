@@ -628,15 +628,16 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // lane) and the wave writes their carrier words into the arena.  Shared by k_fill_carriers (slots whose headers an
 // earlier kernel wrote) and k_query_small (single-launch latency path, slots read straight from the site table).
 // `lds_wave` is the wave's LDS block (slice_lds_words / gt_words + kRingWords words).
-// `ablate` is a profiling aid (bit0: skip listed/sparse, bit1: skip medium, bit2: skip dense); 0 in production.
+// `ablate_arg` is a profiling aid of tuning builds (TUNE: bit0 skip listed/sparse, bit1 skip medium, bit2 skip dense).
 // WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
 // fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
 // one wave of occupancy -- is compiled out.
 // EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
 // per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
-template <bool WIDE, bool EARLY_NIB>
+template <bool WIDE, bool EARLY_NIB, bool TUNE = false>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
-                                            uint64_t gt0, uint64_t cb, uint32_t ablate, uint32_t gt_words) {
+                                            uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words) {
+  const uint32_t ablate = TUNE ? ablate_arg : 0u;   // production instantiations carry no ablation tests
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   }
 }
 
-template <bool WIDE, uint32_t CH>
+template <bool WIDE, uint32_t CH, bool TUNE>
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1055,7 +1056,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
       cb = __builtin_nontemporal_load(&r.r_car_begin[a]);
     }
-    expand_task<WIDE, false>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
@@ -1237,10 +1238,19 @@ struct ServerRequest {        // mapped host memory, 64-byte aligned; the host w
   uint64_t cap_slots, cap_carriers;
   uint64_t n_and_width;       // regions | carrier width << 32
   uint64_t x0, y0;            // the first region (a single-region request is this one line)
-  uint64_t tail;              // == head once the line is complete
+  uint64_t tail;              // server_request_tail(head, body): seals the six words above
   uint64_t xy[128];           // all regions
 };
 static_assert(sizeof(ServerRequest) == 64 + 1024, "request layout");
+// The tail word seals the line: sequence number mixed with a checksum of the six body words.  The device accepts a
+// line only when head == the expected sequence number AND tail matches the body it read, so the hand-off does not
+// depend on the eight 8-byte loads of the poll being served as one 64-byte transaction (a torn read -- new head and
+// tail, old body -- fails the checksum and is simply polled again).
+__host__ __device__ inline uint64_t server_request_tail(uint64_t seq, const uint64_t body[6]) {
+  uint64_t h = seq * 0x9E3779B97F4A7C15ULL;
+  for (int i = 0; i < 6; ++i) { h = (h ^ body[i]) * 0xff51afd7ed558ccdULL; h ^= h >> 29; }
+  return h;
+}
 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_query_server(DevImage im, const ServerRequest* req, unsigned long long* done_counter,
@@ -1267,8 +1277,13 @@ __global__ void __launch_bounds__(256) k_query_server(DevImage im, const ServerR
         if (lane < 8) w = __hip_atomic_load(reqw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint64_t head = wave_bcast64(w, 0), tail = wave_bcast64(w, 7);
         const uint64_t now = wall_clock64();
+        bool sealed = false;
+        if (head == expect) {
+          const uint64_t body[6] = {wave_bcast64(w, 1), wave_bcast64(w, 2), wave_bcast64(w, 3), wave_bcast64(w, 4), wave_bcast64(w, 5), wave_bcast64(w, 6)};
+          sealed = tail == server_request_tail(expect, body);
+        }
         if (head == ~0ULL || now - t_start > life_ticks || now - t_last > idle_ticks) state = 2;
-        else if (head == expect && tail == expect) {
+        else if (sealed) {
           if (lane < 8) s_req[lane] = w;
           const uint32_t n = (uint32_t)wave_bcast64(w, 4) & 0xFFFFu;
           if (n > 1) {   // the other regions: one more round trip
@@ -1547,7 +1562,7 @@ __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r
 
 // Compact hit lists for a collective: the index (and so the site table) is replicated on every rank,
 // therefore a region's variant list is fully described by its site range.  4 x uint64 per region:
-//   {region_base + q, first site | region flags << 32 | has-dropped << 40, variants reported, carriers}
+//   {region_base + q, first site | region flags << 32 | has-dropped << 40, sites | variants reported << 32, carriers}
 __global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst, uint64_t region_base) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
@@ -1555,8 +1570,26 @@ __global__ void __launch_bounds__(256) k_pack_regions(DevResult r, uint64_t* dst
   const uint64_t dropped = r.var_count[q] != r.q_nvar[q] ? 1ULL : 0ULL;
   dst[4 * q + 0] = region_base + q;
   dst[4 * q + 1] = (uint64_t)r.q_g0[q] | (fl << 32) | (dropped << 40);
-  dst[4 * q + 2] = r.var_count[q];
+  dst[4 * q + 2] = (r.q_nvar[q] & 0xFFFFFFFFULL) | (r.var_count[q] << 32);
   dst[4 * q + 3] = r.q_ncar[q];   // carriers of the reported variants (the arena range car_base[q+1] - car_base[q] is padded)
+}
+
+// The receiving side of that collective: region bounds of a batch taken from gathered records instead of from
+// (x, y) -- the site range is the answer of Index::find + the walk's stop rule on the rank that produced the record,
+// and the replicated site table expands it to the same rows here (k_emit_headers / k_dedup_slow / k_fill_carriers).
+// A record whose range does not fit this index's site table marks its region invalid.
+__global__ void __launch_bounds__(256) k_bounds_from_records(DevImage im, DevResult r, const uint64_t* recs) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t w1 = recs[4 * q + 1], w2 = recs[4 * q + 2];
+  uint32_t g0 = (uint32_t)w1, nsites = (uint32_t)w2;
+  uint8_t fl = (uint8_t)((w1 >> 32) & (kRegionEmpty | kRegionInvalid | kRegionNotFound | kRegionEndless));
+  if ((uint64_t)g0 + nsites > im.G) { g0 = 0; nsites = 0; fl = kRegionInvalid; }
+  if ((w1 >> 40) & 1) fl |= kRegionSlow;   // the producing rank dropped rows: the literal rule runs again here
+  r.q_flags[q] = fl;
+  r.q_g0[q] = g0;
+  r.q_nvar[q] = nsites;
+  r.q_ncar[q] = im.s_carpre[g0 + nsites] - im.s_carpre[g0];
 }
 
 // ---------------------------------------------------------------------------
@@ -2012,6 +2045,17 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
       }
     }
   }
+}
+
+// Totals of a result without copying it: {variants reported, their carriers, their REF + ALT bases}
+__global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned long long* out) {
+  unsigned long long nv = 0, nc = 0, nb = 0;
+  for (uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; a < r.A; a += (uint64_t)gridDim.x * blockDim.x) {
+    if (r.r_flags[a] & kVarDropped) continue;
+    nv += 1; nc += r.r_car_count[a]; nb += (uint64_t)r.r_ref_len[a] + r.r_alt_len[a];
+  }
+  for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); nc += __shfl_down(nc, d, 64); nb += __shfl_down(nb, d, 64); }
+  if ((threadIdx.x & 63) == 0 && (nv | nb)) { atomicAdd(out, nv); atomicAdd(out + 1, nc); atomicAdd(out + 2, nb); }
 }
 
 // Index::find batched (index.h:119-133)

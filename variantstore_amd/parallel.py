@@ -77,3 +77,22 @@ def unpack_records(records, counts):
             "car_count": (a[:, 3] >> np.uint64(32)).astype(np.uint32),
         })
     return out
+
+
+def unpack_region_records(records, counts):
+    """Host view of gathered COMPACT records (vs_result_pack_regions): per rank a dict of numpy arrays.  The device
+    tensor itself is what `VariantStore.expand_site_ranges` takes to rebuild the rows on the receiving rank."""
+    out = []
+    rec = records.cpu().numpy().view(np.uint64)
+    for r in range(rec.shape[0]):
+        a = rec[r, : int(counts[r])]
+        out.append({
+            "region": a[:, 0].copy(),
+            "first_site": (a[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+            "region_flags": ((a[:, 1] >> np.uint64(32)) & np.uint64(0xFF)).astype(np.uint8),
+            "has_dropped": ((a[:, 1] >> np.uint64(40)) & np.uint64(1)).astype(bool),
+            "sites": (a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+            "variants": (a[:, 2] >> np.uint64(32)).astype(np.uint64),
+            "carriers": a[:, 3].copy(),
+        })
+    return out
