@@ -138,3 +138,28 @@ def test_one_million_region_batch_on_one_gpu(big):
     b = vs.expand_site_ranges(recs.data_ptr(), 1_000_000)
     assert (b.totals(), b.digest()) == (ta, da)
     b.close()
+
+
+def test_type4_event_bitmap_walk_equals_the_literal_walk_at_full_size(big):
+    """Query type 4 over the whole 100 k-region batch, 16 samples round-robin (the bench's leg): the walk that jumps
+    over uneventful ref-path runs with the per-sample event bitmaps gives the digest, the totals and the rows of the
+    walk that visits every vertex."""
+    vs, regions = big
+    assert vs.info().num_samples == 2505
+    sids = np.array([1 + ((i % 16) * 157) % 2504 for i in range(len(regions))], dtype=np.uint32)
+    fast = vs.get_sample_var_in_ref(regions, sids)
+    tf, df = fast.totals(), fast.digest()
+    assert tf[1] > 500_000
+    vs.set_option("t4_skip", 0)
+    try:
+        slow = vs.get_sample_var_in_ref(regions, sids)
+    finally:
+        vs.set_option("t4_skip", 1)
+    assert (slow.totals(), slow.digest()) == (tf, df)
+    for q in (0, 17, 50_001, 99_999):
+        assert fast.region_text(q) == slow.region_text(q)
+    vf, vl = fast.view(False), slow.view(False)
+    for k in ("region_flags", "var_begin", "var_count", "pos", "ref_off", "ref_len", "alt_off", "alt_len", "car_count"):
+        assert np.array_equal(vf[k], vl[k]), k
+    fast.close()
+    slow.close()

@@ -25,10 +25,11 @@ for name, ctr in raw.items():
     short = next((v for k, v in SHORT.items() if k in name), None)
     if short is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
         continue
-    if short in kernels and kernels[short]["_launches"] >= ctr["_launches"]:
-        continue  # (template instantiations: keep the one that ran most)
+    grid = int(name.rsplit("[grid ", 1)[1].rstrip("]"))
+    if short in kernels and kernels[short]["grid"] >= grid:
+        continue  # (a kernel that ran in several shapes: the bench batch is the largest)
     fetch, write = ctr["FETCH_SIZE"] * 1024, ctr["WRITE_SIZE"] * 1024
-    e = {"full_name": name, "_launches": ctr["_launches"], "FETCH_SIZE_KiB": ctr["FETCH_SIZE"], "WRITE_SIZE_KiB": ctr["WRITE_SIZE"],
+    e = {"full_name": name, "grid": grid, "_launches": ctr["_launches"], "avg_us_under_pmc": ctr["_avg_us"], "FETCH_SIZE_KiB": ctr["FETCH_SIZE"], "WRITE_SIZE_KiB": ctr["WRITE_SIZE"],
          "traffic_bytes_per_launch": int(2 * fetch + write), "traffic_bytes_per_launch_uncorrected": int(fetch + write)}
     hit, miss = ctr.get("TCC_HIT_sum", ctr.get("TCC_HIT")), ctr.get("TCC_MISS_sum", ctr.get("TCC_MISS"))
     if hit is not None and miss is not None and hit + miss > 0:

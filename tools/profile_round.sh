@@ -1,21 +1,27 @@
 #!/bin/bash
 # One profiling round of the bench command on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag> [workload]
-#  1. rocprofv3 --kernel-trace --stats            -> profiles/<tag>_kernel_stats.txt
-#  2. rocprofv3 --pmc, one pass per counter group -> profiles/<tag>_pmc.json, profiles/traffic_<workload>.json
-#  3. the bench line of the same tree             -> profiles/<tag>_bench.json
+#  1. rocprofv3 --kernel-trace --stats (headline batch alone; then with the type-4 leg)
+#                                                 -> <tag>_kernel_stats.txt, <tag>_kernel_stats_t4.txt
+#  2. rocprofv3 --pmc, one pass per counter group -> <tag>_pmc.json, traffic_<workload>.json
+#  3. the bench line of the same tree             -> <tag>_bench.json
+# Everything lands in gpurun_out/profiles_<tag>/ (the only directory that travels back); copy what is to be kept into profiles/.
 # The program after `--` is python3 itself (no env/bash hops: the profiler has initialised the GPU by then);
 # counters are never combined with tracing.
 tag=$1; wl=${2:-chr1-2504}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
 cd /tmp
+ARGS0="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras none --workload $wl"
 ARGS="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras t4 --workload $wl"
-mkdir -p $R/gpurun_out $R/profiles
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_$tag.log 2>&1
+O=$R/gpurun_out/profiles_$tag
+mkdir -p $O
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py $ARGS0 > $R/gpurun_out/prof_$tag.log 2>&1
 echo "kernel-trace rc=$?"
-db=$(ls $R/gpurun_out/prof_$tag/*/*results.db $R/gpurun_out/prof_$tag/*results.db 2>/dev/null | head -1)
-python3 $R/tools/prof_summary.py $db "rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS" > $R/profiles/${tag}_kernel_stats.txt
+python3 $R/tools/prof_summary.py $R/gpurun_out/prof_$tag/p_results.db "rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS0" > $O/${tag}_kernel_stats.txt
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_t4 -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${tag}_t4.log 2>&1
+echo "kernel-trace (with type 4) rc=$?"
+python3 $R/tools/prof_summary.py $R/gpurun_out/prof_${tag}_t4/p_results.db "rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS" > $O/${tag}_kernel_stats_t4.txt
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
              "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
@@ -25,8 +31,9 @@ for group in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   echo "pmc pass $i ($group): rc=$?"
 done
 cd $R
-python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_1 gpurun_out/pmc_${tag}_2 gpurun_out/pmc_${tag}_3 gpurun_out/pmc_${tag}_4 > profiles/${tag}_pmc.json
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_1 gpurun_out/pmc_${tag}_2 gpurun_out/pmc_${tag}_3 gpurun_out/pmc_${tag}_4 > $O/${tag}_pmc.json
 python3 tools/make_traffic_json.py $wl $tag gpurun_out/pmc_${tag}_1 gpurun_out/pmc_${tag}_2 gpurun_out/pmc_${tag}_3 gpurun_out/pmc_${tag}_4
-python3 bench.py --workload $wl > profiles/${tag}_bench.json 2> gpurun_out/${tag}_bench_err.log
+cp profiles/traffic_$wl.json $O/
+python3 bench.py --workload $wl > $O/${tag}_bench.json 2> gpurun_out/${tag}_bench_err.log
 echo "bench rc=$?"
-tail -c 600 profiles/${tag}_bench.json
+tail -c 600 $O/${tag}_bench.json

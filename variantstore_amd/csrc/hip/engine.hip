@@ -59,6 +59,7 @@ struct EngineOpts {
   bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
   bool seq_two_walks = false;   // the same for types 2 / 3
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
+  bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
   size_t fill_lds_pad = 0;      // tuning builds only: pad the fill kernel's LDS block (occupancy experiments)
 };
@@ -367,6 +368,29 @@ static int build_device_image(vs_index* idx) {
   }
   VS_TRY(upload_image(idx, sus_g, &d.sus_g));
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
+  // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
+  //      what this part has plenty of).  Skipped when they would take more than a third of the free memory or 64 GB. ----
+  d.t4_events = nullptr; d.t4_stride = 0;
+  if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
+    const uint64_t stride = (im.P + 63) / 64 + 1;
+    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (bytes <= (64ull << 30) && bytes <= free_b / 3) {
+      uint64_t* events = nullptr;
+      VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
+      HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
+      d.t4_stride = stride;
+      const unsigned tiles = (unsigned)((im.P + 63) / 64);
+      if (d.use_bv) hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
+      else {
+        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
+        hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
+      }
+      HIP_TRY(hipGetLastError());
+      d.t4_events = events;
+    }
+  }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   return VS_OK;
 }
@@ -381,6 +405,7 @@ static void read_env_opts(vs_index* idx) {
   o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
+  o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 }
 
@@ -459,6 +484,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
   WalkScratch ws{};
   bool single_walk = false;
+  DevImage dwalk = idx->d;   // what the type-4 walk sees: with or without the event bitmaps
+  if (!idx->opts.t4_skip) dwalk.t4_events = nullptr;
   if (n && t4 && !idx->opts.t4_two_walks) {
     if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
@@ -478,7 +505,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch.bufs));
     HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, ws);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
   }
@@ -486,7 +513,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (single_walk) {
   } else if (n) {
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
     else if (site_records) hipLaunchKernelGGL(k_bounds_from_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, site_records);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
@@ -502,7 +529,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
     HIP_TRY(hipStreamSynchronize(idx->stream));
     totals[0] = ((volatile uint64_t*)pin_totals)[0];
@@ -531,7 +558,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (n) {
     if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
+    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
       hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);

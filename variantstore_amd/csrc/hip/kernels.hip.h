@@ -82,6 +82,13 @@ struct DevImage {
   const uint64_t* rp_kpre;        // [P+1] s_kpre likewise
   uint32_t n_sus, has_car_index;
   uint32_t list_max, pad2_;
+  // Query type 4: per-sample EVENT bitmaps over the ref-path slots (k_build_events).  Bit j of row s is set when a walk
+  // of sample s's path can do anything but step from slot j to slot j + 1 there: the node or one of its out-neighbours
+  // holds s, or the node is irregular (its last ref neighbour is not its path successor / it ends the path).  Runs of
+  // clear bits are skipped by k_sample_walk.  NULL: not built (over budget, or an index whose slots do not map onto
+  // the rank structure one to one) -- the walk then visits every vertex.
+  const uint64_t* t4_events;
+  uint64_t t4_stride;       // 64-bit words per sample row: ceil(P / 64) + 1
 };
 
 struct DevResult {
@@ -1367,6 +1374,91 @@ __device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v
   return false;
 }
 
+// ---------------------------------------------------------------------------
+// Event bitmaps of query type 4 (DevImage::t4_events), built once when an index is opened.
+// One wave per tile of 64 consecutive ref-path slots: lane j ORs the class rows of slot j's node and of its
+// out-neighbours one 64-sample word at a time, a 64 x 64 bit transpose through 64 ballots turns "samples of a slot"
+// into "slots of a sample", and lane t stores the tile's word of sample w * 64 + t.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool slot_is_irregular(const DevImage& im, uint64_t j) {
+  // the walk's "last ref neighbour" (next_ref_pos / cur_ref of query.h:640-667) must be the path successor, and there
+  // must be one; anything else is walked literally
+  if (j + 1 >= im.P) return true;
+  const uint32_t v = im.rp_vid[j], succ = im.rp_vid[j + 1];
+  uint32_t last_ref = kNone;
+  for (uint32_t e = im.row_ptr[v]; e < im.row_ptr[v + 1]; ++e)
+    if (im.v_ridx[im.col[e]]) last_ref = im.col[e];
+  return last_ref != succ;
+}
+
+__global__ void __launch_bounds__(256) k_build_events(DevImage im, uint64_t* events) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t tile = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t ntiles = (im.P + 63) >> 6;
+  if (tile >= ntiles) return;
+  const uint64_t j = tile * 64 + lane;
+  const bool valid = j < im.P;
+  const uint64_t irr = __ballot(valid && slot_is_irregular(im, j));
+  const uint32_t v = valid ? im.rp_vid[j] : 0;
+  const uint32_t e0 = valid ? im.row_ptr[v] : 0, e1 = valid ? im.row_ptr[v + 1] : 0;
+  const uint32_t wpc = im.wpc;
+  for (uint32_t w = 0; w < wpc; ++w) {
+    uint64_t word = 0;
+    if (valid) {
+      word = im.class_rows[(uint64_t)im.v_class[v] * wpc + w];
+      for (uint32_t e = e0; e < e1; ++e) word |= im.class_rows[(uint64_t)im.v_class[im.col[e]] * wpc + w];
+    }
+    uint64_t mine = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < 64; ++b) {
+      const uint64_t m = __ballot((word >> b) & 1);
+      if (lane == b) mine = m;
+    }
+    const uint32_t sample = w * 64 + lane;
+    if (sample >= 1 && sample < im.num_samples) events[(uint64_t)sample * im.t4_stride + tile] = mine | irr;
+  }
+}
+
+// explicit-id cohorts (no class rows): the rows start as the irregular mask, then every carrier record of a slot's
+// node and of its out-neighbours sets its sample's bit
+__global__ void __launch_bounds__(256) k_events_irregular_rows(DevImage im, uint64_t* events) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t tile = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t ntiles = (im.P + 63) >> 6;
+  if (tile >= ntiles) return;
+  const uint64_t j = tile * 64 + lane;
+  const uint64_t irr = __ballot(j < im.P && slot_is_irregular(im, j));
+  for (uint32_t s = 1 + lane; s < im.num_samples; s += 64) events[(uint64_t)s * im.t4_stride + tile] = irr;
+}
+__global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* events) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= im.P) return;
+  const uint32_t v = im.rp_vid[j];
+  const unsigned long long bit = 1ULL << (j & 63);
+  const uint32_t e0 = im.row_ptr[v], e1 = im.row_ptr[v + 1];
+  for (uint32_t e = e0; e <= e1; ++e) {             // e == e1: the node itself
+    const uint32_t u = e < e1 ? im.col[e] : v;
+    const uint64_t b = im.v_car_begin[u];
+    for (uint32_t i = 0; i < im.v_ncar[u]; ++i) {
+      const uint32_t sid = im.car_sid[b + i];
+      if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&events[(uint64_t)sid * im.t4_stride + (j >> 6)], bit);
+    }
+  }
+}
+
+// first slot >= m whose bit is set in the sample's row, or `limit` when there is none below it (m < limit <= P)
+__device__ __forceinline__ uint32_t next_event_slot(const uint64_t* __restrict__ row, uint32_t m, uint32_t limit) {
+  uint32_t w = m >> 6;
+  const uint32_t w_end = (limit + 63) >> 6;
+  uint64_t word = row[w] & (~0ULL << (m & 63));
+  while (!word) {
+    if (++w >= w_end) return limit;
+    word = row[w];
+  }
+  const uint32_t k = (w << 6) + (uint32_t)__builtin_ctzll(word);
+  return k < limit ? k : limit;
+}
+
 // Walk records (device_image.hpp): one step of a path walk reads the current vertex in one 32-byte record and each
 // neighbour in one 16-byte edge record instead of gathering a dozen 4-byte fields from as many arrays.
 struct WalkVertex { uint32_t row_begin, deg, ridx, off, len, cls, ncar; };
@@ -1427,22 +1519,44 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
     }
     if (empty) fl = kRegionEmpty;
     else {
+      // Event bitmap of this sample (DevImage::t4_events): clear bits are ref-path slots where neither the node nor any
+      // of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do nothing
+      // there but step on, so both the backward search and the walk below jump over them.  Everything that happens at
+      // a set bit is the literal code.
+      const uint64_t* __restrict__ ev = (im.t4_events && sid != 0) ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr;
       // ---- get_prev_vertex_with_sample ----
-      uint64_t rank = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;  // find(pos, rank)
+      const uint64_t rank0 = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;  // find(pos, rank)
+      uint64_t rank = rank0;
       uint64_t ref_pos = 1;
       uint32_t start_v = 0;
+      bool jump = ev != nullptr, jumped = false;
       while (true) {
-        const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
-        if (rank <= 1) { ref_pos = 1; start_v = v; break; }
-        bool found = false;
+        const uint32_t pslot = im.rank_to_slot[rank == 0 ? 0 : rank - 1];  // Index::previous
+        if (rank <= 1) { ref_pos = 1; start_v = im.rp_vid[pslot]; break; }
+        if (jump && !((ev[pslot >> 6] >> (pslot & 63)) & 1)) {
+          // no out-neighbour of this node holds the sample: the scan below would find nothing and count the rank
+          // down once per neighbour (#branches + the path successor, which every node but the last has)
+          const uint32_t deg = im.rp_cand_prefix[pslot + 1] - im.rp_cand_prefix[pslot] + (pslot + 1 < im.P ? 1u : 0u);
+          rank = rank > deg ? rank - deg : 0;
+          jumped = true;
+          continue;
+        }
+        const uint32_t v = im.rp_vid[pslot];
+        bool found = false, had_ref = false;
         const WalkVertex wv = walk_vertex(im, v);
         for (uint32_t e = wv.row_begin; e < wv.row_begin + wv.deg; ++e) {
           const WalkEdge ed = walk_edge(im, e);
-          if (ed.ridx) ref_pos = ed.ridx;
+          if (ed.ridx) { ref_pos = ed.ridx; had_ref = true; }
           if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; }
           rank = rank ? rank - 1 : 0;  // the reference's unsigned counter would wrap here: clamped
         }
-        if (found) break;
+        if (found) {
+          // ref_pos is the last ref neighbour seen in ANY iteration so far: when this node has none of its own and
+          // iterations were jumped over, the value is not known -- search again, literally (a node without a ref
+          // neighbour is the end of the path: practically never)
+          if (!had_ref && jumped) { jump = false; jumped = false; rank = rank0; ref_pos = 1; start_v = 0; continue; }
+          break;
+        }
       }
       // ---- walk the sample's path ----
       uint32_t cur = start_v;
@@ -1451,10 +1565,28 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
       const uint64_t cb = EMIT ? r.car_base[q] : 0;
       WalkVertex wc = walk_vertex(im, cur);   // afterwards the record of a vertex arrives with the edge the walk takes to it
+      // first slot whose node starts at or after y: a walk that reaches it in step with the reference stops there
+      uint32_t limit = 0;
+      if (ev && y >= 1) { const uint32_t ry = rank1(im, y - 1); limit = im.rank_to_slot[ry < im.R ? ry : im.R]; }
       while (!done) {
         if (ref_pos >= y) break;
-        // (jumping over runs of forced, empty ref-path vertices was tried: in SNP-dense cohorts such runs are one
-        //  vertex long -- the 1-bp ref allele between two branching nodes -- and the two extra look-ups cost more)
+        if (ev && wc.ridx && ref_pos == wc.ridx) {
+          // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
+          // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
+          // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
+          // stop at `limit` if that comes first.  Arriving at k it holds {k's node, its index, cur_ref = k's node}.
+          const uint32_t slot1 = im.w_vertex[2 * (uint64_t)cur + 1].w;   // slot + 1; 0: not on the ref path
+          if (slot1 && slot1 - 1 < limit) {
+            const uint32_t k = next_event_slot(ev, slot1 - 1, limit);
+            if (k != slot1 - 1) {
+              if (k >= limit) break;
+              cur = im.rp_vid[k];
+              wc = walk_vertex(im, cur);
+              ref_pos = wc.ridx;
+              cur_ref_v = cur;
+            }
+          }
+        }
         uint64_t next_ref_pos = ref_pos + wc.len;
         uint32_t next_ref_v = kNone;   // the last ref neighbour: its sequence becomes cur_ref (read only when a substitution is emitted)
         uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;

@@ -80,7 +80,10 @@ struct HostImage {
   // its row_begin | its degree, offset, length, #carriers}: the first half answers the tests of a step, the second
   // half IS the neighbour's vertex record, so stepping onto it needs no further look-up -- two or three memory
   // accesses per step instead of a dozen scattered 4-byte reads.
-  std::vector<uint32_t> w_vertex;   // 8 words per vertex
+  std::vector<uint32_t> w_vertex;   // 8 words per vertex; word 7 = ref-path slot + 1 (0 for vertices off the path)
+  // every ref-path slot's node starts at the index of its rank (slots of rank r: [rank_to_slot[r], rank_to_slot[r+1])):
+  // what the type-4 event bitmaps rely on to find where a walk stops; false for an index that breaks it (never seen)
+  bool slots_follow_ranks = false;
   std::vector<uint32_t> w_edge;     // 8 words per CSR entry
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
@@ -243,6 +246,13 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     }
   }
 
+  im.slots_follow_ranks = im.R > 0 && im.rank_to_slot[0] == 0;
+  for (uint64_t r = 0; r < im.R && im.slots_follow_ranks; ++r) {
+    if (im.rank_to_slot[r] >= im.rank_to_slot[r + 1]) { im.slots_follow_ranks = false; break; }
+    for (uint32_t i = im.rank_to_slot[r]; i < im.rank_to_slot[r + 1]; ++i)
+      if (g.ref_index[im.rp_vid[i]] != g.idx_pos[r]) { im.slots_follow_ranks = false; break; }
+  }
+
   // ---- nri: ref index reached by one path step from a branch along its first carrier
   //      (query.h:353-365).  VS_NONE = "consecutive mutation": the reference then
   //      keeps the ref entry of the node the branch hangs off. ----
@@ -320,6 +330,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     w[0] = im.row_ptr[v]; w[1] = im.row_ptr[v + 1] - im.row_ptr[v]; w[2] = im.v_ridx[v]; w[3] = im.v_off[v];
     w[4] = im.v_len[v]; w[5] = im.v_class[v]; w[6] = im.v_ncar[v];
   }
+  for (uint64_t i = 0; i < im.P; ++i) im.w_vertex[(uint64_t)im.rp_vid[i] * 8 + 7] = (uint32_t)i + 1;   // ref-path slot + 1 (0: off the path)
   im.w_edge.assign(im.E * 8, 0);
   for (uint64_t e = 0; e < im.E; ++e) {
     const uint32_t n = im.col[e];
