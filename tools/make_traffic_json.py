@@ -17,6 +17,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 workload, tag, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+# the hash of the kernels the counters were taken on: recorded by the profiling run itself (profile_round.sh writes
+# kernels_blob.txt next to its outputs on the GPU box); only a summary made on that same tree may fall back to hashing
+blob = None
+if dirs and dirs[0].startswith("--blob="):
+    blob, dirs = dirs[0].split("=", 1)[1].strip(), dirs[1:]
 raw = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs))
 SHORT = {"k_fill_carriers": "k_fill_carriers", "k_emit_headers": "k_emit_headers", "k_sample_walk": "k_sample_walk",
          "k_emit_from_walk": "k_emit_from_walk", "k_region_bounds": "k_region_bounds"}
@@ -38,7 +43,7 @@ for name, ctr in raw.items():
         if k.startswith("SQ_") or k.startswith("GRBM_"):
             e[k] = v
     kernels[short] = e
-out = {"workload": workload, "tag": tag, "kernels_blob": bench.git_blob_hash(bench.KERNEL_SOURCE),
+out = {"workload": workload, "tag": tag, "kernels_blob": blob or bench.git_blob_hash(bench.KERNEL_SOURCE),
        "note": "separate rocprofv3 --pmc passes of `python3 bench.py --steps 6 --warmup 2 --extras t4` (tools/profile_round.sh); "
                "means over all launches of a kernel; traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; an "
                "upper bound where reads are narrow)",
