@@ -225,7 +225,8 @@ void vs_result_free(vs_result* r);
  * The environment is read once when a handle is opened; afterwards only this call changes a
  * switch.  Keys: "latency_server" 0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first
  * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
- * form the event bitmaps shortcut); "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
+ * chosen from the batch's shape); "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
  * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
 int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 

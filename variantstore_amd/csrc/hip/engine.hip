@@ -59,6 +59,7 @@ struct EngineOpts {
   bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
   bool seq_two_walks = false;   // the same for types 2 / 3
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
+  uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
   size_t fill_lds_pad = 0;      // tuning builds only: pad the fill kernel's LDS block (occupancy experiments)
@@ -285,6 +286,12 @@ static int build_device_image(vs_index* idx) {
     VS_TRY(upload_image(idx, im.w_edge, &we));
     d.w_vertex = reinterpret_cast<const uint4*>(wv);
     d.w_edge = reinterpret_cast<const uint4*>(we);
+    const uint32_t *rw = nullptr, *rb = nullptr;
+    VS_TRY(upload_image(idx, im.e_slot, &d.e_slot));
+    VS_TRY(upload_image(idx, im.rp_walk, &rw));
+    VS_TRY(upload_image(idx, im.rk_back, &rb));
+    d.rp_walk = reinterpret_cast<const uint4*>(rw);
+    d.rk_back = reinterpret_cast<const uint2*>(rb);
   }
   VS_TRY(upload_image(idx, im.v_ncar, &d.v_ncar));
   VS_TRY(upload_image(idx, im.v_nri, &d.v_nri));
@@ -579,9 +586,13 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (d.A) {
     {
-      const uint64_t nchunks = (d.A + 63) / 64;
-      // one 64-slot task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
-      // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time)
+      // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
+      // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time).
+      // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
+      // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
+      uint32_t chunk = idx->opts.fill_chunk;
+      if (chunk == 0) chunk = (d.A < 64ull * 8192 * 8 && d.S / d.A >= 256) ? 16 : 64;
+      const uint64_t nchunks = (d.A + chunk - 1) / chunk;
       const uint64_t blocks = (nchunks + 3) / 4;
       if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
@@ -595,10 +606,14 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint32_t ablate = 0;
       constexpr bool kTune = false;
 #endif
-      if (idx->d.wpc <= 63)
+      if (idx->d.wpc <= 63 && chunk == 64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
-      else
+      else if (idx->d.wpc <= 63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+      else if (chunk == 64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
     }
     HIP_TRY(hipGetLastError());
   }
@@ -1190,6 +1205,10 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_two_walks") o.t4_two_walks = value != 0;
   else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
   else if (k == "t4_skip") o.t4_skip = value != 0;
+  else if (k == "fill_chunk") {
+    if (value != 0 && value != 16 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 16 or 64");
+    o.fill_chunk = (uint32_t)value;
+  }
   else if (k == "fill_ablate" || k == "fill_lds_pad") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);

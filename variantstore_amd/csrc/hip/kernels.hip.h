@@ -89,6 +89,10 @@ struct DevImage {
   // the rank structure one to one) -- the walk then visits every vertex.
   const uint64_t* t4_events;
   uint64_t t4_stride;       // 64-bit words per sample row: ceil(P / 64) + 1
+  // walk tables beside the records above (device_image.hpp)
+  const uint32_t* e_slot;   // [E] ref-path slot + 1 of each CSR entry's neighbour (0: not on the path)
+  const uint4* rp_walk;     // [P] 2 x uint4 per ref-path slot: the vertex record of its node, word 7 = the vertex id
+  const uint2* rk_back;     // [R] per rank r: {first ref-path slot of r (= Index::previous(r + 1)), out-degree of that node}
 };
 
 struct DevResult {
@@ -541,6 +545,7 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 //    wave take the out-of-line generic path.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
+constexpr uint32_t kFillChunkDense = 16;     // throughput launches over few, carrier-heavy variants (type-4 batches)
 constexpr uint32_t kFillChunkSmall = 4;      // latency launches (a handful of regions): more waves per region
 constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
 // per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
@@ -1498,6 +1503,72 @@ struct WalkScratch {
   uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path)
 };
 
+// One literal step's view of a vertex's out-edges, read with memory-level parallelism: all edge records (and, for
+// ref neighbours, their ref-path slots) are requested together, then all class words; the reference's in-order
+// decision logic runs over registers.  Up to kStepEdges edges; higher degrees (rare) take the one-at-a-time loop.
+constexpr uint32_t kStepEdges = 4;
+struct StepOut {
+  uint64_t next_ref_pos;      // ref index of the LAST ref neighbour (unchanged if there is none)
+  uint32_t next_ref_v;        // that neighbour (kNone: none)
+  uint32_t nxt;               // get_neighbor_vertex: first neighbour holding the sample, else the ref neighbour with the smallest index; 0 = none
+  uint32_t nxt_slot1;         // its ref-path slot + 1 (0: not on the path)
+  WalkVertex wn;              // its vertex record
+};
+__device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, const WalkVertex& wc, uint32_t sid, uint64_t next_ref_pos_default) {
+  StepOut o;
+  o.next_ref_pos = next_ref_pos_default; o.next_ref_v = kNone; o.nxt = 0; o.nxt_slot1 = 0; o.wn = WalkVertex{};
+  uint32_t min_idx = 0xFFFFFFFFu;
+  bool nxt_by_sample = false;
+  if (wc.deg <= kStepEdges && im.use_bv) {
+    uint4 a[kStepEdges], b[kStepEdges];
+    uint32_t es[kStepEdges];
+    uint64_t cw[kStepEdges];
+#pragma unroll
+    for (uint32_t i = 0; i < kStepEdges; ++i) {
+      a[i] = uint4{0, 0, 0, 0}; b[i] = uint4{0, 0, 0, 0}; es[i] = 0;
+      if (i < wc.deg) {
+        a[i] = im.w_edge[2 * (uint64_t)(wc.row_begin + i)];
+        b[i] = im.w_edge[2 * (uint64_t)(wc.row_begin + i) + 1];
+        es[i] = im.e_slot[wc.row_begin + i];
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kStepEdges; ++i) {
+      cw[i] = 0;
+      if (i < wc.deg && sid != 0) cw[i] = im.class_rows[(uint64_t)a[i].z * im.wpc + (sid >> 6)];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kStepEdges; ++i) {
+      if (i >= wc.deg) break;
+      const uint32_t n = a[i].x, nr = a[i].y;
+      if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
+      if (!nxt_by_sample) {
+        const bool holds = sid != 0 && ((cw[i] >> (sid & 63)) & 1);
+        if (holds || (nr && min_idx > nr)) {
+          o.nxt = n; o.nxt_slot1 = es[i];
+          o.wn = WalkVertex{a[i].w, b[i].x, a[i].y, b[i].y, b[i].z, a[i].z, b[i].w};
+          if (holds) nxt_by_sample = true; else min_idx = nr;
+        }
+      }
+    }
+    return o;
+  }
+  for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+    WalkVertex nv;
+    const WalkEdge ed = walk_edge_full(im, e, nv);   // neighbour, its ref index, its class, and its own record
+    const uint32_t n = ed.nbr, nr = ed.ridx;
+    if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }
+    if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
+      const bool holds = sid != 0 && record_has_sample(im, n, nr, ed.cls, sid);
+      if (holds || (nr && min_idx > nr)) {
+        o.nxt = n; o.nxt_slot1 = im.e_slot[e]; o.wn = nv;
+        if (holds) nxt_by_sample = true; else min_idx = nr;
+      }
+    }
+  }
+  return o;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                     WalkScratch ws) {
@@ -1510,13 +1581,14 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
   if (x < 1) fl = kRegionInvalid;
   else {
-    bool empty = false;  // Index::is_empty, index.h:150-166
+    // Index::is_empty (index.h:150-166), find(pos, rank) and -- for the event-bitmap walk -- the stop slot, all from two
+    // ranks requested together
+    const RankLoads lx = rank1_issue(im, x), ly = rank1_issue(im, y ? y - 1 : 0);
+    const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
+    bool empty = false;
     if (x > im.ref_length) empty = true;
-    else {
-      const uint32_t rx = rank1(im, x);
-      if (rx >= im.R) empty = true;
-      else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
-    }
+    else if (rx >= im.R) empty = true;
+    else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
     if (empty) fl = kRegionEmpty;
     else {
       // Event bitmap of this sample (DevImage::t4_events): clear bits are ref-path slots where neither the node nor any
@@ -1525,19 +1597,21 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       // a set bit is the literal code.
       const uint64_t* __restrict__ ev = (im.t4_events && sid != 0) ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr;
       // ---- get_prev_vertex_with_sample ----
-      const uint64_t rank0 = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, x) - 1;  // find(pos, rank)
+      const uint64_t rank0 = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rx - 1;  // find(pos, rank)
       uint64_t rank = rank0;
       uint64_t ref_pos = 1;
       uint32_t start_v = 0;
       bool jump = ev != nullptr, jumped = false;
       while (true) {
-        const uint32_t pslot = im.rank_to_slot[rank == 0 ? 0 : rank - 1];  // Index::previous
+        // Index::previous(rank) is the first ref-path slot of rank - 1; rk_back holds it together with that node's
+        // out-degree (what the scan below counts the rank down by): one 8-byte record per iteration of the jumped form
+        const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
+        const uint32_t pslot = back.x;
         if (rank <= 1) { ref_pos = 1; start_v = im.rp_vid[pslot]; break; }
         if (jump && !((ev[pslot >> 6] >> (pslot & 63)) & 1)) {
           // no out-neighbour of this node holds the sample: the scan below would find nothing and count the rank
-          // down once per neighbour (#branches + the path successor, which every node but the last has)
-          const uint32_t deg = im.rp_cand_prefix[pslot + 1] - im.rp_cand_prefix[pslot] + (pslot + 1 < im.P ? 1u : 0u);
-          rank = rank > deg ? rank - deg : 0;
+          // down once per neighbour
+          rank = rank > back.y ? rank - back.y : 0;
           jumped = true;
           continue;
         }
@@ -1565,44 +1639,32 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
       const uint64_t cb = EMIT ? r.car_base[q] : 0;
       WalkVertex wc = walk_vertex(im, cur);   // afterwards the record of a vertex arrives with the edge the walk takes to it
+      uint32_t cur_slot1 = im.w_vertex[2 * (uint64_t)cur + 1].w;   // ref-path slot + 1 of cur; 0: not on the path
       // first slot whose node starts at or after y: a walk that reaches it in step with the reference stops there
-      uint32_t limit = 0;
-      if (ev && y >= 1) { const uint32_t ry = rank1(im, y - 1); limit = im.rank_to_slot[ry < im.R ? ry : im.R]; }
+      const uint32_t limit = (ev && y >= 1) ? im.rank_to_slot[ry < im.R ? ry : im.R] : 0;
       while (!done) {
         if (ref_pos >= y) break;
-        if (ev && wc.ridx && ref_pos == wc.ridx) {
+        if (ev && cur_slot1 && ref_pos == wc.ridx && cur_slot1 - 1 < limit) {
           // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
           // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
           // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
           // stop at `limit` if that comes first.  Arriving at k it holds {k's node, its index, cur_ref = k's node}.
-          const uint32_t slot1 = im.w_vertex[2 * (uint64_t)cur + 1].w;   // slot + 1; 0: not on the ref path
-          if (slot1 && slot1 - 1 < limit) {
-            const uint32_t k = next_event_slot(ev, slot1 - 1, limit);
-            if (k != slot1 - 1) {
-              if (k >= limit) break;
-              cur = im.rp_vid[k];
-              wc = walk_vertex(im, cur);
-              ref_pos = wc.ridx;
-              cur_ref_v = cur;
-            }
+          const uint32_t k = next_event_slot(ev, cur_slot1 - 1, limit);
+          if (k != cur_slot1 - 1) {
+            if (k >= limit) break;
+            const uint4 ra = im.rp_walk[2 * (uint64_t)k], rb = im.rp_walk[2 * (uint64_t)k + 1];   // vertex record of slot k's node
+            cur = rb.w;
+            wc = WalkVertex{ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
+            ref_pos = wc.ridx;
+            cur_ref_v = cur;
+            cur_slot1 = k + 1;
           }
         }
-        uint64_t next_ref_pos = ref_pos + wc.len;
-        uint32_t next_ref_v = kNone;   // the last ref neighbour: its sequence becomes cur_ref (read only when a substitution is emitted)
-        uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
-        WalkVertex wn{};               // vertex record of nxt
-        bool nxt_by_sample = false;
-        for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
-          WalkVertex nv;
-          const WalkEdge ed = walk_edge_full(im, e, nv);   // neighbour, its ref index, its class, and its own record
-          const uint32_t n = ed.nbr, nr = ed.ridx;
-          if (nr) { next_ref_pos = nr; next_ref_v = n; }  // last ref neighbour wins
-          if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
-            if (sid != 0 && record_has_sample(im, n, nr, ed.cls, sid)) { nxt = n; wn = nv; nxt_by_sample = true; }
-            else if (nr && min_idx > nr) { nxt = n; wn = nv; min_idx = nr; }
-          }
-        }
-        if (ref_pos >= x && record_has_sample(im, cur, wc.ridx, wc.cls, sid)) {
+        // does cur hold the sample?  (requested before the edges: it is independent of them)
+        const bool cur_holds = ref_pos >= x && record_has_sample(im, cur, wc.ridx, wc.cls, sid);
+        const StepOut st = walk_step_edges(im, wc, sid, ref_pos + wc.len);
+        const uint64_t next_ref_pos = st.next_ref_pos;
+        if (cur_holds) {
           uint64_t pos;
           uint32_t ro, rl, ao, al;
           bool ok = true;
@@ -1640,11 +1702,12 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
             nvar++; ncar += pad_car(c); ncar_kept += c;
           }
         }
-        cur_ref_v = next_ref_v;
+        cur_ref_v = st.next_ref_v;
         ref_pos = next_ref_pos;
-        if (nxt == 0) done = true;  // no neighbour: the path iterator is done
-        cur = nxt;
-        wc = wn;
+        if (st.nxt == 0) done = true;  // no neighbour: the path iterator is done
+        cur = st.nxt;
+        wc = st.wn;
+        cur_slot1 = st.nxt_slot1;
       }
     }
   }

@@ -85,6 +85,9 @@ struct HostImage {
   // what the type-4 event bitmaps rely on to find where a walk stops; false for an index that breaks it (never seen)
   bool slots_follow_ranks = false;
   std::vector<uint32_t> w_edge;     // 8 words per CSR entry
+  std::vector<uint32_t> e_slot;     // [E] ref-path slot + 1 of the neighbour (0: not on the path): arrives with the edge record
+  std::vector<uint32_t> rp_walk;    // 8 words per ref-path slot: w_vertex of the slot's node with word 7 = the vertex id
+  std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
   std::vector<uint32_t> car_index;   // sample-coordinate index per carrier record (query types 2/3/5); may be empty
@@ -332,11 +335,25 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   }
   for (uint64_t i = 0; i < im.P; ++i) im.w_vertex[(uint64_t)im.rp_vid[i] * 8 + 7] = (uint32_t)i + 1;   // ref-path slot + 1 (0: off the path)
   im.w_edge.assign(im.E * 8, 0);
+  im.e_slot.assign(im.E + 1, 0);
   for (uint64_t e = 0; e < im.E; ++e) {
     const uint32_t n = im.col[e];
     uint32_t* w = &im.w_edge[e * 8];
     w[0] = n; w[1] = im.v_ridx[n]; w[2] = im.v_class[n]; w[3] = im.row_ptr[n];
     w[4] = im.row_ptr[n + 1] - im.row_ptr[n]; w[5] = im.v_off[n]; w[6] = im.v_len[n]; w[7] = im.v_ncar[n];
+    im.e_slot[e] = im.w_vertex[(uint64_t)n * 8 + 7];
+  }
+  im.rp_walk.assign((im.P + 1) * 8, 0);
+  for (uint64_t i = 0; i < im.P; ++i) {
+    const uint32_t v = im.rp_vid[i];
+    std::copy(&im.w_vertex[(uint64_t)v * 8], &im.w_vertex[(uint64_t)v * 8 + 7], &im.rp_walk[i * 8]);
+    im.rp_walk[i * 8 + 7] = v;
+  }
+  im.rk_back.assign((im.R + 1) * 2, 0);
+  for (uint64_t r = 0; r < im.R; ++r) {
+    const uint32_t slot = im.rank_to_slot[r];
+    im.rk_back[2 * r] = slot;
+    if (slot < im.P) { const uint32_t v = im.rp_vid[slot]; im.rk_back[2 * r + 1] = im.row_ptr[v + 1] - im.row_ptr[v]; }
   }
 }
 
