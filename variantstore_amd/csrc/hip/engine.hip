@@ -59,6 +59,8 @@ struct EngineOpts {
   bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
   bool seq_two_walks = false;   // the same for types 2 / 3
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
+  bool t4_coop = true;          // type 4: 16 lanes per region, episodes in parallel (k_sample_walk_coop); false: one lane per region
+  bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
@@ -511,12 +513,31 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch.bufs));
     VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch.bufs));
     HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
+#ifdef VS_TUNING
+    if (idx->opts.walk_stats) {
+      VS_TRY(dev_alloc(idx, 128, (void**)&ws.stats, &scratch.bufs));
+      HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, idx->stream));
+    }
+#endif
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
+    else if (dwalk.t4_events && idx->opts.t4_coop)   // 16 lanes per region: the episodes of a region run in parallel
+      hipLaunchKernelGGL(k_sample_walk_coop, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
   }
   uint64_t walk_overflow = 0;
+#ifdef VS_TUNING
+  if (single_walk && ws.stats) {
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, ws.stats, 128, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    const double nr = h[0] ? (double)h[0] : 1.0;
+    fprintf(stderr, "walk stats: %llu regions | per region: search iterations %.1f (literal %.2f), jumps %.1f, steps %.1f, variants %.1f | "
+            "mean ticks(10ns): search %.0f walk %.0f head %.0f | max: search iters %llu steps %llu search ticks %llu walk ticks %llu\n",
+            h[0], h[1] / nr, h[2] / nr, h[3] / nr, h[4] / nr, h[7] / nr, h[5] / nr, h[6] / nr, h[12] / nr, h[8], h[9], h[10], h[11]);
+  }
+#endif
   if (single_walk) {
   } else if (n) {
     if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
@@ -563,7 +584,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   if (n) {
-    if (t4 && single_walk) hipLaunchKernelGGL(k_emit_from_walk, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
+    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
+    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
@@ -1205,14 +1227,17 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_two_walks") o.t4_two_walks = value != 0;
   else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
   else if (k == "t4_skip") o.t4_skip = value != 0;
+  else if (k == "t4_coop") o.t4_coop = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 16 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 16 or 64");
     o.fill_chunk = (uint32_t)value;
   }
-  else if (k == "fill_ablate" || k == "fill_lds_pad") {
+  else if (k == "fill_ablate" || k == "fill_lds_pad" || k == "walk_stats") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
-    if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u; else o.fill_lds_pad = (size_t)value;
+    if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;
+    else if (k == "walk_stats") o.walk_stats = value != 0;
+    else o.fill_lds_pad = (size_t)value;
 #else
     return fail(VS_ERR_UNSUPPORTED, "%s exists in tuning builds only (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force)", key);
 #endif

@@ -1451,19 +1451,6 @@ __global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* 
   }
 }
 
-// first slot >= m whose bit is set in the sample's row, or `limit` when there is none below it (m < limit <= P)
-__device__ __forceinline__ uint32_t next_event_slot(const uint64_t* __restrict__ row, uint32_t m, uint32_t limit) {
-  uint32_t w = m >> 6;
-  const uint32_t w_end = (limit + 63) >> 6;
-  uint64_t word = row[w] & (~0ULL << (m & 63));
-  while (!word) {
-    if (++w >= w_end) return limit;
-    word = row[w];
-  }
-  const uint32_t k = (w << 6) + (uint32_t)__builtin_ctzll(word);
-  return k < limit ? k : limit;
-}
-
 // Walk records (device_image.hpp): one step of a path walk reads the current vertex in one 32-byte record and each
 // neighbour in one 16-byte edge record instead of gathering a dozen 4-byte fields from as many arrays.
 struct WalkVertex { uint32_t row_begin, deg, ridx, off, len, cls, ncar; };
@@ -1501,7 +1488,37 @@ struct WalkScratch {
   uint64_t* pos;
   uint32_t *cur, *ro, *rl, *ao, *al;
   uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path)
+  unsigned long long* stats;   // tuning builds (VS_TUNING): 16 counters of k_sample_walk (iteration counts, device-clock ticks); else NULL
 };
+#ifdef VS_TUNING
+#define VS_WALK_STAT(i, v) do { if (ws.stats) atomicAdd(&ws.stats[i], (unsigned long long)(v)); } while (0)
+#define VS_WALK_STATMAX(i, v) do { if (ws.stats) atomicMax(&ws.stats[i], (unsigned long long)(v)); } while (0)
+#define VS_WALK_CLOCK() (ws.stats ? wall_clock64() : 0ULL)
+#else
+#define VS_WALK_STAT(i, v) do { } while (0)
+#define VS_WALK_STATMAX(i, v) do { } while (0)
+#define VS_WALK_CLOCK() 0ULL
+#endif
+
+// What get_sample_var_in_ref reports for a vertex on the sample's path (query.h:680-704), from the walk's state at that
+// vertex: kind 0 insertion (ref_pos == next_ref_pos), 1 deletion (the vertex is a ref vertex: ref = sequence of
+// find(ref_pos - 1)), 2 substitution (ref = sequence of the previous step's last ref neighbour).  Resolved where it is
+// cheap: by the wide k_emit_from_walk for the recording walk, in place for the two-walk fallback.
+struct WalkVariant { uint64_t pos; uint32_t ro, rl, ao, al; };
+__device__ __forceinline__ WalkVariant resolve_walk_variant(const DevImage& im, uint32_t kind, uint32_t cur, uint64_t ref_pos, uint32_t cur_ref_v) {
+  WalkVariant o{0, 0, 0, 0, 0};
+  if (kind == 1) {   // (the walk only records a deletion when ref_pos >= 2)
+    const uint64_t p = ref_pos - 1;
+    const uint64_t rf = (p >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, p) - 1;
+    const uint32_t fv = im.rp_vid[im.rank_to_slot[rf]];
+    o.pos = im.v_ridx[fv]; o.ro = im.v_off[fv]; o.rl = im.v_len[fv];
+  } else {
+    o.pos = kind == 0 ? ref_pos - 1 : ref_pos;
+    o.ao = im.v_off[cur]; o.al = im.v_len[cur];
+    if (kind == 2 && cur_ref_v != kNone) { o.ro = im.v_off[cur_ref_v]; o.rl = im.v_len[cur_ref_v]; }
+  }
+  return o;
+}
 
 // One literal step's view of a vertex's out-edges, read with memory-level parallelism: all edge records (and, for
 // ref neighbours, their ref-path slots) are requested together, then all class words; the reference's in-order
@@ -1538,11 +1555,11 @@ __device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, const Wal
       if (i < wc.deg && sid != 0) cw[i] = im.class_rows[(uint64_t)a[i].z * im.wpc + (sid >> 6)];
     }
 #pragma unroll
-    for (uint32_t i = 0; i < kStepEdges; ++i) {
-      if (i >= wc.deg) break;
+    for (uint32_t i = 0; i < kStepEdges; ++i) {   // (predicated, not `break`: the arrays must stay in registers)
+      const bool on = i < wc.deg;
       const uint32_t n = a[i].x, nr = a[i].y;
-      if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
-      if (!nxt_by_sample) {
+      if (on && nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
+      if (on && !nxt_by_sample) {
         const bool holds = sid != 0 && ((cw[i] >> (sid & 63)) & 1);
         if (holds || (nr && min_idx > nr)) {
           o.nxt = n; o.nxt_slot1 = es[i];
@@ -1569,155 +1586,446 @@ __device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, const Wal
   return o;
 }
 
+// The sample's event row read through a one-word cache: consecutive look-ups of a walk (and of the backward search)
+// fall into the same 64-slot word more often than not.
+struct EventRow {
+  const uint64_t* __restrict__ row;
+  uint32_t w;          // index of the cached word (kNone: nothing cached)
+  uint64_t word;
+  __device__ __forceinline__ uint64_t at(uint32_t wi) {
+    if (wi != w) { w = wi; word = row[wi]; }
+    return word;
+  }
+  __device__ __forceinline__ bool bit(uint32_t slot) { return (at(slot >> 6) >> (slot & 63)) & 1; }
+  // first slot >= m whose bit is set, or `limit` when there is none below it (m < limit <= P)
+  __device__ __forceinline__ uint32_t next(uint32_t m, uint32_t limit) {
+    uint32_t wi = m >> 6;
+    const uint32_t w_end = (limit + 63) >> 6;
+    uint64_t x = at(wi) & (~0ULL << (m & 63));
+    while (!x) {
+      if (++wi >= w_end) return limit;
+      x = at(wi);
+    }
+    const uint32_t k = (wi << 6) + (uint32_t)__builtin_ctzll(x);
+    return k < limit ? k : limit;
+  }
+};
+
+// ---- the walk of get_sample_var_in_ref as reusable pieces (serial kernel k_sample_walk, cooperative k_sample_walk_coop) ----
+struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; };
+struct WalkSt { uint32_t cur; WalkVertex wc; uint64_t ref_pos; uint32_t cur_ref_v, cur_slot1; };   // cur_slot1: ref-path slot + 1 of cur, 0 = off the path
+struct WalkEmit { uint64_t ref_pos; uint32_t cur, kind, cur_ref_v, c; };   // the walk's state at a reported vertex (-> resolve_walk_variant)
+
+// One iteration of the reference's loop body (query.h:640-720) at st.cur: is the vertex reported, then the step to the
+// next vertex of the sample's path.  `done`: the path iterator has no next vertex.
+__device__ __forceinline__ bool walk_literal_step(const DevImage& im, const WalkCtx& cx, WalkSt& st, WalkEmit& em, bool& done) {
+  // does cur hold the sample?  (requested before the edges: it is independent of them)
+  const bool cur_holds = st.ref_pos >= cx.x && record_has_sample(im, st.cur, st.wc.ridx, st.wc.cls, cx.sid);
+  const StepOut so = walk_step_edges(im, st.wc, cx.sid, st.ref_pos + st.wc.len);
+  bool emit = false;
+  if (cur_holds) {
+    const uint32_t kind = st.ref_pos == so.next_ref_pos ? 0u : (st.wc.ridx ? 1u : 2u);
+    if (!(kind == 1 && st.ref_pos < 2)) {   // a deletion at ref_pos 1 has no find(ref_pos - 1): skipped
+      em = WalkEmit{st.ref_pos, st.cur, kind, st.cur_ref_v, st.wc.ncar};
+      emit = true;
+    }
+  }
+  st.cur_ref_v = so.next_ref_v;
+  st.ref_pos = so.next_ref_pos;
+  done = so.nxt == 0;  // no neighbour: the path iterator is done
+  st.cur = so.nxt; st.wc = so.wn; st.cur_slot1 = so.nxt_slot1;
+  return emit;
+}
+// on a ref-path node, in step with it (ref_pos == its index), before the stop slot: where a jump may start / an episode ends
+__device__ __forceinline__ bool walk_in_step(const WalkCtx& cx, const WalkSt& st) {
+  return cx.use_ev && st.cur_slot1 && st.ref_pos == st.wc.ridx && st.cur_slot1 - 1 < cx.limit;
+}
+// arrival at event slot k "in step": {k's node, its index}; cur_ref is not read before the step overwrites it (it only
+// enters a substitution, and a ref-path node is never reported as one)
+__device__ __forceinline__ void walk_arrive_at_slot(const DevImage& im, WalkSt& st, uint32_t k) {
+  const uint4 ra = im.rp_walk[2 * (uint64_t)k], rb = im.rp_walk[2 * (uint64_t)k + 1];   // vertex record of slot k's node
+  st.cur = rb.w;
+  st.wc = WalkVertex{ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
+  st.ref_pos = st.wc.ridx;
+  st.cur_ref_v = st.cur;
+  st.cur_slot1 = k + 1;
+}
+
+// get_prev_vertex_with_sample (query.h:57-113) from find(x)'s rank: the start state of the walk
+__device__ __forceinline__ void walk_start_search(const DevImage& im, const WalkCtx& cx, EventRow& ev, uint64_t rank0, WalkSt& st,
+                                                  uint32_t& st_iters, uint32_t& st_lit) {
+  const uint32_t sid = cx.sid;
+  uint64_t rank = rank0;
+  uint64_t ref_pos = 1;
+  uint32_t start_v = 0, start_slot1 = 0;
+  WalkVertex wc{};
+  bool have_start_rec = false;   // the search found start_v through an edge record that carries its vertex record
+  bool jump = cx.use_ev, jumped = false;
+  while (true) {
+    ++st_iters;
+    // Index::previous(rank) is the first ref-path slot of rank - 1; rk_back holds it together with that node's
+    // out-degree (what the scan below counts the rank down by): one 8-byte record per iteration of the jumped form
+    const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
+    const uint32_t pslot = back.x;
+    if (rank <= 1) { ref_pos = 1; start_v = im.rp_vid[pslot]; have_start_rec = false; break; }
+    if (jump && !ev.bit(pslot)) {
+      // no out-neighbour of this node holds the sample: the scan below would find nothing and count the rank
+      // down once per neighbour
+      rank = rank > back.y ? rank - back.y : 0;
+      jumped = true;
+      continue;
+    }
+    ++st_lit;
+    bool found = false, had_ref = false;
+    const uint4 pa = im.rp_walk[2 * (uint64_t)pslot];   // {row_begin, degree, ..} of the slot's node
+    const uint32_t rb0 = pa.x, deg = pa.y;
+    if (deg <= kStepEdges && im.use_bv && sid != 0) {
+      uint4 a[kStepEdges], b[kStepEdges];
+      uint32_t es[kStepEdges];
+      uint64_t cw[kStepEdges];
+#pragma unroll
+      for (uint32_t i = 0; i < kStepEdges; ++i) {
+        a[i] = uint4{0, 0, 0, 0}; b[i] = uint4{0, 0, 0, 0}; es[i] = 0;
+        if (i < deg) { a[i] = im.w_edge[2 * (uint64_t)(rb0 + i)]; b[i] = im.w_edge[2 * (uint64_t)(rb0 + i) + 1]; es[i] = im.e_slot[rb0 + i]; }
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < kStepEdges; ++i) cw[i] = i < deg ? im.class_rows[(uint64_t)a[i].z * im.wpc + (sid >> 6)] : 0;
+#pragma unroll
+      for (uint32_t i = 0; i < kStepEdges; ++i) {
+        if (i < deg && a[i].y) { ref_pos = a[i].y; had_ref = true; }
+        if (i < deg && ((cw[i] >> (sid & 63)) & 1)) {
+          start_v = a[i].x; found = true; have_start_rec = true; start_slot1 = es[i];
+          wc = WalkVertex{a[i].w, b[i].x, a[i].y, b[i].y, b[i].z, a[i].z, b[i].w};
+        }
+      }
+      rank = rank > deg ? rank - deg : 0;   // one count per neighbour (the reference's unsigned counter would wrap: clamped)
+    } else {
+      for (uint32_t e = rb0; e < rb0 + deg; ++e) {
+        const WalkEdge ed = walk_edge(im, e);
+        if (ed.ridx) { ref_pos = ed.ridx; had_ref = true; }
+        if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; have_start_rec = false; }
+        rank = rank ? rank - 1 : 0;
+      }
+    }
+    if (found) {
+      // ref_pos is the last ref neighbour seen in ANY iteration so far: when this node has none of its own and
+      // iterations were jumped over, the value is not known -- search again, literally (a node without a ref
+      // neighbour is the end of the path: practically never)
+      if (!had_ref && jumped) { jump = false; jumped = false; rank = rank0; ref_pos = 1; start_v = 0; continue; }
+      break;
+    }
+  }
+  st.cur = start_v;
+  st.ref_pos = ref_pos;
+  st.cur_ref_v = kNone;  // cur_ref: the last ref neighbour of the previous vertex (its sequence; none = empty string)
+  if (have_start_rec) { st.wc = wc; st.cur_slot1 = start_slot1; }
+  else {                 // afterwards the record of a vertex arrives with the edge the walk takes to it
+    st.wc = walk_vertex(im, start_v);
+    st.cur_slot1 = im.w_vertex[2 * (uint64_t)start_v + 1].w;
+  }
+}
+
+// Index::is_empty (index.h:150-166), find(pos, rank) and -- for the event-bitmap walk -- the stop slot, all from two ranks
+// requested together.  Returns the region flag (0: walk), fills rank0 and cx.limit.
+__device__ __forceinline__ uint8_t walk_prologue(const DevImage& im, WalkCtx& cx, uint64_t& rank0) {
+  if (cx.x < 1) return kRegionInvalid;
+  const RankLoads lx = rank1_issue(im, cx.x), ly = rank1_issue(im, cx.y ? cx.y - 1 : 0);
+  const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
+  bool empty = false;
+  if (cx.x > im.ref_length) empty = true;
+  else if (rx >= im.R) empty = true;
+  else if (!((uint64_t)im.idx_pos[rx] - 1 <= cx.y)) empty = true;
+  if (empty) return kRegionEmpty;
+  rank0 = (cx.x >= im.ref_length) ? im.R - 1 : (uint64_t)rx - 1;  // find(pos, rank)
+  // first slot whose node starts at or after y: a walk that reaches it in step with the reference stops there
+  cx.limit = (cx.use_ev && cx.y >= 1) ? im.rank_to_slot[ry < im.R ? ry : im.R] : 0;
+  return 0;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                     WalkScratch ws) {
   constexpr bool EMIT = MODE == 1;
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
-  const uint32_t sid = sid_per_region ? sid_per_region[q] : sid_all;
-  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
-  uint8_t fl = 0;
-  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
-  if (x < 1) fl = kRegionInvalid;
-  else {
-    // Index::is_empty (index.h:150-166), find(pos, rank) and -- for the event-bitmap walk -- the stop slot, all from two
-    // ranks requested together
-    const RankLoads lx = rank1_issue(im, x), ly = rank1_issue(im, y ? y - 1 : 0);
-    const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
-    bool empty = false;
-    if (x > im.ref_length) empty = true;
-    else if (rx >= im.R) empty = true;
-    else if (!((uint64_t)im.idx_pos[rx] - 1 <= y)) empty = true;
-    if (empty) fl = kRegionEmpty;
-    else {
-      // Event bitmap of this sample (DevImage::t4_events): clear bits are ref-path slots where neither the node nor any
-      // of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do nothing
-      // there but step on, so both the backward search and the walk below jump over them.  Everything that happens at
-      // a set bit is the literal code.
-      const uint64_t* __restrict__ ev = (im.t4_events && sid != 0) ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr;
-      // ---- get_prev_vertex_with_sample ----
-      const uint64_t rank0 = (x >= im.ref_length) ? im.R - 1 : (uint64_t)rx - 1;  // find(pos, rank)
-      uint64_t rank = rank0;
-      uint64_t ref_pos = 1;
-      uint32_t start_v = 0;
-      bool jump = ev != nullptr, jumped = false;
-      while (true) {
-        // Index::previous(rank) is the first ref-path slot of rank - 1; rk_back holds it together with that node's
-        // out-degree (what the scan below counts the rank down by): one 8-byte record per iteration of the jumped form
-        const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
-        const uint32_t pslot = back.x;
-        if (rank <= 1) { ref_pos = 1; start_v = im.rp_vid[pslot]; break; }
-        if (jump && !((ev[pslot >> 6] >> (pslot & 63)) & 1)) {
-          // no out-neighbour of this node holds the sample: the scan below would find nothing and count the rank
-          // down once per neighbour
-          rank = rank > back.y ? rank - back.y : 0;
-          jumped = true;
-          continue;
-        }
-        const uint32_t v = im.rp_vid[pslot];
-        bool found = false, had_ref = false;
-        const WalkVertex wv = walk_vertex(im, v);
-        for (uint32_t e = wv.row_begin; e < wv.row_begin + wv.deg; ++e) {
-          const WalkEdge ed = walk_edge(im, e);
-          if (ed.ridx) { ref_pos = ed.ridx; had_ref = true; }
-          if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; }
-          rank = rank ? rank - 1 : 0;  // the reference's unsigned counter would wrap here: clamped
-        }
-        if (found) {
-          // ref_pos is the last ref neighbour seen in ANY iteration so far: when this node has none of its own and
-          // iterations were jumped over, the value is not known -- search again, literally (a node without a ref
-          // neighbour is the end of the path: practically never)
-          if (!had_ref && jumped) { jump = false; jumped = false; rank = rank0; ref_pos = 1; start_v = 0; continue; }
-          break;
+  WalkCtx cx{sid_per_region ? sid_per_region[q] : sid_all, r.regions[2 * q], r.regions[2 * q + 1], false, 0};
+  // Event bitmap of this sample (DevImage::t4_events): clear bits are ref-path slots where neither the node nor any
+  // of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do nothing
+  // there but step on, so both the backward search and the walk below jump over them.  Everything that happens at
+  // a set bit is the literal code.
+  cx.use_ev = im.t4_events && cx.sid != 0;
+  uint64_t nvar = 0, ncar = 0, ncar_kept = 0, rank0 = 0;
+  const uint8_t fl = walk_prologue(im, cx, rank0);
+  if (!fl) {
+    EventRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};
+    const uint64_t t_s0 = VS_WALK_CLOCK();
+    uint32_t st_iters = 0, st_lit = 0, st_jumps = 0, st_steps = 0;
+    WalkSt st;
+    walk_start_search(im, cx, ev, rank0, st, st_iters, st_lit);
+    const uint64_t t_s1 = VS_WALK_CLOCK();
+    // ---- walk the sample's path ----
+    bool done = false;
+    const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
+    const uint64_t cb = EMIT ? r.car_base[q] : 0;
+    const uint64_t s0 = MODE == 2 ? ws.cap_begin[q] : 0, scap = MODE == 2 ? ws.cap_begin[q + 1] - s0 : 0;
+    while (!done) {
+      if (st.ref_pos >= cx.y) break;
+      if (walk_in_step(cx, st)) {
+        // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
+        // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
+        // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
+        // stop at `limit` if that comes first.
+        const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
+        if (k != st.cur_slot1 - 1) {
+          if (k >= cx.limit) break;
+          walk_arrive_at_slot(im, st, k);
+          ++st_jumps;
         }
       }
-      // ---- walk the sample's path ----
-      uint32_t cur = start_v;
-      uint32_t cur_ref_v = kNone;  // cur_ref: the last ref neighbour of the previous vertex (its sequence; none = empty string)
-      bool done = false;
-      const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
-      const uint64_t cb = EMIT ? r.car_base[q] : 0;
-      WalkVertex wc = walk_vertex(im, cur);   // afterwards the record of a vertex arrives with the edge the walk takes to it
-      uint32_t cur_slot1 = im.w_vertex[2 * (uint64_t)cur + 1].w;   // ref-path slot + 1 of cur; 0: not on the path
-      // first slot whose node starts at or after y: a walk that reaches it in step with the reference stops there
-      const uint32_t limit = (ev && y >= 1) ? im.rank_to_slot[ry < im.R ? ry : im.R] : 0;
-      while (!done) {
-        if (ref_pos >= y) break;
-        if (ev && cur_slot1 && ref_pos == wc.ridx && cur_slot1 - 1 < limit) {
-          // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
-          // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
-          // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
-          // stop at `limit` if that comes first.  Arriving at k it holds {k's node, its index, cur_ref = k's node}.
-          const uint32_t k = next_event_slot(ev, cur_slot1 - 1, limit);
-          if (k != cur_slot1 - 1) {
-            if (k >= limit) break;
-            const uint4 ra = im.rp_walk[2 * (uint64_t)k], rb = im.rp_walk[2 * (uint64_t)k + 1];   // vertex record of slot k's node
-            cur = rb.w;
-            wc = WalkVertex{ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
-            ref_pos = wc.ridx;
-            cur_ref_v = cur;
-            cur_slot1 = k + 1;
-          }
+      ++st_steps;
+      WalkEmit em;
+      if (walk_literal_step(im, cx, st, em, done)) {
+        if (EMIT) {
+          const WalkVariant wv = resolve_walk_variant(im, em.kind, em.cur, em.ref_pos, em.cur_ref_v);
+          const uint64_t a = a0 + nvar;
+          r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
+          r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = em.c;
+          r.r_region[a] = (uint32_t)q;
+          r.r_class[a] = im.v_src[em.cur]; r.r_gt0[a] = im.v_car_begin[em.cur];
         }
-        // does cur hold the sample?  (requested before the edges: it is independent of them)
-        const bool cur_holds = ref_pos >= x && record_has_sample(im, cur, wc.ridx, wc.cls, sid);
-        const StepOut st = walk_step_edges(im, wc, sid, ref_pos + wc.len);
-        const uint64_t next_ref_pos = st.next_ref_pos;
-        if (cur_holds) {
-          uint64_t pos;
-          uint32_t ro, rl, ao, al;
-          bool ok = true;
-          if (ref_pos == next_ref_pos) {  // insertion
-            pos = ref_pos - 1; ro = 0; rl = 0; ao = wc.off; al = wc.len;
-          } else if (wc.ridx) {   // deletion: ref = sequence of find(ref_pos - 1)
-            const uint64_t p = ref_pos - 1;
-            uint32_t fv;
-            if (p < 1) { ok = false; fv = 0; }
-            else {
-              const uint64_t rf = (p >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, p) - 1;
-              fv = im.rp_vid[im.rank_to_slot[rf]];
-            }
-            pos = im.v_ridx[fv]; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
-          } else {                        // substitution: ref = sequence of the previous step's last ref neighbour
-            pos = ref_pos; ro = 0; rl = 0; ao = wc.off; al = wc.len;
-            if (cur_ref_v != kNone) { const WalkVertex wr = walk_vertex(im, cur_ref_v); ro = wr.off; rl = wr.len; }
-          }
-          if (ok) {
-            const uint32_t c = wc.ncar;
-            if (EMIT) {
-              const uint64_t a = a0 + nvar;
-              r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
-              r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
-              r.r_region[a] = (uint32_t)q;
-              r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
-            }
-            if (MODE == 2) {
-              const uint64_t s0 = ws.cap_begin[q];
-              if (nvar < ws.cap_begin[q + 1] - s0) {
-                const uint64_t s = s0 + nvar;
-                ws.pos[s] = pos; ws.cur[s] = cur; ws.ro[s] = ro; ws.rl[s] = rl; ws.ao[s] = ao; ws.al[s] = al;
-              } else *ws.overflow = 1;
-            }
-            nvar++; ncar += pad_car(c); ncar_kept += c;
-          }
+        if (MODE == 2) {   // the walk's state at the vertex; k_emit_from_walk turns it into the row
+          if (nvar < scap) {
+            const uint64_t s = s0 + nvar;
+            ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v;
+          } else *ws.overflow = 1;
         }
-        cur_ref_v = st.next_ref_v;
-        ref_pos = next_ref_pos;
-        if (st.nxt == 0) done = true;  // no neighbour: the path iterator is done
-        cur = st.nxt;
-        wc = st.wn;
-        cur_slot1 = st.nxt_slot1;
+        nvar++; ncar += pad_car(em.c); ncar_kept += em.c;
       }
     }
+    const uint64_t t_s2 = VS_WALK_CLOCK();
+    VS_WALK_STAT(0, 1); VS_WALK_STAT(1, st_iters); VS_WALK_STAT(2, st_lit); VS_WALK_STAT(3, st_jumps); VS_WALK_STAT(4, st_steps);
+    VS_WALK_STAT(5, t_s1 - t_s0); VS_WALK_STAT(6, t_s2 - t_s1); VS_WALK_STAT(7, nvar);
+    VS_WALK_STATMAX(8, st_iters); VS_WALK_STATMAX(9, st_steps); VS_WALK_STATMAX(10, t_s1 - t_s0); VS_WALK_STATMAX(11, t_s2 - t_s1);
+    (void)st_lit; (void)st_jumps; (void)st_steps; (void)st_iters; (void)t_s0; (void)t_s1; (void)t_s2;
   }
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
   else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
 }
 
+// ---------------------------------------------------------------------------
+// Cooperative form of the recording walk: 16 lanes per region.
+//
+// Between two events a walk is in step with the ref path, and what it does from an event slot on depends only on
+// {slot's node, its index} (walk_arrive_at_slot) -- so the EPISODES of a region (event slot -> literal steps until the
+// walk is in step again, or ends) are independent of each other and run in parallel, one per lane, speculatively from
+// every event slot of the region's range.  The group then follows the chain of hand-overs in registers: the head
+// episode (from the backward search's start state) ends in step at some slot; the first event at or after it is the
+// next episode that really happens; it ends in step at its own slot; and so on until an episode ends the walk or no
+// event is left below the stop slot.  Episodes the chain skips (events on ref nodes the sample's path bypasses) are
+// discarded.  The accepted episodes' reports are compacted into the region's scratch list in order.
+// The prologue, the backward search and the head run redundantly in all 16 lanes (same addresses: one request), so
+// a wave diverges four ways instead of sixty-four; an episode that outgrows its registers (more than kEpEmits reports
+// or kEpSteps steps -- not seen) sends its region through the serial loop, again redundantly in the 16 lanes.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEpEmits = 4, kEpSteps = 12;
+
+__device__ __forceinline__ uint32_t group_inclusive_scan16(uint32_t v) {   // prefix sum inside each row of 16 lanes (DPP)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  return v;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t select_bit(uint64_t word, uint32_t rank) {   // position of the rank-th (0-based) set bit
+  for (uint32_t i = 0; i < rank; ++i) word &= word - 1;
+  return (uint32_t)__builtin_ctzll(word);
+}
+
+__global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
+                                                          WalkScratch ws) {
+  const uint32_t lane = threadIdx.x & 63, l = lane & 15, gbase = lane & 48;
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = q < r.Q;
+  WalkCtx cx{0, 0, 0, false, 0};
+  if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
+  cx.use_ev = live && im.t4_events && cx.sid != 0;
+  // group-uniform state: every lane of a group computes / receives the same values
+  uint64_t nvar = 0, ncar = 0, rank0 = 0;
+  uint8_t fl = 0;
+  bool busy = false;         // the group still has episodes to run
+  bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
+  uint32_t cur_slot = 0;     // slot at which the chain is in step
+  uint64_t s0 = 0, scap = 0;
+  EventRow ev{nullptr, kNone, 0};
+  WalkSt st{};
+  const uint64_t t_c0 = VS_WALK_CLOCK();
+  uint64_t t_c1 = t_c0, t_c2 = t_c0;
+  uint32_t n_chunks = 0, n_search = 0;
+  if (live) {
+    fl = walk_prologue(im, cx, rank0);
+    s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
+    if (!fl) {
+      ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
+      uint32_t it = 0, lit = 0;
+      walk_start_search(im, cx, ev, rank0, st, it, lit);
+      n_search = it;
+      t_c1 = VS_WALK_CLOCK();
+      if (!cx.use_ev) serial = true;
+      else {
+        // ---- head: literal steps from the start state until the walk is in step (redundant in the group) ----
+        bool done = false, term = false;
+        uint32_t steps = 0;
+        while (true) {
+          if (done || st.ref_pos >= cx.y) { term = true; break; }
+          if (walk_in_step(cx, st)) { cur_slot = st.cur_slot1 - 1; break; }
+          if (++steps > 64) { serial = true; break; }   // (a start state that never falls in step: walk it serially)
+          WalkEmit em;
+          if (walk_literal_step(im, cx, st, em, done)) {
+            if (nvar < scap) {
+              if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v; }
+            } else if (l == 0) *ws.overflow = 1;
+            nvar++; ncar += pad_car(em.c);
+          }
+        }
+        busy = !term && !serial;
+      }
+      t_c2 = VS_WALK_CLOCK();
+    }
+  }
+  // ---- episodes, 16 events of a group at a time ----
+  while (__any(busy)) {
+    if (busy) ++n_chunks;
+    // the next 16 events at or after cur_slot, one per lane: lane l loads word l of the row from cur_slot's word on
+    const uint32_t w0 = cur_slot >> 6, w_end = (cx.limit + 63) >> 6, wi = w0 + l;
+    uint64_t word = (busy && wi < w_end) ? ev.row[wi] : 0;
+    if (l == 0) word &= ~0ULL << (cur_slot & 63);
+    if (busy && wi == (cx.limit >> 6) && (cx.limit & 63)) word &= (1ULL << (cx.limit & 63)) - 1;
+    const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan16(pc);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)gbase + 15, 64);
+    uint32_t j = 0;                                   // the word holding this lane's event: #words whose inclusive count is <= l
+#pragma unroll
+    for (int t = 0; t < 16; ++t) j += (uint32_t)__shfl((int)incl, (int)gbase + t, 64) <= l ? 1u : 0u;
+    const bool have = busy && l < total;
+    const int src = (int)gbase + (int)(j < 16 ? j : 15);
+    const uint64_t wj = shfl64(word, src);
+    const uint32_t excl_j = (uint32_t)__shfl((int)(incl - pc), src, 64);
+    const bool more = total > 16 || w0 + 16 < w_end;  // events beyond this chunk may exist
+    uint32_t slot = 0;
+    if (have) slot = ((w0 + j) << 6) + select_bit(wj, l - excl_j);
+    // ---- this lane's episode ----
+    WalkEmit em[kEpEmits];
+    uint32_t n_em = 0, ep_pad = 0, ep_end = 0;
+    bool ep_term = false, ep_ovf = false;
+    if (have) {
+      WalkSt es;
+      walk_arrive_at_slot(im, es, slot);
+      bool done = false;
+      uint32_t steps = 0;
+      while (true) {
+        WalkEmit e1;
+        if (walk_literal_step(im, cx, es, e1, done)) {
+          if (n_em < kEpEmits) {
+#pragma unroll
+            for (uint32_t t = 0; t < kEpEmits; ++t) if (t == n_em) em[t] = e1;
+          } else ep_ovf = true;
+          ++n_em; ep_pad += pad_car(e1.c);
+        }
+        if (done || es.ref_pos >= cx.y) { ep_term = true; break; }
+        if (walk_in_step(cx, es)) { ep_end = es.cur_slot1 - 1; break; }
+        if (++steps >= kEpSteps) { ep_ovf = true; break; }
+      }
+      if (!ep_term && !ep_ovf && ep_end <= slot) ep_ovf = true;   // (a walk that does not advance: serial loop)
+    }
+    // ---- the chain of hand-overs (registers only) ----
+    bool accepted = false, gdone = !busy, finished = false, fallback = false;
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) {
+      const bool cand = !gdone && have && slot >= cur_slot;
+      const uint32_t gb = (uint32_t)((__ballot(cand) >> gbase) & 0xFFFFu);
+      const int i = gb ? (int)gbase + __builtin_ctz(gb) : (int)gbase;
+      const bool t_i = __shfl((int)ep_term, i, 64), o_i = __shfl((int)ep_ovf, i, 64);
+      const uint32_t end_i = (uint32_t)__shfl((int)ep_end, i, 64);
+      if (!gdone) {
+        if (!gb) gdone = true;                       // no event left in this chunk
+        else {
+          if ((int)lane == i) accepted = true;
+          if (o_i) { fallback = true; gdone = true; }
+          else if (t_i) { finished = true; gdone = true; }
+          else cur_slot = end_i;
+        }
+      }
+      if (!__any(!gdone)) break;
+    }
+    if (busy && !fallback && !finished && !more) finished = true;   // nothing below the stop slot any more: the walk runs into it
+    // events may remain beyond this chunk: the chain is in step at least up to where the chunk's enumeration ended
+    const uint32_t last_slot = (uint32_t)__shfl((int)slot, (int)gbase + 15, 64);
+    const uint32_t chunk_next = total > 16 ? last_slot + 1 : (w0 + 16) << 6;
+    if (busy && !fallback && !finished && chunk_next > cur_slot) cur_slot = chunk_next;
+    // ---- the accepted episodes' reports, compacted in order ----
+    const uint32_t mine = (accepted && !fallback) ? n_em : 0u;
+    const uint32_t inc_e = group_inclusive_scan16(mine), tot_e = (uint32_t)__shfl((int)inc_e, (int)gbase + 15, 64);
+    const uint32_t inc_p = group_inclusive_scan16((accepted && !fallback) ? ep_pad : 0u), tot_p = (uint32_t)__shfl((int)inc_p, (int)gbase + 15, 64);
+    if (mine) {
+      const uint64_t at = nvar + (inc_e - mine);
+#pragma unroll
+      for (uint32_t t = 0; t < kEpEmits; ++t)
+        if (t < mine) {
+          if (at + t < scap) { const uint64_t s = s0 + at + t; ws.pos[s] = em[t].ref_pos; ws.cur[s] = em[t].cur; ws.ro[s] = em[t].kind; ws.rl[s] = em[t].cur_ref_v; }
+          else *ws.overflow = 1;
+        }
+    }
+    if (busy) { nvar += tot_e; ncar += tot_p; }
+    if (fallback) serial = true;
+    if (busy && (finished || fallback)) busy = false;
+  }
+  // ---- regions without event rows, and fallbacks: the serial loop (redundant in the group; lane 0 writes) ----
+  if (__any(serial)) {
+    if (serial) {
+      uint32_t it = 0, lit = 0;
+      nvar = 0; ncar = 0;
+      ev.w = kNone;
+      walk_start_search(im, cx, ev, rank0, st, it, lit);
+      bool done = false;
+      while (!done) {
+        if (st.ref_pos >= cx.y) break;
+        if (walk_in_step(cx, st)) {
+          const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
+          if (k != st.cur_slot1 - 1) {
+            if (k >= cx.limit) break;
+            walk_arrive_at_slot(im, st, k);
+          }
+        }
+        WalkEmit e1;
+        if (walk_literal_step(im, cx, st, e1, done)) {
+          if (nvar < scap) {
+            if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
+          } else if (l == 0) *ws.overflow = 1;
+          nvar++; ncar += pad_car(e1.c);
+        }
+      }
+    }
+  }
+  if (live && l == 0) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
+  if (live && l == 0 && !fl) {
+    const uint64_t t_c3 = VS_WALK_CLOCK();
+    VS_WALK_STAT(0, 1); VS_WALK_STAT(1, n_search); VS_WALK_STAT(3, n_chunks); VS_WALK_STAT(7, nvar);
+    VS_WALK_STAT(5, t_c1 - t_c0); VS_WALK_STAT(6, t_c3 - t_c2); VS_WALK_STAT(12, t_c2 - t_c1);
+    VS_WALK_STATMAX(10, t_c1 - t_c0); VS_WALK_STATMAX(11, t_c3 - t_c2); VS_WALK_STATMAX(8, n_search); VS_WALK_STATMAX(9, n_chunks);
+    (void)t_c3;
+  }
+  (void)t_c1; (void)t_c2; (void)n_chunks; (void)n_search;
+}
+
 // Headers of a type-4 batch from the scratch list of the single walk (one thread per region; ~10 variants each)
 // 16 lanes per region (a sample has ~10 variants in a 10 kb region): coalesced reads of the walk's record and coalesced
 // header writes; the arena offsets are a prefix sum inside each 16-lane row (four DPP steps).
+// RESOLVE: the scratch holds the type-4 walk's state per reported vertex {ref_pos, vertex, kind, cur_ref} and the row is
+// worked out here (resolve_walk_variant); otherwise (type 5) it holds finished rows.
+template <bool RESOLVE>
 __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t l16 = threadIdx.x & 15u, row_last = (threadIdx.x & 63u) | 15u;
@@ -1744,7 +2052,10 @@ __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r
     csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x114, 0xF, 0xF, true);
     csum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)csum, 0x118, 0xF, 0xF, true);
     if (on) {
-      r.r_pos[a] = ws.pos[s]; r.r_ref_off[a] = ws.ro[s]; r.r_ref_len[a] = ws.rl[s]; r.r_alt_off[a] = ws.ao[s]; r.r_alt_len[a] = ws.al[s];
+      WalkVariant wv;
+      if (RESOLVE) wv = resolve_walk_variant(im, ws.ro[s], cur, ws.pos[s], ws.rl[s]);
+      else wv = WalkVariant{ws.pos[s], ws.ro[s], ws.rl[s], ws.ao[s], ws.al[s]};
+      r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
       r.r_flags[a] = 0; r.r_car_begin[a] = cb + (incl - pad_car(c)); r.r_car_count[a] = c;
       r.r_region[a] = (uint32_t)q;
       r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
