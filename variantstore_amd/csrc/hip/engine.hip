@@ -288,11 +288,12 @@ static int build_device_image(vs_index* idx) {
     VS_TRY(upload_image(idx, im.w_edge, &we));
     d.w_vertex = reinterpret_cast<const uint4*>(wv);
     d.w_edge = reinterpret_cast<const uint4*>(we);
-    const uint32_t *rw = nullptr, *rb = nullptr;
-    VS_TRY(upload_image(idx, im.e_slot, &d.e_slot));
-    VS_TRY(upload_image(idx, im.rp_walk, &rw));
+    const uint32_t *wb = nullptr, *rb = nullptr;
+    VS_TRY(upload_image(idx, im.wblob, &wb));
+    VS_TRY(upload_image(idx, im.blob_of_slot, &d.blob_of_slot));
+    VS_TRY(upload_image(idx, im.blob_row, &d.blob_row));
     VS_TRY(upload_image(idx, im.rk_back, &rb));
-    d.rp_walk = reinterpret_cast<const uint4*>(rw);
+    d.wblob = reinterpret_cast<const uint4*>(wb);
     d.rk_back = reinterpret_cast<const uint2*>(rb);
   }
   VS_TRY(upload_image(idx, im.v_ncar, &d.v_ncar));
@@ -379,25 +380,30 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
   //      what this part has plenty of).  Skipped when they would take more than a third of the free memory or 64 GB. ----
-  d.t4_events = nullptr; d.t4_stride = 0;
+  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0;
   if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
-    const uint64_t stride = (im.P + 63) / 64 + 1;
-    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8;
+    const uint64_t stride = (im.P + 63) / 64 + 1, hstride = (im.V + 63) / 64 + 1;
+    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (bytes <= (64ull << 30) && bytes <= free_b / 3) {
-      uint64_t* events = nullptr;
+    if (bytes + hbytes <= (96ull << 30) && bytes + hbytes <= free_b / 3) {
+      uint64_t *events = nullptr, *hold = nullptr;
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
+      VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
       HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
-      d.t4_stride = stride;
-      const unsigned tiles = (unsigned)((im.P + 63) / 64);
-      if (d.use_bv) hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
-      else {
+      HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
+      d.t4_stride = stride; d.t4_hold_stride = hstride;
+      const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
+      if (d.use_bv) {
+        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
+        hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, d, hold);
+      } else {
         hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
         hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
+        hipLaunchKernelGGL(k_hold_explicit, dim3((unsigned)((im.V + 255) / 256)), dim3(256), 0, idx->stream, d, hold);
       }
       HIP_TRY(hipGetLastError());
-      d.t4_events = events;
+      d.t4_events = events; d.t4_hold = hold;
     }
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));

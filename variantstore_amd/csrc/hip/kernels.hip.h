@@ -89,9 +89,20 @@ struct DevImage {
   // the rank structure one to one) -- the walk then visits every vertex.
   const uint64_t* t4_events;
   uint64_t t4_stride;       // 64-bit words per sample row: ceil(P / 64) + 1
-  // walk tables beside the records above (device_image.hpp)
-  const uint32_t* e_slot;   // [E] ref-path slot + 1 of each CSR entry's neighbour (0: not on the path)
-  const uint4* rp_walk;     // [P] 2 x uint4 per ref-path slot: the vertex record of its node, word 7 = the vertex id
+  // Per-sample HOLD rows over the vertex ids (k_build_hold): bit v of row s = vertex v holds sample s (what
+  // get_sample_from_vertex_if_exists answers).  Vertex ids grow along the reference, so every test of one walk step --
+  // the node, its neighbours, the neighbours' neighbours -- falls into one or two 64-bit words of the sample's row
+  // instead of one class-row line per vertex.  Built together with t4_events.
+  const uint64_t* t4_hold;
+  uint64_t t4_hold_stride;  // 64-bit words per sample row: ceil(V / 64) + 1
+  // The walk blob (device_image.hpp): 32-byte records in the order a walk along the reference needs them -- per ref-path
+  // slot one header record {first edge record, degree, ref index, 0, length, class, #carriers, vertex id}, the edge
+  // records of the slot's node {neighbour, its ref index, its class, ITS first edge record, its degree, its ref-path
+  // slot + 1, its length, its #carriers}, then the edge records of its off-path neighbours (and theirs): one or two
+  // cache lines hold everything an episode of the type-4 walk reads.
+  const uint4* wblob;
+  const uint32_t* blob_of_slot;   // [P + 1] header record of each ref-path slot
+  const uint32_t* blob_row;       // [V] first edge record of each vertex
   const uint2* rk_back;     // [R] per rank r: {first ref-path slot of r (= Index::previous(r + 1)), out-degree of that node}
 };
 
@@ -1451,6 +1462,36 @@ __global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* 
   }
 }
 
+// Hold rows (DevImage::t4_hold): one wave per tile of 64 consecutive vertex ids, the same transpose as k_build_events.
+__global__ void __launch_bounds__(256) k_build_hold(DevImage im, uint64_t* hold) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t tile = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= (im.V + 63) >> 6) return;
+  const uint64_t v = tile * 64 + lane;
+  const bool valid = v < im.V;
+  const uint32_t cls = valid ? im.v_class[v] : 0;
+  for (uint32_t w = 0; w < im.wpc; ++w) {
+    const uint64_t word = valid ? im.class_rows[(uint64_t)cls * im.wpc + w] : 0;
+    uint64_t mine = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < 64; ++b) {
+      const uint64_t m = __ballot((word >> b) & 1);
+      if (lane == b) mine = m;
+    }
+    const uint32_t sample = w * 64 + lane;
+    if (sample >= 1 && sample < im.num_samples) hold[(uint64_t)sample * im.t4_hold_stride + tile] = mine;
+  }
+}
+__global__ void __launch_bounds__(256) k_hold_explicit(DevImage im, uint64_t* hold) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= im.V) return;
+  const uint64_t b = im.v_car_begin[v];
+  for (uint32_t i = 0; i < im.v_ncar[v]; ++i) {
+    const uint32_t sid = im.car_sid[b + i];
+    if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&hold[(uint64_t)sid * im.t4_hold_stride + (v >> 6)], 1ULL << (v & 63));
+  }
+}
+
 // Walk records (device_image.hpp): one step of a path walk reads the current vertex in one 32-byte record and each
 // neighbour in one 16-byte edge record instead of gathering a dozen 4-byte fields from as many arrays.
 struct WalkVertex { uint32_t row_begin, deg, ridx, off, len, cls, ncar; };
@@ -1520,75 +1561,9 @@ __device__ __forceinline__ WalkVariant resolve_walk_variant(const DevImage& im, 
   return o;
 }
 
-// One literal step's view of a vertex's out-edges, read with memory-level parallelism: all edge records (and, for
-// ref neighbours, their ref-path slots) are requested together, then all class words; the reference's in-order
-// decision logic runs over registers.  Up to kStepEdges edges; higher degrees (rare) take the one-at-a-time loop.
-constexpr uint32_t kStepEdges = 4;
-struct StepOut {
-  uint64_t next_ref_pos;      // ref index of the LAST ref neighbour (unchanged if there is none)
-  uint32_t next_ref_v;        // that neighbour (kNone: none)
-  uint32_t nxt;               // get_neighbor_vertex: first neighbour holding the sample, else the ref neighbour with the smallest index; 0 = none
-  uint32_t nxt_slot1;         // its ref-path slot + 1 (0: not on the path)
-  WalkVertex wn;              // its vertex record
-};
-__device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, const WalkVertex& wc, uint32_t sid, uint64_t next_ref_pos_default) {
-  StepOut o;
-  o.next_ref_pos = next_ref_pos_default; o.next_ref_v = kNone; o.nxt = 0; o.nxt_slot1 = 0; o.wn = WalkVertex{};
-  uint32_t min_idx = 0xFFFFFFFFu;
-  bool nxt_by_sample = false;
-  if (wc.deg <= kStepEdges && im.use_bv) {
-    uint4 a[kStepEdges], b[kStepEdges];
-    uint32_t es[kStepEdges];
-    uint64_t cw[kStepEdges];
-#pragma unroll
-    for (uint32_t i = 0; i < kStepEdges; ++i) {
-      a[i] = uint4{0, 0, 0, 0}; b[i] = uint4{0, 0, 0, 0}; es[i] = 0;
-      if (i < wc.deg) {
-        a[i] = im.w_edge[2 * (uint64_t)(wc.row_begin + i)];
-        b[i] = im.w_edge[2 * (uint64_t)(wc.row_begin + i) + 1];
-        es[i] = im.e_slot[wc.row_begin + i];
-      }
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < kStepEdges; ++i) {
-      cw[i] = 0;
-      if (i < wc.deg && sid != 0) cw[i] = im.class_rows[(uint64_t)a[i].z * im.wpc + (sid >> 6)];
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < kStepEdges; ++i) {   // (predicated, not `break`: the arrays must stay in registers)
-      const bool on = i < wc.deg;
-      const uint32_t n = a[i].x, nr = a[i].y;
-      if (on && nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
-      if (on && !nxt_by_sample) {
-        const bool holds = sid != 0 && ((cw[i] >> (sid & 63)) & 1);
-        if (holds || (nr && min_idx > nr)) {
-          o.nxt = n; o.nxt_slot1 = es[i];
-          o.wn = WalkVertex{a[i].w, b[i].x, a[i].y, b[i].y, b[i].z, a[i].z, b[i].w};
-          if (holds) nxt_by_sample = true; else min_idx = nr;
-        }
-      }
-    }
-    return o;
-  }
-  for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
-    WalkVertex nv;
-    const WalkEdge ed = walk_edge_full(im, e, nv);   // neighbour, its ref index, its class, and its own record
-    const uint32_t n = ed.nbr, nr = ed.ridx;
-    if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }
-    if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
-      const bool holds = sid != 0 && record_has_sample(im, n, nr, ed.cls, sid);
-      if (holds || (nr && min_idx > nr)) {
-        o.nxt = n; o.nxt_slot1 = im.e_slot[e]; o.wn = nv;
-        if (holds) nxt_by_sample = true; else min_idx = nr;
-      }
-    }
-  }
-  return o;
-}
-
-// The sample's event row read through a one-word cache: consecutive look-ups of a walk (and of the backward search)
-// fall into the same 64-slot word more often than not.
-struct EventRow {
+// One 64-bit-word cache in front of a per-sample bit row (event rows over slots, hold rows over vertex ids): consecutive
+// look-ups of a walk fall into the same word more often than not.
+struct BitRow {
   const uint64_t* __restrict__ row;
   uint32_t w;          // index of the cached word (kNone: nothing cached)
   uint64_t word;
@@ -1596,8 +1571,8 @@ struct EventRow {
     if (wi != w) { w = wi; word = row[wi]; }
     return word;
   }
-  __device__ __forceinline__ bool bit(uint32_t slot) { return (at(slot >> 6) >> (slot & 63)) & 1; }
-  // first slot >= m whose bit is set, or `limit` when there is none below it (m < limit <= P)
+  __device__ __forceinline__ bool bit(uint32_t i) { return (at(i >> 6) >> (i & 63)) & 1; }
+  // first index >= m whose bit is set, or `limit` when there is none below it (m < limit)
   __device__ __forceinline__ uint32_t next(uint32_t m, uint32_t limit) {
     uint32_t wi = m >> 6;
     const uint32_t w_end = (limit + 63) >> 6;
@@ -1610,18 +1585,88 @@ struct EventRow {
     return k < limit ? k : limit;
   }
 };
+typedef BitRow EventRow;
 
 // ---- the walk of get_sample_var_in_ref as reusable pieces (serial kernel k_sample_walk, cooperative k_sample_walk_coop) ----
+// Two data paths, chosen per region: BLOB (the sample has event + hold rows: records from the walk blob, "does v hold
+// the sample" from the hold row, jumps over uneventful runs) and plain (sample 0 = "ref", or an index without the rows:
+// the round-2 records, class rows, every vertex visited).  WalkVertex::row_begin indexes the blob resp. w_edge.
 struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; };
 struct WalkSt { uint32_t cur; WalkVertex wc; uint64_t ref_pos; uint32_t cur_ref_v, cur_slot1; };   // cur_slot1: ref-path slot + 1 of cur, 0 = off the path
 struct WalkEmit { uint64_t ref_pos; uint32_t cur, kind, cur_ref_v, c; };   // the walk's state at a reported vertex (-> resolve_walk_variant)
 
+constexpr uint32_t kStepEdges = 3;   // out-edges a step reads together (higher degrees -- rare -- one at a time)
+struct StepOut {
+  uint64_t next_ref_pos;      // ref index of the LAST ref neighbour (unchanged if there is none)
+  uint32_t next_ref_v;        // that neighbour (kNone: none)
+  uint32_t nxt;               // get_neighbor_vertex: first neighbour holding the sample, else the ref neighbour with the smallest index; 0 = none
+  uint32_t nxt_slot1;         // its ref-path slot + 1 (0: not on the path)
+  WalkVertex wn;              // its vertex record
+};
+// does vertex v hold the sample (get_sample_from_vertex_if_exists)?  BLOB: the sample's hold row; else class row / carrier list
+template <bool BLOB>
+__device__ __forceinline__ bool walk_holds(const DevImage& im, BitRow& hold, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t sid) {
+  if (BLOB) return hold.bit(v);
+  return record_has_sample(im, v, ridx, cls, sid);
+}
+// One literal step's view of a vertex's out-edges: all edge records are requested together (one or two lines of the
+// blob), the hold bits of the neighbours come from a word that is usually cached already, and the reference's in-order
+// decision logic (get_neighbor_vertex, variant_graph.h:1402-1451; "last ref neighbour", query.h:640-667) runs over registers.
+template <bool BLOB>
+__device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, BitRow& hold, const WalkVertex& wc, uint32_t sid, uint64_t next_ref_pos_default) {
+  StepOut o;
+  o.next_ref_pos = next_ref_pos_default; o.next_ref_v = kNone; o.nxt = 0; o.nxt_slot1 = 0; o.wn = WalkVertex{};
+  uint32_t min_idx = 0xFFFFFFFFu;
+  bool nxt_by_sample = false;
+  if (BLOB && wc.deg <= kStepEdges) {
+    uint4 a[kStepEdges], b[kStepEdges];
+#pragma unroll
+    for (uint32_t i = 0; i < kStepEdges; ++i) {
+      a[i] = uint4{0, 0, 0, 0}; b[i] = uint4{0, 0, 0, 0};
+      if (i < wc.deg) { a[i] = im.wblob[2 * (uint64_t)(wc.row_begin + i)]; b[i] = im.wblob[2 * (uint64_t)(wc.row_begin + i) + 1]; }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kStepEdges; ++i) {   // (predicated, not `break`: the arrays must stay in registers)
+      const bool on = i < wc.deg;
+      const uint32_t n = a[i].x, nr = a[i].y;
+      if (on && nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
+      if (on && !nxt_by_sample) {
+        const bool holds = hold.bit(n);
+        if (holds || (nr && min_idx > nr)) {
+          o.nxt = n; o.nxt_slot1 = b[i].y;
+          o.wn = WalkVertex{a[i].w, b[i].x, a[i].y, 0u, b[i].z, a[i].z, b[i].w};
+          if (holds) nxt_by_sample = true; else min_idx = nr;
+        }
+      }
+    }
+    return o;
+  }
+  for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+    uint4 a, b;
+    if (BLOB) { a = im.wblob[2 * (uint64_t)e]; b = im.wblob[2 * (uint64_t)e + 1]; }
+    else { a = im.w_edge[2 * (uint64_t)e]; b = im.w_edge[2 * (uint64_t)e + 1]; }
+    const uint32_t n = a.x, nr = a.y;
+    if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }
+    if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
+      const bool holds = sid != 0 && walk_holds<BLOB>(im, hold, n, nr, a.z, sid);
+      if (holds || (nr && min_idx > nr)) {
+        o.nxt = n;
+        o.nxt_slot1 = BLOB ? b.y : 0u;
+        o.wn = BLOB ? WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w} : WalkVertex{a.w, b.x, a.y, b.y, b.z, a.z, b.w};
+        if (holds) nxt_by_sample = true; else min_idx = nr;
+      }
+    }
+  }
+  return o;
+}
+
 // One iteration of the reference's loop body (query.h:640-720) at st.cur: is the vertex reported, then the step to the
 // next vertex of the sample's path.  `done`: the path iterator has no next vertex.
-__device__ __forceinline__ bool walk_literal_step(const DevImage& im, const WalkCtx& cx, WalkSt& st, WalkEmit& em, bool& done) {
+template <bool BLOB>
+__device__ __forceinline__ bool walk_literal_step(const DevImage& im, const WalkCtx& cx, BitRow& hold, WalkSt& st, WalkEmit& em, bool& done) {
   // does cur hold the sample?  (requested before the edges: it is independent of them)
-  const bool cur_holds = st.ref_pos >= cx.x && record_has_sample(im, st.cur, st.wc.ridx, st.wc.cls, cx.sid);
-  const StepOut so = walk_step_edges(im, st.wc, cx.sid, st.ref_pos + st.wc.len);
+  const bool cur_holds = st.ref_pos >= cx.x && walk_holds<BLOB>(im, hold, st.cur, st.wc.ridx, st.wc.cls, cx.sid);
+  const StepOut so = walk_step_edges<BLOB>(im, hold, st.wc, cx.sid, st.ref_pos + st.wc.len);
   bool emit = false;
   if (cur_holds) {
     const uint32_t kind = st.ref_pos == so.next_ref_pos ? 0u : (st.wc.ridx ? 1u : 2u);
@@ -1643,16 +1688,24 @@ __device__ __forceinline__ bool walk_in_step(const WalkCtx& cx, const WalkSt& st
 // arrival at event slot k "in step": {k's node, its index}; cur_ref is not read before the step overwrites it (it only
 // enters a substitution, and a ref-path node is never reported as one)
 __device__ __forceinline__ void walk_arrive_at_slot(const DevImage& im, WalkSt& st, uint32_t k) {
-  const uint4 ra = im.rp_walk[2 * (uint64_t)k], rb = im.rp_walk[2 * (uint64_t)k + 1];   // vertex record of slot k's node
+  const uint64_t h = im.blob_of_slot[k];
+  const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header record of slot k
   st.cur = rb.w;
-  st.wc = WalkVertex{ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z};
+  st.wc = WalkVertex{ra.x, ra.y, ra.z, 0u, rb.x, rb.y, rb.z};
   st.ref_pos = st.wc.ridx;
   st.cur_ref_v = st.cur;
   st.cur_slot1 = k + 1;
 }
+// the blob-mode vertex record of an arbitrary vertex (rare: the walk's start at the head of the path, slow paths)
+__device__ __forceinline__ WalkVertex blob_vertex(const DevImage& im, uint32_t v) {
+  WalkVertex w = walk_vertex(im, v);
+  w.row_begin = im.blob_row[v];
+  return w;
+}
 
 // get_prev_vertex_with_sample (query.h:57-113) from find(x)'s rank: the start state of the walk
-__device__ __forceinline__ void walk_start_search(const DevImage& im, const WalkCtx& cx, EventRow& ev, uint64_t rank0, WalkSt& st,
+template <bool BLOB>
+__device__ __forceinline__ void walk_start_search(const DevImage& im, const WalkCtx& cx, BitRow& ev, BitRow& hold, uint64_t rank0, WalkSt& st,
                                                   uint32_t& st_iters, uint32_t& st_lit) {
   const uint32_t sid = cx.sid;
   uint64_t rank = rank0;
@@ -1660,7 +1713,7 @@ __device__ __forceinline__ void walk_start_search(const DevImage& im, const Walk
   uint32_t start_v = 0, start_slot1 = 0;
   WalkVertex wc{};
   bool have_start_rec = false;   // the search found start_v through an edge record that carries its vertex record
-  bool jump = cx.use_ev, jumped = false;
+  bool jump = BLOB, jumped = false;
   while (true) {
     ++st_iters;
     // Index::previous(rank) is the first ref-path slot of rank - 1; rk_back holds it together with that node's
@@ -1668,7 +1721,7 @@ __device__ __forceinline__ void walk_start_search(const DevImage& im, const Walk
     const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
     const uint32_t pslot = back.x;
     if (rank <= 1) { ref_pos = 1; start_v = im.rp_vid[pslot]; have_start_rec = false; break; }
-    if (jump && !ev.bit(pslot)) {
+    if (BLOB && jump && !ev.bit(pslot)) {
       // no out-neighbour of this node holds the sample: the scan below would find nothing and count the rank
       // down once per neighbour
       rank = rank > back.y ? rank - back.y : 0;
@@ -1677,33 +1730,26 @@ __device__ __forceinline__ void walk_start_search(const DevImage& im, const Walk
     }
     ++st_lit;
     bool found = false, had_ref = false;
-    const uint4 pa = im.rp_walk[2 * (uint64_t)pslot];   // {row_begin, degree, ..} of the slot's node
-    const uint32_t rb0 = pa.x, deg = pa.y;
-    if (deg <= kStepEdges && im.use_bv && sid != 0) {
-      uint4 a[kStepEdges], b[kStepEdges];
-      uint32_t es[kStepEdges];
-      uint64_t cw[kStepEdges];
-#pragma unroll
-      for (uint32_t i = 0; i < kStepEdges; ++i) {
-        a[i] = uint4{0, 0, 0, 0}; b[i] = uint4{0, 0, 0, 0}; es[i] = 0;
-        if (i < deg) { a[i] = im.w_edge[2 * (uint64_t)(rb0 + i)]; b[i] = im.w_edge[2 * (uint64_t)(rb0 + i) + 1]; es[i] = im.e_slot[rb0 + i]; }
-      }
-#pragma unroll
-      for (uint32_t i = 0; i < kStepEdges; ++i) cw[i] = i < deg ? im.class_rows[(uint64_t)a[i].z * im.wpc + (sid >> 6)] : 0;
-#pragma unroll
-      for (uint32_t i = 0; i < kStepEdges; ++i) {
-        if (i < deg && a[i].y) { ref_pos = a[i].y; had_ref = true; }
-        if (i < deg && ((cw[i] >> (sid & 63)) & 1)) {
-          start_v = a[i].x; found = true; have_start_rec = true; start_slot1 = es[i];
-          wc = WalkVertex{a[i].w, b[i].x, a[i].y, b[i].y, b[i].z, a[i].z, b[i].w};
+    const uint32_t deg = back.y;
+    if (BLOB) {
+      const uint32_t rb0 = im.blob_of_slot[pslot] + 1;   // the edge records follow the slot's header
+      for (uint32_t e = rb0; e < rb0 + deg; ++e) {
+        const uint4 a = im.wblob[2 * (uint64_t)e];
+        if (a.y) { ref_pos = a.y; had_ref = true; }
+        if (hold.bit(a.x)) {
+          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+          start_v = a.x; found = true; have_start_rec = true; start_slot1 = b.y;
+          wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
         }
       }
       rank = rank > deg ? rank - deg : 0;   // one count per neighbour (the reference's unsigned counter would wrap: clamped)
     } else {
+      const uint32_t v = im.rp_vid[pslot];
+      const uint32_t rb0 = im.row_ptr[v];
       for (uint32_t e = rb0; e < rb0 + deg; ++e) {
         const WalkEdge ed = walk_edge(im, e);
         if (ed.ridx) { ref_pos = ed.ridx; had_ref = true; }
-        if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; have_start_rec = false; }
+        if (record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { start_v = ed.nbr; found = true; }
         rank = rank ? rank - 1 : 0;
       }
     }
@@ -1719,10 +1765,10 @@ __device__ __forceinline__ void walk_start_search(const DevImage& im, const Walk
   st.ref_pos = ref_pos;
   st.cur_ref_v = kNone;  // cur_ref: the last ref neighbour of the previous vertex (its sequence; none = empty string)
   if (have_start_rec) { st.wc = wc; st.cur_slot1 = start_slot1; }
-  else {                 // afterwards the record of a vertex arrives with the edge the walk takes to it
-    st.wc = walk_vertex(im, start_v);
+  else if (BLOB) {       // afterwards the record of a vertex arrives with the edge the walk takes to it
+    st.wc = blob_vertex(im, start_v);
     st.cur_slot1 = im.w_vertex[2 * (uint64_t)start_v + 1].w;
-  }
+  } else { st.wc = walk_vertex(im, start_v); st.cur_slot1 = 0; }
 }
 
 // Index::is_empty (index.h:150-166), find(pos, rank) and -- for the event-bitmap walk -- the stop slot, all from two ranks
@@ -1742,6 +1788,32 @@ __device__ __forceinline__ uint8_t walk_prologue(const DevImage& im, WalkCtx& cx
   return 0;
 }
 
+// The serial walk of one region: the reference's loop, with jumps over uneventful runs in BLOB mode.  `sink(em)` takes
+// each reported vertex.
+template <bool BLOB, typename Sink>
+__device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& cx, BitRow& ev, BitRow& hold, WalkSt& st, Sink&& sink,
+                                            uint32_t& st_jumps, uint32_t& st_steps) {
+  bool done = false;
+  while (!done) {
+    if (st.ref_pos >= cx.y) break;
+    if (BLOB && walk_in_step(cx, st)) {
+      // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
+      // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
+      // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
+      // stop at `limit` if that comes first.
+      const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
+      if (k != st.cur_slot1 - 1) {
+        if (k >= cx.limit) break;
+        walk_arrive_at_slot(im, st, k);
+        ++st_jumps;
+      }
+    }
+    ++st_steps;
+    WalkEmit em;
+    if (walk_literal_step<BLOB>(im, cx, hold, st, em, done)) sink(em);
+  }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                     WalkScratch ws) {
@@ -1749,59 +1821,45 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
   WalkCtx cx{sid_per_region ? sid_per_region[q] : sid_all, r.regions[2 * q], r.regions[2 * q + 1], false, 0};
-  // Event bitmap of this sample (DevImage::t4_events): clear bits are ref-path slots where neither the node nor any
-  // of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do nothing
-  // there but step on, so both the backward search and the walk below jump over them.  Everything that happens at
-  // a set bit is the literal code.
+  // Event and hold rows of this sample (DevImage::t4_events, t4_hold): clear event bits are ref-path slots where neither
+  // the node nor any of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do
+  // nothing there but step on, so both the backward search and the walk jump over them.  Everything that happens at a
+  // set bit is the literal code.
   cx.use_ev = im.t4_events && cx.sid != 0;
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0, rank0 = 0;
   const uint8_t fl = walk_prologue(im, cx, rank0);
   if (!fl) {
-    EventRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};
+    BitRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};
+    BitRow hold{cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr, kNone, 0};
     const uint64_t t_s0 = VS_WALK_CLOCK();
     uint32_t st_iters = 0, st_lit = 0, st_jumps = 0, st_steps = 0;
     WalkSt st;
-    walk_start_search(im, cx, ev, rank0, st, st_iters, st_lit);
+    if (cx.use_ev) walk_start_search<true>(im, cx, ev, hold, rank0, st, st_iters, st_lit);
+    else walk_start_search<false>(im, cx, ev, hold, rank0, st, st_iters, st_lit);
     const uint64_t t_s1 = VS_WALK_CLOCK();
     // ---- walk the sample's path ----
-    bool done = false;
     const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
     const uint64_t cb = EMIT ? r.car_base[q] : 0;
     const uint64_t s0 = MODE == 2 ? ws.cap_begin[q] : 0, scap = MODE == 2 ? ws.cap_begin[q + 1] - s0 : 0;
-    while (!done) {
-      if (st.ref_pos >= cx.y) break;
-      if (walk_in_step(cx, st)) {
-        // On a ref-path node, in step with it (ref_pos == its index): up to the next event slot k the literal loop
-        // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
-        // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
-        // stop at `limit` if that comes first.
-        const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
-        if (k != st.cur_slot1 - 1) {
-          if (k >= cx.limit) break;
-          walk_arrive_at_slot(im, st, k);
-          ++st_jumps;
-        }
+    auto sink = [&](const WalkEmit& em) {
+      if (EMIT) {
+        const WalkVariant wv = resolve_walk_variant(im, em.kind, em.cur, em.ref_pos, em.cur_ref_v);
+        const uint64_t a = a0 + nvar;
+        r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
+        r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = em.c;
+        r.r_region[a] = (uint32_t)q;
+        r.r_class[a] = im.v_src[em.cur]; r.r_gt0[a] = im.v_car_begin[em.cur];
       }
-      ++st_steps;
-      WalkEmit em;
-      if (walk_literal_step(im, cx, st, em, done)) {
-        if (EMIT) {
-          const WalkVariant wv = resolve_walk_variant(im, em.kind, em.cur, em.ref_pos, em.cur_ref_v);
-          const uint64_t a = a0 + nvar;
-          r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
-          r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = em.c;
-          r.r_region[a] = (uint32_t)q;
-          r.r_class[a] = im.v_src[em.cur]; r.r_gt0[a] = im.v_car_begin[em.cur];
-        }
-        if (MODE == 2) {   // the walk's state at the vertex; k_emit_from_walk turns it into the row
-          if (nvar < scap) {
-            const uint64_t s = s0 + nvar;
-            ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v;
-          } else *ws.overflow = 1;
-        }
-        nvar++; ncar += pad_car(em.c); ncar_kept += em.c;
+      if (MODE == 2) {   // the walk's state at the vertex; k_emit_from_walk turns it into the row
+        if (nvar < scap) {
+          const uint64_t s = s0 + nvar;
+          ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v;
+        } else *ws.overflow = 1;
       }
-    }
+      nvar++; ncar += pad_car(em.c); ncar_kept += em.c;
+    };
+    if (cx.use_ev) walk_serial<true>(im, cx, ev, hold, st, sink, st_jumps, st_steps);
+    else walk_serial<false>(im, cx, ev, hold, st, sink, st_jumps, st_steps);
     const uint64_t t_s2 = VS_WALK_CLOCK();
     VS_WALK_STAT(0, 1); VS_WALK_STAT(1, st_iters); VS_WALK_STAT(2, st_lit); VS_WALK_STAT(3, st_jumps); VS_WALK_STAT(4, st_steps);
     VS_WALK_STAT(5, t_s1 - t_s0); VS_WALK_STAT(6, t_s2 - t_s1); VS_WALK_STAT(7, nvar);
@@ -1860,7 +1918,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
   uint32_t cur_slot = 0;     // slot at which the chain is in step
   uint64_t s0 = 0, scap = 0;
-  EventRow ev{nullptr, kNone, 0};
+  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0};
   WalkSt st{};
   const uint64_t t_c0 = VS_WALK_CLOCK();
   uint64_t t_c1 = t_c0, t_c2 = t_c0;
@@ -1870,8 +1928,9 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
     if (!fl) {
       ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
+      hold.row = cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr;
       uint32_t it = 0, lit = 0;
-      walk_start_search(im, cx, ev, rank0, st, it, lit);
+      if (cx.use_ev) walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit);
       n_search = it;
       t_c1 = VS_WALK_CLOCK();
       if (!cx.use_ev) serial = true;
@@ -1884,7 +1943,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
           if (walk_in_step(cx, st)) { cur_slot = st.cur_slot1 - 1; break; }
           if (++steps > 64) { serial = true; break; }   // (a start state that never falls in step: walk it serially)
           WalkEmit em;
-          if (walk_literal_step(im, cx, st, em, done)) {
+          if (walk_literal_step<true>(im, cx, hold, st, em, done)) {
             if (nvar < scap) {
               if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v; }
             } else if (l == 0) *ws.overflow = 1;
@@ -1927,7 +1986,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       uint32_t steps = 0;
       while (true) {
         WalkEmit e1;
-        if (walk_literal_step(im, cx, es, e1, done)) {
+        if (walk_literal_step<true>(im, cx, hold, es, e1, done)) {
           if (n_em < kEpEmits) {
 #pragma unroll
             for (uint32_t t = 0; t < kEpEmits; ++t) if (t == n_em) em[t] = e1;
@@ -1985,28 +2044,17 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   // ---- regions without event rows, and fallbacks: the serial loop (redundant in the group; lane 0 writes) ----
   if (__any(serial)) {
     if (serial) {
-      uint32_t it = 0, lit = 0;
+      uint32_t it = 0, lit = 0, jm = 0, sp = 0;
       nvar = 0; ncar = 0;
-      ev.w = kNone;
-      walk_start_search(im, cx, ev, rank0, st, it, lit);
-      bool done = false;
-      while (!done) {
-        if (st.ref_pos >= cx.y) break;
-        if (walk_in_step(cx, st)) {
-          const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
-          if (k != st.cur_slot1 - 1) {
-            if (k >= cx.limit) break;
-            walk_arrive_at_slot(im, st, k);
-          }
-        }
-        WalkEmit e1;
-        if (walk_literal_step(im, cx, st, e1, done)) {
-          if (nvar < scap) {
-            if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
-          } else if (l == 0) *ws.overflow = 1;
-          nvar++; ncar += pad_car(e1.c);
-        }
-      }
+      ev.w = kNone; hold.w = kNone;
+      auto sink = [&](const WalkEmit& e1) {
+        if (nvar < scap) {
+          if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
+        } else if (l == 0) *ws.overflow = 1;
+        nvar++; ncar += pad_car(e1.c);
+      };
+      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, ev, hold, st, sink, jm, sp); }
+      else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, ev, hold, st, sink, jm, sp); }
     }
   }
   if (live && l == 0) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }

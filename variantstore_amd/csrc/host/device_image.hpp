@@ -85,8 +85,15 @@ struct HostImage {
   // what the type-4 event bitmaps rely on to find where a walk stops; false for an index that breaks it (never seen)
   bool slots_follow_ranks = false;
   std::vector<uint32_t> w_edge;     // 8 words per CSR entry
-  std::vector<uint32_t> e_slot;     // [E] ref-path slot + 1 of the neighbour (0: not on the path): arrives with the edge record
-  std::vector<uint32_t> rp_walk;    // 8 words per ref-path slot: w_vertex of the slot's node with word 7 = the vertex id
+  // The walk blob of query type 4: 8-word records laid out in the order a walk along the reference meets them.  Per
+  // ref-path slot, in slot order: a header {first edge record, degree, ref index, 0, length, class, #carriers, vertex id},
+  // the edge records of the slot's node {neighbour, its ref index, its class, its first edge record, its degree, its
+  // ref-path slot + 1, its length, its #carriers}, then -- breadth first -- the edge records of the off-path vertices
+  // reachable from it that have not been placed yet (alt alleles hang off the node in front of them): the node, its
+  // branches and where they rejoin sit in one or two cache lines.
+  std::vector<uint32_t> wblob;
+  std::vector<uint32_t> blob_of_slot;   // [P + 1] header record of each slot
+  std::vector<uint32_t> blob_row;       // [V] first edge record of each vertex
   std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
@@ -335,19 +342,53 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   }
   for (uint64_t i = 0; i < im.P; ++i) im.w_vertex[(uint64_t)im.rp_vid[i] * 8 + 7] = (uint32_t)i + 1;   // ref-path slot + 1 (0: off the path)
   im.w_edge.assign(im.E * 8, 0);
-  im.e_slot.assign(im.E + 1, 0);
   for (uint64_t e = 0; e < im.E; ++e) {
     const uint32_t n = im.col[e];
     uint32_t* w = &im.w_edge[e * 8];
     w[0] = n; w[1] = im.v_ridx[n]; w[2] = im.v_class[n]; w[3] = im.row_ptr[n];
     w[4] = im.row_ptr[n + 1] - im.row_ptr[n]; w[5] = im.v_off[n]; w[6] = im.v_len[n]; w[7] = im.v_ncar[n];
-    im.e_slot[e] = im.w_vertex[(uint64_t)n * 8 + 7];
   }
-  im.rp_walk.assign((im.P + 1) * 8, 0);
-  for (uint64_t i = 0; i < im.P; ++i) {
-    const uint32_t v = im.rp_vid[i];
-    std::copy(&im.w_vertex[(uint64_t)v * 8], &im.w_vertex[(uint64_t)v * 8 + 7], &im.rp_walk[i * 8]);
-    im.rp_walk[i * 8 + 7] = v;
+  {  // ---- walk blob ----
+    im.blob_row.assign(V + 1, VS_NONE);
+    im.blob_of_slot.assign(im.P + 1, 0);
+    std::vector<uint32_t> placed;   // vertices in the order their edge rows are laid out
+    placed.reserve(V);
+    uint64_t at = 0;
+    std::vector<uint32_t> queue;
+    auto deg_of = [&](uint32_t v) { return im.row_ptr[v + 1] - im.row_ptr[v]; };
+    for (uint64_t k = 0; k < im.P; ++k) {
+      const uint32_t R = im.rp_vid[k];
+      im.blob_of_slot[k] = (uint32_t)at++;           // the header
+      im.blob_row[R] = (uint32_t)at; at += deg_of(R); placed.push_back(R);
+      queue.assign(1, R);
+      for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const uint32_t u = queue[qi];
+        for (uint32_t e = im.row_ptr[u]; e < im.row_ptr[u + 1]; ++e) {
+          const uint32_t n = im.col[e];
+          if (im.w_vertex[(uint64_t)n * 8 + 7] != 0 || im.blob_row[n] != VS_NONE) continue;   // on the path, or placed already
+          im.blob_row[n] = (uint32_t)at; at += deg_of(n); placed.push_back(n);
+          queue.push_back(n);
+        }
+      }
+    }
+    im.blob_of_slot[im.P] = (uint32_t)at;
+    for (uint64_t v = 0; v < V; ++v)
+      if (im.blob_row[v] == VS_NONE) { im.blob_row[v] = (uint32_t)at; at += deg_of((uint32_t)v); placed.push_back((uint32_t)v); }
+    if (at > 0xFFFFFFF0ull) throw std::runtime_error("walk blob exceeds 2^32 records");
+    im.wblob.assign((at + 1) * 8, 0);
+    for (uint32_t u : placed)
+      for (uint32_t i = 0; i < deg_of(u); ++i) {
+        const uint32_t n = im.col[im.row_ptr[u] + i];
+        uint32_t* w = &im.wblob[((uint64_t)im.blob_row[u] + i) * 8];
+        w[0] = n; w[1] = im.v_ridx[n]; w[2] = im.v_class[n]; w[3] = im.blob_row[n];
+        w[4] = deg_of(n); w[5] = im.w_vertex[(uint64_t)n * 8 + 7]; w[6] = im.v_len[n]; w[7] = im.v_ncar[n];
+      }
+    for (uint64_t k = 0; k < im.P; ++k) {
+      const uint32_t R = im.rp_vid[k];
+      uint32_t* w = &im.wblob[(uint64_t)im.blob_of_slot[k] * 8];
+      w[0] = im.blob_row[R]; w[1] = deg_of(R); w[2] = im.v_ridx[R]; w[3] = 0; w[4] = im.v_len[R]; w[5] = im.v_class[R];
+      w[6] = im.v_ncar[R]; w[7] = R;
+    }
   }
   im.rk_back.assign((im.R + 1) * 2, 0);
   for (uint64_t r = 0; r < im.R; ++r) {
