@@ -201,6 +201,11 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view);
 /* Totals without any copy of the arrays. */
 int vs_result_totals(const vs_result* r, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers,
                      uint64_t* n_bases);
+/* How the result lies in HBM: variant slots, arena entries in use (padded to groups of 8), carrier lists actually
+ * expanded, and whether lists are SHARED: a sorted type-6 batch of overlapping regions expands every site it covers once
+ * and all regions reporting that site point at the one list (car_begin of their rows) -- like REF / ALT, which are
+ * references into the sequence pool.  Views and texts are unaffected. */
+int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared);
 /* The `-o` file of region q (print_header + print_var, query.h:38-50) as text owned by the result. */
 int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len);
 /* Order-independent 64-bit digest of (region, pos, ref, alt, carriers) computed
@@ -226,7 +231,8 @@ void vs_result_free(vs_result* r);
  * switch.  Keys: "latency_server" 0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first
  * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
  * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
- * chosen from the batch's shape); "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * chosen from the batch's shape); "share_lists" 0 = every region gets private copies of its carrier lists even in a
+ * sorted batch; "t4_coop" 0 = one lane per region in the type-4 walk; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
  * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
 int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 

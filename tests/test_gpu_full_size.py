@@ -163,3 +163,26 @@ def test_type4_event_bitmap_walk_equals_the_literal_walk_at_full_size(big):
         assert np.array_equal(vf[k], vl[k]), k
     fast.close()
     slow.close()
+
+
+def test_shared_and_private_carrier_lists_agree_at_full_size(big):
+    """The bench batch both ways: one list per covered site shared by the regions that report it (the default for a
+    sorted batch) against a private copy per region -- same digest, totals and rows; a quarter of the lists."""
+    vs, regions = big
+    shared = vs.get_var_in_ref(regions)
+    slots, arena, lists, is_shared = shared.layout()
+    assert is_shared and slots > 15_000_000 and lists < 5_100_000 and lists > 4_000_000
+    ts, ds = shared.totals(), shared.digest()
+    texts = {q: shared.region_text(q) for q in (0, 7, 55_555, 99_999)}
+    shared.close()
+    vs.set_option("share_lists", 0)
+    try:
+        private = vs.get_var_in_ref(regions)
+    finally:
+        vs.set_option("share_lists", 1)
+    p_slots, p_arena, p_lists, p_shared = private.layout()
+    assert not p_shared and p_slots == slots and p_lists == slots and p_arena > 3 * arena
+    assert (private.totals(), private.digest()) == (ts, ds)
+    for q, text in texts.items():
+        assert private.region_text(q) == text
+    private.close()

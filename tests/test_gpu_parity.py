@@ -768,3 +768,50 @@ def test_positions_far_beyond_the_reference(tmp_path):
     for q, p in enumerate([2 ** 32 + 7, 2 ** 40 + 3]):
         n, text = orc.closest_var(p)
         assert (n < 0) == bool(flags[q] & 4) and (n < 0 or res.region_text(q) == text), p
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (601, dict(n_rows=400, ref_len=5000, n_samples=70, carrier_p=0.4)),                      # class rows wider than one word
+    (602, dict(n_rows=400, ref_len=4000, p_near=0.7, p_multi=0.3, p_same=0.25)),              # crowded: the duplicate rule fires
+    (603, dict(n_rows=300, ref_len=5000, n_samples=130, carrier_p=0.004)),                    # explicit sample ids
+    (604, dict(n_rows=300, ref_len=6000, n_samples=900, carrier_p=0.5, p_ins=0.2, p_del=0.2)),  # dense rows: the row path
+])
+def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
+    """A sorted batch of overlapping regions expands every covered site once and lets the regions share the list
+    (kernels.hip.h: k_share_*): same text as the oracle, same digest and view as the private-list form; an unsorted
+    batch takes the private form by itself."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), seed, **kw)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(seed)
+    ref_len = vs.info().ref_length
+    regions = sorted(random_regions(rng, ref_len, 500, max_len=900))
+    shared = vs.get_var_in_ref(regions)
+    slots, arena, lists, is_shared = shared.layout()
+    assert is_shared and lists < slots / 2 and arena > 0
+    want = oracle_texts(orc, regions)
+    for q, (n, early, text) in enumerate(want):
+        if n >= 0:
+            assert shared.region_text(q) == text, (q, regions[q])
+    vs.set_option("share_lists", 0)
+    private = vs.get_var_in_ref(regions)
+    vs.set_option("share_lists", 1)
+    p_slots, p_arena, p_lists, p_shared = private.layout()
+    assert not p_shared and p_lists == p_slots == slots and p_arena > 2 * arena
+    assert private.digest() == shared.digest() and private.totals() == shared.totals()
+    va, vb = shared.view(True), private.view(True)
+    for k in va:
+        assert np.array_equal(va[k], vb[k]), k
+    # not sorted: private lists, same answers
+    perm = rng.permutation(len(regions))
+    mixed = vs.get_var_in_ref([regions[i] for i in perm])
+    assert not mixed.layout()[3]
+    for j in (0, 1, 17, 250, 499):
+        assert mixed.region_text(j) == shared.region_text(int(perm[j]))
+    # duplicates of one region, regions without sites in between, one region swallowing many others
+    odd = sorted([(1, ref_len)] * 3 + regions[::7] + [(ref_len + 5, ref_len + 9), (0, 5)] + [(40, 41)] * 70)
+    a = vs.get_var_in_ref(odd)
+    assert a.layout()[3]
+    for q, (x, y) in enumerate(odd):
+        n, _, text = orc.get_var_in_ref(x, y) if x >= 1 else (-1, None, None)
+        if n >= 0:
+            assert a.region_text(q) == text, (q, x, y)

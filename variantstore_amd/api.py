@@ -85,6 +85,12 @@ class QueryResult:
         raw = C.string_at(C.cast(chars, C.c_void_p).value, int(b[q])) if q else b""
         return flags, [raw[int(b[i]):int(b[i + 1])].decode("latin-1") for i in range(q)]
 
+    def layout(self):
+        """(variant slots, arena entries, carrier lists expanded, lists shared between regions?) of the result in HBM."""
+        a, s, u, sh = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(self._lib.vs_result_layout(self._h, C.byref(a), C.byref(s), C.byref(u), C.byref(sh)), "vs_result_layout")
+        return int(a.value), int(s.value), int(u.value), bool(sh.value)
+
     def digest(self):
         d = C.c_uint64()
         _check(self._lib.vs_result_digest(self._h, C.byref(d)), "vs_result_digest")

@@ -61,6 +61,7 @@ struct EngineOpts {
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
   bool t4_coop = true;          // type 4: 16 lanes per region, episodes in parallel (k_sample_walk_coop); false: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
+  bool share_lists = true;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
@@ -120,6 +121,9 @@ struct vs_result {
   std::vector<uint32_t> slice_carriers;
   // per-region arrays alone (flags, slot and arena offsets, counts): all that totals and single-region formatting need
   bool have_meta = false;
+  bool shared_lists = false;          // carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
+  uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the slots
+  std::vector<uint64_t> h_car_len;
   // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
   std::vector<uint64_t> sl_pos, sl_car_begin;
   std::vector<uint32_t> sl_ref_off, sl_ref_len, sl_alt_off, sl_alt_len, sl_vflags, sl_car_count;
@@ -420,6 +424,7 @@ static void read_env_opts(vs_index* idx) {
   o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
+  if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = false;
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 }
@@ -555,11 +560,46 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
   uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
+  // Shared carrier lists (kernels.hip.h: k_share_*): a sorted type-6 batch expands every site it covers once and lets
+  // all regions that report the site point at that one list.  Not for batches the latency path would take anyway.
+  bool share = !t4 && !point_mode && idx->opts.share_lists && n > 64;
+  uint32_t* sh_new_start = nullptr;
+  uint64_t *sh_u_begin = nullptr, *sh_arena_new = nullptr;
+  uint64_t n_unique = 0;
+  if (share) {
+    const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
+    ShareMax* tile_max = nullptr;
+    Scan3* tile_sums = nullptr;
+    uint32_t *e_prev = nullptr, *status = nullptr;
+    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan3), (void**)&tile_sums, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 4, (void**)&sh_new_start, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_u_begin, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_arena_new, &scratch.bufs));
+    VS_TRY(ralloc(r, n, &d.q_car_len));
+    HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
+    hipLaunchKernelGGL(k_share_tile_max, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, d, tile_max);
+    hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
+    hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
+    hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status);
+    hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan3*)tile_sums,
+                       sh_new_start, sh_u_begin, sh_arena_new, d.q_car_len);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    totals[0] = ((volatile uint64_t*)pin_totals)[0];
+    totals[1] = ((volatile uint64_t*)pin_totals)[1];
+    n_unique = ((volatile uint64_t*)pin_totals)[2];
+    if (((volatile uint64_t*)pin_totals)[3]) { share = false; d.q_car_len = nullptr; }   // not sorted by first site: private lists
+  }
+  if (!share) {
   VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   totals[0] = ((volatile uint64_t*)pin_totals)[0];
   totals[1] = ((volatile uint64_t*)pin_totals)[1];
+  }
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
@@ -580,8 +620,12 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   VS_TRY(ralloc(r, d.A, &d.r_car_count));
   VS_TRY(ralloc(r, d.A, &d.r_region));
   VS_TRY(ralloc(r, d.A, &d.r_car_begin));
-  VS_TRY(ralloc(r, d.A, &d.r_class));
-  VS_TRY(ralloc(r, d.A, &d.r_gt0));
+  if (!share) {   // slot parameters of k_fill_carriers (shared lists are expanded from the site table)
+    VS_TRY(ralloc(r, d.A, &d.r_class));
+    VS_TRY(ralloc(r, d.A, &d.r_gt0));
+  }
+  r->shared_lists = share;
+  r->n_unique_sites = share ? n_unique : d.A;
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
   {
     uint8_t* arena = nullptr;
@@ -595,7 +639,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
-      hipLaunchKernelGGL(k_emit_headers, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
       if (strings) {
         uint8_t* dchars = nullptr;
@@ -612,15 +657,25 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
-  if (d.A) {
+  const uint64_t n_fill = share ? n_unique : d.A;   // variant slots resp. unique sites to expand
+  uint32_t* u_site = nullptr;
+  uint64_t* u_cb = nullptr;
+  if (share && n_unique) {
+    VS_TRY(dev_alloc(idx, n_unique * 4, (void**)&u_site, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n_unique * 8, (void**)&u_cb, &scratch.bufs));
+    hipLaunchKernelGGL(k_unique_sites, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start,
+                       (const uint64_t*)sh_u_begin, (const uint64_t*)sh_arena_new, u_site, u_cb);
+    HIP_TRY(hipGetLastError());
+  }
+  if (n_fill) {
     {
       // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
       // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time).
       // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
       // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
       uint32_t chunk = idx->opts.fill_chunk;
-      if (chunk == 0) chunk = (d.A < 64ull * 8192 * 8 && d.S / d.A >= 256) ? 16 : 64;
-      const uint64_t nchunks = (d.A + chunk - 1) / chunk;
+      if (chunk == 0) chunk = (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256) ? 16 : 64;
+      const uint64_t nchunks = (n_fill + chunk - 1) / chunk;
       const uint64_t blocks = (nchunks + 3) / 4;
       if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
       // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
@@ -634,6 +689,16 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint32_t ablate = 0;
       constexpr bool kTune = false;
 #endif
+      if (share) {
+        if (idx->d.wpc <= 63 && chunk == 64)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+        else if (idx->d.wpc <= 63)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+        else if (chunk == 64)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+        else
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+      } else
       if (idx->d.wpc <= 63 && chunk == 64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
       else if (idx->d.wpc <= 63)
@@ -654,7 +719,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
   HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
   HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
-  t.fill_launches = d.A ? 1 : 0;
+  t.fill_launches = n_fill ? 1 : 0;
   return VS_OK;
 }
 
@@ -696,7 +761,12 @@ static int fetch_region_meta(vs_result* r) {
   VS_TRY(fetch(idx, r->h_var_begin, (const uint64_t*)d.var_begin, d.Q + 1));
   VS_TRY(fetch(idx, r->h_car_base, (const uint64_t*)d.car_base, d.Q + 1));
   VS_TRY(fetch(idx, r->h_var_count, (const uint64_t*)d.var_count, d.Q));
+  if (d.q_car_len) VS_TRY(fetch(idx, r->h_car_len, (const uint64_t*)d.q_car_len, d.Q));
   HIP_TRY(hipStreamSynchronize(idx->stream));
+  if (!d.q_car_len) {
+    r->h_car_len.resize(d.Q);
+    for (uint64_t q = 0; q < d.Q; ++q) r->h_car_len[q] = r->h_car_base[q + 1] - r->h_car_base[q];
+  }
   for (auto& f : r->h_flags) f &= (uint8_t)~kRegionSlow;
   r->have_meta = true;
   return VS_OK;
@@ -1234,6 +1304,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
   else if (k == "t4_skip") o.t4_skip = value != 0;
   else if (k == "t4_coop") o.t4_coop = value != 0;
+  else if (k == "share_lists") o.share_lists = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 16 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 16 or 64");
     o.fill_chunk = (uint32_t)value;
@@ -1557,7 +1628,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   if (q >= r->d.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
   vs_index* idx = r->idx;
   const uint64_t a0 = r->h_var_begin[q], a1 = r->h_var_begin[q + 1];
-  const uint64_t c0 = r->h_car_base[q], c1 = r->h_car_base[q + 1];
+  const uint64_t c0 = r->h_car_base[q], c1 = c0 + r->h_car_len[q];
   const uint32_t* car = nullptr;
   const bool from_view = r->have_carriers;
   // the rows: the whole table when a view has already brought it over, otherwise this region's slice of it
@@ -1634,6 +1705,16 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   }
   *text = out.c_str();
   if (len) *len = out.size();
+  return VS_OK;
+}
+
+int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared) {
+  if (!r) return fail(VS_ERR_ARG, "null argument");
+  VS_NOT_SEQ(r);
+  if (n_slots) *n_slots = r->d.A;
+  if (arena_entries) *arena_entries = r->d.S;
+  if (lists_expanded) *lists_expanded = r->n_unique_sites;
+  if (shared) *shared = r->shared_lists ? 1 : 0;
   return VS_OK;
 }
 

@@ -115,7 +115,8 @@ struct DevResult {
   uint64_t* q_ncar;         // [Q] arena entries of the region (padded counts) until the offsets are scanned; afterwards the
                             //     header kernels overwrite it with the carriers of the region's REPORTED variants
   uint64_t* var_begin;      // [Q+1]
-  uint64_t* car_base;       // [Q+1]
+  uint64_t* car_base;       // [Q+1] arena offset of each region's first site; with shared carrier lists NOT monotone ([Q] = arena entries used)
+  uint64_t* q_car_len;      // [Q] shared carrier lists only: the region's padded arena extent (else NULL: car_base[q + 1] - car_base[q])
   uint64_t* var_count;      // [Q]
   uint64_t* r_pos;
   uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_region;
@@ -469,6 +470,9 @@ __global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const uint64_t* nvar
 // ---------------------------------------------------------------------------
 // Variant headers: one wave per region, lanes stride the region's site range.
 // ---------------------------------------------------------------------------
+// PARAMS: also write the per-slot parameters k_fill_carriers reads (source handle, genotype offset); a batch whose
+// carrier lists are shared between regions (k_fill_sites) expands straight from the site table and needs none.
+template <bool PARAMS>
 __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult& r, uint64_t q, uint32_t lane) {
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
   const uint32_t g0 = r.q_g0[q];
@@ -488,17 +492,199 @@ __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult&
     r.r_car_begin[a] = cb + (im.s_carpre[g] - pre0);
     r.r_car_count[a] = im.s_ncar[g];
     r.r_region[a] = (uint32_t)q;
-    r.r_class[a] = im.s_class[g];
-    r.r_gt0[a] = im.s_gt0[g];
+    if (PARAMS) {
+      r.r_class[a] = im.s_class[g];
+      r.r_gt0[a] = im.s_gt0[g];
+    }
   }
   kept = wave_inclusive_scan(kept);
   if (lane == 63 && !(r.q_flags[q] & kRegionSlow)) { r.var_count[q] = n; r.q_ncar[q] = kept; }
 }
 
+template <bool PARAMS>
 __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
-  emit_region(im, r, q, threadIdx.x & 63);
+  emit_region<PARAMS>(im, r, q, threadIdx.x & 63);
+}
+
+// ---------------------------------------------------------------------------
+// Shared carrier lists.  The regions of a batch arrive sorted (the reference's driver sorts them, commands.cc:91) and
+// overlap -- 100 k regions of 10 kb cover chr1 four times over -- so most sites are reported by several regions of the
+// same batch.  A site's carrier list is then expanded ONCE into the arena and every region that reports the site
+// points its row at it (the way REF / ALT strings are (offset, length) references into the sequence pool):
+//   E_prev[q]   = largest site end among the regions before q         (exclusive prefix max)
+//   new part    = [max(g0, E_prev), g1): the sites no earlier region covers -- the part of the arena region q OWNS
+//   arena_new   = exclusive prefix sum of the new parts' padded carrier counts: where the new part starts
+//   car_base[q] = arena position of site g0 = arena_new[q] - (carpre[E_prev] - carpre[g0]) when g0 lies in covered
+//                 ground (sites [g0, E_prev) are contiguous there: the region that reached E_prev starts at or before g0)
+// so a row's carrier offset keeps its form car_base[q] + carpre[g] - carpre[g0].  Needs g0 ascending over the
+// regions with any site; a batch that is not reports so (status) and takes the private-list path.
+// ---------------------------------------------------------------------------
+struct ShareMax { uint32_t g1, g0; };
+__device__ __forceinline__ ShareMax smax(ShareMax a, ShareMax b) { return ShareMax{a.g1 > b.g1 ? a.g1 : b.g1, a.g0 > b.g0 ? a.g0 : b.g0}; }
+__device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* total) {
+  __shared__ ShareMax wmx[kScanBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  ShareMax incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a = __shfl_up(incl.g1, d, 64), b = __shfl_up(incl.g0, d, 64);
+    if (lane >= d) incl = smax(incl, ShareMax{a, b});
+  }
+  if (lane == 63) wmx[wid] = incl;
+  __syncthreads();
+  ShareMax woff{0, 0}, tot{0, 0};
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    if (w < wid) woff = smax(woff, wmx[w]);
+    tot = smax(tot, wmx[w]);
+  }
+  __syncthreads();
+  *total = tot;
+  const uint32_t pa = __shfl_up(incl.g1, 1, 64), pb = __shfl_up(incl.g0, 1, 64);
+  return lane ? smax(woff, ShareMax{pa, pb}) : woff;
+}
+__device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {   // {end, start} of a region's site range; {0, 0} without sites
+  const uint32_t nv = (uint32_t)r.q_nvar[q];
+  return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q]} : ShareMax{0, 0};
+}
+__global__ void __launch_bounds__(kScanBlock) k_share_tile_max(DevResult r, ShareMax* tile_max) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  ShareMax m{0, 0};
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < r.Q) m = smax(m, share_elem(r, base + i));
+  ShareMax tot;
+  block_exclusive_max(m, &tot);
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(kScanBlock) k_share_spine_max(ShareMax* tile_max, uint64_t ntiles) {   // exclusive prefix max, in place
+  ShareMax carry{0, 0};
+  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const ShareMax v = i < ntiles ? tile_max[i] : ShareMax{0, 0};
+    ShareMax tot;
+    const ShareMax ex = block_exclusive_max(v, &tot);
+    if (i < ntiles) tile_max[i] = smax(carry, ex);
+    carry = smax(carry, tot);
+  }
+}
+struct Scan3 { uint64_t a, u, c; };   // slots, unique (newly covered) sites, arena entries of the new parts
+__device__ __forceinline__ Scan3 block_exclusive_scan3(Scan3 v, Scan3* total) {
+  __shared__ Scan3 wsum[kScanBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  Scan3 incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t ta = __shfl_up(incl.a, d, 64), tu = __shfl_up(incl.u, d, 64), tc = __shfl_up(incl.c, d, 64);
+    if (lane >= d) { incl.a += ta; incl.u += tu; incl.c += tc; }
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  Scan3 woff{0, 0, 0}, tot{0, 0, 0};
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    if (w < wid) { woff.a += wsum[w].a; woff.u += wsum[w].u; woff.c += wsum[w].c; }
+    tot.a += wsum[w].a; tot.u += wsum[w].u; tot.c += wsum[w].c;
+  }
+  __syncthreads();
+  *total = tot;
+  return Scan3{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c};
+}
+// what region q adds to the batch, given the largest site end before it
+struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back; };
+__device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, uint32_t nv, uint32_t e_prev) {
+  ShareNew o{g0, 0, 0, 0};
+  if (!nv) return o;
+  const uint32_t g1 = g0 + nv;
+  o.ns = e_prev > g0 ? (e_prev < g1 ? e_prev : g1) : g0;
+  o.n_new = g1 - o.ns;
+  const uint64_t c0 = im.s_carpre[g0];
+  o.arena_new = im.s_carpre[g1] - im.s_carpre[o.ns];
+  o.back = e_prev > g0 ? im.s_carpre[e_prev] - c0 : 0;   // arena distance from site g0 to where the covered ground ends
+  return o;
+}
+// per element: E_prev (kept for the last pass) and the tile sums of {slots, new sites, new arena entries}
+__global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t* e_prev, Scan3* tile_sums,
+                                                         uint32_t* status) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  ShareMax loc[kScanItems], m{0, 0};
+  for (int i = 0; i < kScanItems; ++i) {
+    loc[i] = base + i < r.Q ? share_elem(r, base + i) : ShareMax{0, 0};
+    m = smax(m, loc[i]);
+  }
+  ShareMax tot;
+  ShareMax ex = smax(block_exclusive_max(m, &tot), tile_max[blockIdx.x]);
+  Scan3 s{0, 0, 0};
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < r.Q) {
+      const uint32_t nv = (uint32_t)r.q_nvar[base + i];
+      if (nv && loc[i].g0 < ex.g0) *status = 1;          // a region that starts before an earlier one: not sorted
+      e_prev[base + i] = ex.g1;
+      const ShareNew w = share_new(im, loc[i].g0, nv, ex.g1);
+      s.a += nv; s.u += w.n_new; s.c += w.arena_new;
+    }
+    ex = smax(ex, loc[i]);
+  }
+  Scan3 t3;
+  block_exclusive_scan3(s, &t3);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = t3;
+}
+__global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan3* tile_sums, uint64_t ntiles, DevResult r, uint64_t* u_begin, uint64_t* totals,
+                                                               const uint32_t* status) {
+  Scan3 carry{0, 0, 0};
+  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const Scan3 v = i < ntiles ? tile_sums[i] : Scan3{0, 0, 0};
+    Scan3 tot;
+    const Scan3 ex = block_exclusive_scan3(v, &tot);
+    if (i < ntiles) tile_sums[i] = Scan3{carry.a + ex.a, carry.u + ex.u, carry.c + ex.c};
+    carry.a += tot.a; carry.u += tot.u; carry.c += tot.c;
+  }
+  if (threadIdx.x == 0) {
+    r.var_begin[r.Q] = carry.a; r.car_base[r.Q] = carry.c; u_begin[r.Q] = carry.u;
+    totals[0] = carry.a; totals[1] = carry.c; totals[2] = carry.u; totals[3] = *status;
+  }
+}
+__global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan3* tile_sums, uint32_t* new_start,
+                                                           uint64_t* u_begin, uint64_t* arena_new, uint64_t* q_car_len) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  ShareNew loc[kScanItems];
+  uint32_t nvs[kScanItems];
+  Scan3 s{0, 0, 0};
+  for (int i = 0; i < kScanItems; ++i) {
+    loc[i] = ShareNew{0, 0, 0, 0}; nvs[i] = 0;
+    if (base + i < r.Q) {
+      nvs[i] = (uint32_t)r.q_nvar[base + i];
+      loc[i] = share_new(im, r.q_g0[base + i], nvs[i], e_prev[base + i]);
+      s.a += nvs[i]; s.u += loc[i].n_new; s.c += loc[i].arena_new;
+    }
+  }
+  Scan3 tot;
+  Scan3 ex = block_exclusive_scan3(s, &tot);
+  const Scan3 ts = tile_sums[blockIdx.x];
+  ex.a += ts.a; ex.u += ts.u; ex.c += ts.c;
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < r.Q) {
+      const uint64_t q = base + i;
+      r.var_begin[q] = ex.a; u_begin[q] = ex.u; arena_new[q] = ex.c; new_start[q] = loc[i].ns;
+      r.car_base[q] = ex.c - loc[i].back;
+      q_car_len[q] = r.q_ncar[q];                    // the region's own padded arena extent (q_ncar is overwritten by the header kernels)
+    }
+    ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new;
+  }
+}
+// the owned sites of every region, in arena order: site index and arena offset per unique site (one wave per region)
+__global__ void __launch_bounds__(256) k_unique_sites(DevImage im, DevResult r, const uint32_t* new_start, const uint64_t* u_begin, const uint64_t* arena_new,
+                                                      uint32_t* u_site, uint64_t* u_cb) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t u0 = u_begin[q], n_new = u_begin[q + 1] - u0;
+  if (!n_new) return;
+  const uint32_t ns = new_start[q];
+  const uint64_t cb0 = arena_new[q], pre = im.s_carpre[ns];
+  for (uint64_t j = lane; j < n_new; j += 64) {
+    const uint32_t g = ns + (uint32_t)j;
+    u_site[u0 + j] = g;
+    u_cb[u0 + j] = cb0 + (im.s_carpre[g] - pre);
+  }
 }
 
 // The reference's "only add var if not seen before" rule (query.h:397-414),
@@ -1080,6 +1266,31 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       cb = __builtin_nontemporal_load(&r.r_car_begin[a]);
     }
     expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+  }
+}
+
+// The same expansion over the UNIQUE sites of a batch whose carrier lists are shared: the slot parameters come straight
+// from the site table (sequential reads, each site once), the arena offset from k_unique_sites.
+template <bool WIDE, uint32_t CH, bool TUNE>
+__global__ void __launch_bounds__(256) k_fill_sites(DevImage im, void* arena, const uint32_t* u_site, const uint64_t* u_cb, uint64_t U,
+                                                    uint32_t ablate, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nchunks = (U + CH - 1) / CH;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  if (wave < nchunks) {
+    const uint64_t u = wave * CH + lane;
+    uint32_t cnt = 0, cls = 0;
+    uint64_t gt0 = 0, cb = 0;
+    if (u < U && lane < CH) {
+      const uint32_t g = __builtin_nontemporal_load(&u_site[u]);
+      cb = __builtin_nontemporal_load(&u_cb[u]);
+      cnt = im.s_ncar[g];
+      cls = im.s_class[g];
+      gt0 = im.s_gt0[g];
+    }
+    expand_task<WIDE, false, TUNE>(im, arena, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
