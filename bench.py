@@ -47,6 +47,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FILL_SLOT_BYTES = 24    # slot parameters k_fill_carriers reads per variant slot: count 4, source handle 4, genotype offset 8, arena offset 8
+FILL_SITE_BYTES = 28    # shared lists (k_fill_sites), per unique site: site index 4 + arena offset 8, then count 4, source handle 4, genotype offset 8 from the site table
 
 
 def make_regions(w, rank, n):
@@ -350,8 +351,16 @@ def main():
         id_bytes = int((padded[listed] * car_word).sum()) + int((~listed).sum()) * W   # list entries are as wide as carrier words
     else:  # explicit sample ids: 4 B per carrier record, read in whole groups of 8
         id_bytes = int(4 * padded.sum())
-    n_slots = res.num_header_records()
-    fill_bytes_layout = n_slots * FILL_SLOT_BYTES + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
+    n_slots, arena_entries, lists_expanded, lists_shared = res.layout()
+    if lists_shared:
+        # every covered site is expanded once (k_fill_sites) and the regions reporting it share the list: the reads scale
+        # with the lists actually expanded (the slots of a random batch are ~uniform copies of the covered sites), the
+        # writes are the arena entries in use, exactly
+        f = lists_expanded / max(len(cc), 1)
+        fill_bytes_layout = int(lists_expanded * FILL_SITE_BYTES + f * (id_bytes + (ncar + 1) // 2)) + car_word * arena_entries
+    else:
+        fill_bytes_layout = n_slots * FILL_SLOT_BYTES + id_bytes + (ncar + 1) // 2 + car_word * int(padded.sum())
+    fill_kernel = "k_fill_sites" if lists_shared else "k_fill_carriers"
     # SURVEY.md section 8(d)'s implementation-independent formula, restricted to the terms this kernel owns: per
     # variant its class row (W) + car_begin word (8), per carrier 3 genotype bits in and 4 + 1 bytes out.  It prices
     # bytes this layout never moves (5 B per carrier written where the arena holds 2), so it is reported for
@@ -364,7 +373,7 @@ def main():
     # roofline.achieved: what crossed the HBM pins per launch (PMC counters of THESE kernels, committed under
     # profiles/) over the launch time measured live here; without matching counters, the layout bytes.
     tj = committed_traffic(args.workload, (not strong) and nreg == w["regions"])
-    traffic = tj["kernels"]["k_fill_carriers"]["traffic_bytes_per_launch"] if tj else None
+    traffic = tj["kernels"][fill_kernel]["traffic_bytes_per_launch"] if tj and fill_kernel in tj["kernels"] else None
     if traffic and fill_s > 0:
         achieved, basis = traffic / fill_s / 1e9, "pmc_traffic"
     else:
@@ -409,7 +418,7 @@ def main():
         torch.cuda.synchronize()
         t4 = {"queries_per_s": 5 * nreg / (time.perf_counter() - a4), "regions_per_batch": nreg, "samples": 16,
               "variants_per_region": nv4 / nreg, "carriers_per_variant": nc4 / max(nv4, 1), "walk_phase_ms": walk_ms / 5}
-        tw = tj["kernels"].get("k_sample_walk") if tj else None
+        tw = (tj["kernels"].get("k_sample_walk_coop") or tj["kernels"].get("k_sample_walk")) if tj else None
         if tw and walk_ms > 0:   # the walk kernel's own pin traffic (PMC) over the walk phase (capacity bounds + scan + walk) timed here
             t4["walk_traffic_bytes"] = tw["traffic_bytes_per_launch"]
             t4["walk_traffic_GBps"] = tw["traffic_bytes_per_launch"] / (walk_ms / 5 * 1e-3) / 1e9
@@ -504,6 +513,10 @@ def main():
                             + (" [regions handed over as a host array in every step]" if host_regions else ""),
                 "regions_per_gpu": nreg, "regions_total": total_regions, "region_len": w["region_len"],
                 "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
+                "result_layout": {"variant_rows": n_slots, "carrier_lists_expanded": lists_expanded, "arena_entries": arena_entries,
+                                  "lists_shared_between_regions": lists_shared,
+                                  "note": "a sorted batch expands every site it covers once; the regions that report the site share the list "
+                                          "(rows hold the reference, as they do for REF/ALT into the sequence pool)" if lists_shared else None},
                 "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,
@@ -513,7 +526,7 @@ def main():
             # command on THESE kernels, profiles/traffic_<workload>.json; FETCH_SIZE corrected per MI355X_MICROARCH.md) /
             # the kernel's mean launch time measured live here with HIP events on the engine's stream.  When the tree's
             # kernels are not the profiled ones, traffic is null and achieved falls back to the layout bytes (basis says which).
-            "roofline": {"bound": "hbm", "kernel": "k_fill_carriers", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": fill_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "avg_launch_ms": fill_ms / args.steps,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
@@ -524,7 +537,7 @@ def main():
                                                     "the arena holds 2 -- a time-per-algorithmic-unit figure, not pin traffic"},
                          "emit_kernel_ms": emit_ms / args.steps,
                          "pipeline_ms": tot_ms / args.steps,
-                         "other_kernels": ({k: v for k, v in tj["kernels"].items() if k != "k_fill_carriers"} if tj else None),
+                         "other_kernels": ({k: v for k, v in tj["kernels"].items() if k != fill_kernel} if tj else None),
                          "kernels_blob": git_blob_hash(KERNEL_SOURCE)},
             "p50_latency_us": p50,
             "p50_latency_paced_1ms_us": p50_paced,
