@@ -351,7 +351,7 @@ def main():
         id_bytes = int((padded[listed] * car_word).sum()) + int((~listed).sum()) * W   # list entries are as wide as carrier words
     else:  # explicit sample ids: 4 B per carrier record, read in whole groups of 8
         id_bytes = int(4 * padded.sum())
-    n_slots, arena_entries, lists_expanded, lists_shared = res.layout()
+    n_slots, table_rows, arena_entries, lists_expanded, lists_shared = res.layout()
     if lists_shared:
         # every covered site is expanded once (k_fill_sites) and the regions reporting it share the list: the reads scale
         # with the lists actually expanded (the slots of a random batch are ~uniform copies of the covered sites), the
@@ -513,10 +513,11 @@ def main():
                             + (" [regions handed over as a host array in every step]" if host_regions else ""),
                 "regions_per_gpu": nreg, "regions_total": total_regions, "region_len": w["region_len"],
                 "variants_per_region": nvar / max(nq, 1), "carriers_per_variant": ncar / max(nvar, 1),
-                "result_layout": {"variant_rows": n_slots, "carrier_lists_expanded": lists_expanded, "arena_entries": arena_entries,
-                                  "lists_shared_between_regions": lists_shared,
-                                  "note": "a sorted batch expands every site it covers once; the regions that report the site share the list "
-                                          "(rows hold the reference, as they do for REF/ALT into the sequence pool)" if lists_shared else None},
+                "result_layout": {"rows_reported": n_slots, "variant_table_rows": table_rows, "carrier_lists_expanded": lists_expanded,
+                                  "arena_entries": arena_entries, "shared_between_regions": lists_shared,
+                                  "note": "a sorted batch holds one row and one carrier list per site it covers; every region reporting the "
+                                          "site refers to them (its rows are a range of the shared table), as REF/ALT refer to the sequence "
+                                          "pool" if lists_shared else None},
                 "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,

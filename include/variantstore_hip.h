@@ -201,11 +201,13 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view);
 /* Totals without any copy of the arrays. */
 int vs_result_totals(const vs_result* r, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers,
                      uint64_t* n_bases);
-/* How the result lies in HBM: variant slots, arena entries in use (padded to groups of 8), carrier lists actually
- * expanded, and whether lists are SHARED: a sorted type-6 batch of overlapping regions expands every site it covers once
- * and all regions reporting that site point at the one list (car_begin of their rows) -- like REF / ALT, which are
- * references into the sequence pool.  Views and texts are unaffected. */
-int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared);
+/* How the result lies in HBM: rows the regions report in total, rows of the variant table, arena entries in use (lists
+ * padded to groups of 8), carrier lists actually expanded, and whether rows and lists are SHARED: a sorted type-6 batch
+ * of overlapping regions holds one row and one carrier list per site it covers, and every region reporting the site
+ * refers to them (its rows are a range of the shared table) -- the way REF / ALT are references into the sequence
+ * pool.  Views, texts, digests and totals are per region and unaffected. */
+int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows, uint64_t* arena_entries, uint64_t* lists_expanded,
+                     int* shared);
 /* The `-o` file of region q (print_header + print_var, query.h:38-50) as text owned by the result. */
 int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len);
 /* Order-independent 64-bit digest of (region, pos, ref, alt, carriers) computed

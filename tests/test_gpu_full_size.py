@@ -170,8 +170,8 @@ def test_shared_and_private_carrier_lists_agree_at_full_size(big):
     sorted batch) against a private copy per region -- same digest, totals and rows; a quarter of the lists."""
     vs, regions = big
     shared = vs.get_var_in_ref(regions)
-    slots, arena, lists, is_shared = shared.layout()
-    assert is_shared and slots > 15_000_000 and lists < 5_100_000 and lists > 4_000_000
+    slots, table, arena, lists, is_shared = shared.layout()
+    assert is_shared and slots > 15_000_000 and 4_000_000 < lists <= table < 5_100_000
     ts, ds = shared.totals(), shared.digest()
     texts = {q: shared.region_text(q) for q in (0, 7, 55_555, 99_999)}
     shared.close()
@@ -180,8 +180,8 @@ def test_shared_and_private_carrier_lists_agree_at_full_size(big):
         private = vs.get_var_in_ref(regions)
     finally:
         vs.set_option("share_lists", 1)
-    p_slots, p_arena, p_lists, p_shared = private.layout()
-    assert not p_shared and p_slots == slots and p_lists == slots and p_arena > 3 * arena
+    p_slots, p_table, p_arena, p_lists, p_shared = private.layout()
+    assert not p_shared and p_slots == p_table == p_lists == slots and p_arena > 3 * arena
     assert (private.totals(), private.digest()) == (ts, ds)
     for q, text in texts.items():
         assert private.region_text(q) == text

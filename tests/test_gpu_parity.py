@@ -786,8 +786,8 @@ def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
     ref_len = vs.info().ref_length
     regions = sorted(random_regions(rng, ref_len, 500, max_len=900))
     shared = vs.get_var_in_ref(regions)
-    slots, arena, lists, is_shared = shared.layout()
-    assert is_shared and lists < slots / 2 and arena > 0
+    slots, table, arena, lists, is_shared = shared.layout()
+    assert is_shared and lists < slots / 2 and arena > 0 and lists <= table   # (regions under the duplicate rule keep private rows: table = shared + private)
     want = oracle_texts(orc, regions)
     for q, (n, early, text) in enumerate(want):
         if n >= 0:
@@ -795,8 +795,8 @@ def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
     vs.set_option("share_lists", 0)
     private = vs.get_var_in_ref(regions)
     vs.set_option("share_lists", 1)
-    p_slots, p_arena, p_lists, p_shared = private.layout()
-    assert not p_shared and p_lists == p_slots == slots and p_arena > 2 * arena
+    p_slots, p_table, p_arena, p_lists, p_shared = private.layout()
+    assert not p_shared and p_lists == p_table == p_slots == slots and p_arena > 2 * arena
     assert private.digest() == shared.digest() and private.totals() == shared.totals()
     va, vb = shared.view(True), private.view(True)
     for k in va:
@@ -804,13 +804,13 @@ def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
     # not sorted: private lists, same answers
     perm = rng.permutation(len(regions))
     mixed = vs.get_var_in_ref([regions[i] for i in perm])
-    assert not mixed.layout()[3]
+    assert not mixed.layout()[4]
     for j in (0, 1, 17, 250, 499):
         assert mixed.region_text(j) == shared.region_text(int(perm[j]))
     # duplicates of one region, regions without sites in between, one region swallowing many others
     odd = sorted([(1, ref_len)] * 3 + regions[::7] + [(ref_len + 5, ref_len + 9), (0, 5)] + [(40, 41)] * 70)
     a = vs.get_var_in_ref(odd)
-    assert a.layout()[3]
+    assert a.layout()[4]
     for q, (x, y) in enumerate(odd):
         n, _, text = orc.get_var_in_ref(x, y) if x >= 1 else (-1, None, None)
         if n >= 0:

@@ -86,10 +86,11 @@ class QueryResult:
         return flags, [raw[int(b[i]):int(b[i + 1])].decode("latin-1") for i in range(q)]
 
     def layout(self):
-        """(variant slots, arena entries, carrier lists expanded, lists shared between regions?) of the result in HBM."""
-        a, s, u, sh = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
-        _check(self._lib.vs_result_layout(self._h, C.byref(a), C.byref(s), C.byref(u), C.byref(sh)), "vs_result_layout")
-        return int(a.value), int(s.value), int(u.value), bool(sh.value)
+        """(rows reported over all regions, rows of the variant table, arena entries, carrier lists expanded, rows and lists
+        shared between regions?) of the result in HBM."""
+        n, t, s, u, sh = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(self._lib.vs_result_layout(self._h, C.byref(n), C.byref(t), C.byref(s), C.byref(u), C.byref(sh)), "vs_result_layout")
+        return int(n.value), int(t.value), int(s.value), int(u.value), bool(sh.value)
 
     def digest(self):
         d = C.c_uint64()

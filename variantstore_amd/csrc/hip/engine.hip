@@ -112,8 +112,10 @@ struct vs_result {
   // host copies
   bool have_headers = false, have_carriers = false;
   std::vector<uint8_t> h_flags;
-  std::vector<uint64_t> h_var_begin, h_var_count, h_car_base, h_pos, h_car_begin;   // h_car_begin: arena (padded) offsets
-  std::vector<uint64_t> h_car_begin_view;   // what views hand out: carrier lists back to back
+  std::vector<uint64_t> h_var_begin, h_nvar, h_var_count, h_car_base;   // per region: first table row, rows, variants reported, arena offset
+  std::vector<VariantRow> h_rows;           // the variant table as it lies in HBM (rows may be shared between regions)
+  // the host VIEW: every region's rows expanded back to back (slot = region-major row), carrier lists back to back
+  std::vector<uint64_t> h_view_begin, h_pos, h_car_begin, h_car_begin_view;   // h_car_begin: arena offsets per slot
   std::vector<uint32_t> h_ref_off, h_ref_len, h_alt_off, h_alt_len, h_vflags, h_car_count, h_carriers;
   uint64_t n_variants = 0, n_carriers_kept = 0, n_bases = 0, n_view_carriers = 0;
   bool have_totals = false;
@@ -121,12 +123,12 @@ struct vs_result {
   std::vector<uint32_t> slice_carriers;
   // per-region arrays alone (flags, slot and arena offsets, counts): all that totals and single-region formatting need
   bool have_meta = false;
-  bool shared_lists = false;          // carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
-  uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the slots
+  bool shared_lists = false;          // rows and carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
+  uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the rows
+  uint64_t n_rows_reported = 0;       // rows over all regions (shared rows counted once per region that reports them)
   std::vector<uint64_t> h_car_len;
   // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
-  std::vector<uint64_t> sl_pos, sl_car_begin;
-  std::vector<uint32_t> sl_ref_off, sl_ref_len, sl_alt_off, sl_alt_len, sl_vflags, sl_car_count;
+  std::vector<VariantRow> sl_rows;
   int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line); 2 / 3: sequences
   // sequence results (query types 2 and 3)
   DevSeqResult sq{};
@@ -569,10 +571,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (share) {
     const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
     ShareMax* tile_max = nullptr;
-    Scan3* tile_sums = nullptr;
+    Scan4* tile_sums = nullptr;
     uint32_t *e_prev = nullptr, *status = nullptr;
     VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan3), (void**)&tile_sums, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan4), (void**)&tile_sums, &scratch.bufs));
     VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
     VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
     VS_TRY(dev_alloc(idx, n * 4, (void**)&sh_new_start, &scratch.bufs));
@@ -584,14 +586,18 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
     hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
     hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status);
-    hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan3*)tile_sums,
-                       sh_new_start, sh_u_begin, sh_arena_new, d.q_car_len);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(idx->stream));
     totals[0] = ((volatile uint64_t*)pin_totals)[0];
     totals[1] = ((volatile uint64_t*)pin_totals)[1];
     n_unique = ((volatile uint64_t*)pin_totals)[2];
-    if (((volatile uint64_t*)pin_totals)[3]) { share = false; d.q_car_len = nullptr; }   // not sorted by first site: private lists
+    r->n_rows_reported = ((volatile uint64_t*)pin_totals)[4];
+    if (((volatile uint64_t*)pin_totals)[3]) { share = false; d.q_car_len = nullptr; }   // not sorted by first site: private rows and lists
+    else {   // (only now: it overwrites the per-region counts the private path scans)
+      hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan4*)tile_sums,
+                         sh_new_start, sh_u_begin, sh_arena_new);
+      HIP_TRY(hipGetLastError());
+    }
   }
   if (!share) {
   VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
@@ -611,18 +617,11 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   d.A = totals[0];
   d.S = totals[1];
-  VS_TRY(ralloc(r, d.A, &d.r_pos));
-  VS_TRY(ralloc(r, d.A, &d.r_ref_off));
-  VS_TRY(ralloc(r, d.A, &d.r_ref_len));
-  VS_TRY(ralloc(r, d.A, &d.r_alt_off));
-  VS_TRY(ralloc(r, d.A, &d.r_alt_len));
-  VS_TRY(ralloc(r, d.A, &d.r_flags));
-  VS_TRY(ralloc(r, d.A, &d.r_car_count));
-  VS_TRY(ralloc(r, d.A, &d.r_region));
-  VS_TRY(ralloc(r, d.A, &d.r_car_begin));
-  if (!share) {   // slot parameters of k_fill_carriers (shared lists are expanded from the site table)
+  VS_TRY(ralloc(r, d.A, &d.rows));
+  if (!share) {   // row parameters of k_fill_carriers (shared lists are expanded from the site table)
     VS_TRY(ralloc(r, d.A, &d.r_class));
     VS_TRY(ralloc(r, d.A, &d.r_gt0));
+    r->n_rows_reported = d.A;
   }
   r->shared_lists = share;
   r->n_unique_sites = share ? n_unique : d.A;
@@ -633,14 +632,18 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     d.carriers = arena;
   }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  uint32_t* u_site = nullptr;
   if (n) {
     if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
     else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
-      if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      if (share) {   // the shared rows (each covered site once) + the site index the expansion works from
+        VS_TRY(dev_alloc(idx, n_unique * 4 + 8, (void**)&u_site, &scratch.bufs));
+        hipLaunchKernelGGL(k_share_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start,
+                           (const uint64_t*)sh_u_begin, (const uint64_t*)sh_arena_new, u_site);
+      } else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
       if (strings) {
         uint8_t* dchars = nullptr;
@@ -657,16 +660,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
-  const uint64_t n_fill = share ? n_unique : d.A;   // variant slots resp. unique sites to expand
-  uint32_t* u_site = nullptr;
-  uint64_t* u_cb = nullptr;
-  if (share && n_unique) {
-    VS_TRY(dev_alloc(idx, n_unique * 4, (void**)&u_site, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, n_unique * 8, (void**)&u_cb, &scratch.bufs));
-    hipLaunchKernelGGL(k_unique_sites, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start,
-                       (const uint64_t*)sh_u_begin, (const uint64_t*)sh_arena_new, u_site, u_cb);
-    HIP_TRY(hipGetLastError());
-  }
+  const uint64_t n_fill = share ? n_unique : d.A;   // lists to expand: shared rows resp. all rows
   if (n_fill) {
     {
       // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
@@ -691,13 +685,13 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
 #endif
       if (share) {
         if (idx->d.wpc <= 63 && chunk == 64)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
         else if (idx->d.wpc <= 63)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
         else if (chunk == 64)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
         else
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d.carriers, (const uint32_t*)u_site, (const uint64_t*)u_cb, n_unique, ablate, gt_words);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
       } else
       if (idx->d.wpc <= 63 && chunk == 64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
@@ -761,6 +755,7 @@ static int fetch_region_meta(vs_result* r) {
   VS_TRY(fetch(idx, r->h_var_begin, (const uint64_t*)d.var_begin, d.Q + 1));
   VS_TRY(fetch(idx, r->h_car_base, (const uint64_t*)d.car_base, d.Q + 1));
   VS_TRY(fetch(idx, r->h_var_count, (const uint64_t*)d.var_count, d.Q));
+  VS_TRY(fetch(idx, r->h_nvar, (const uint64_t*)d.q_nvar, d.Q));
   if (d.q_car_len) VS_TRY(fetch(idx, r->h_car_len, (const uint64_t*)d.q_car_len, d.Q));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   if (!d.q_car_len) {
@@ -772,26 +767,34 @@ static int fetch_region_meta(vs_result* r) {
   return VS_OK;
 }
 
+// The whole variant table on the host, and the VIEW built from it: every region's rows expanded back to back (shared
+// rows once per region that reports them) as the structure-of-arrays vs_result_view promises.
 static int fetch_headers(vs_result* r) {
   if (r->have_headers) return VS_OK;
   vs_index* idx = r->idx;
   VS_TRY(fetch_region_meta(r));
   const DevResult& d = r->d;
-  VS_TRY(fetch(idx, r->h_pos, (const uint64_t*)d.r_pos, d.A));
-  VS_TRY(fetch(idx, r->h_ref_off, (const uint32_t*)d.r_ref_off, d.A));
-  VS_TRY(fetch(idx, r->h_ref_len, (const uint32_t*)d.r_ref_len, d.A));
-  VS_TRY(fetch(idx, r->h_alt_off, (const uint32_t*)d.r_alt_off, d.A));
-  VS_TRY(fetch(idx, r->h_alt_len, (const uint32_t*)d.r_alt_len, d.A));
-  VS_TRY(fetch(idx, r->h_vflags, (const uint32_t*)d.r_flags, d.A));
-  VS_TRY(fetch(idx, r->h_car_begin, (const uint64_t*)d.r_car_begin, d.A));
-  VS_TRY(fetch(idx, r->h_car_count, (const uint32_t*)d.r_car_count, d.A));
+  VS_TRY(fetch(idx, r->h_rows, (const VariantRow*)d.rows, d.A));
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  r->h_car_begin_view.resize(d.A);
-  {
-    uint64_t acc = 0;
-    for (uint64_t a = 0; a < d.A; ++a) { r->h_car_begin_view[a] = acc; acc += r->h_car_count[a]; }
-    r->n_view_carriers = acc;
+  r->h_view_begin.assign(d.Q + 1, 0);
+  for (uint64_t q = 0; q < d.Q; ++q) r->h_view_begin[q + 1] = r->h_view_begin[q] + r->h_nvar[q];
+  const uint64_t ns = r->h_view_begin[d.Q];
+  r->h_pos.resize(ns); r->h_car_begin.resize(ns); r->h_car_begin_view.resize(ns);
+  r->h_ref_off.resize(ns); r->h_ref_len.resize(ns); r->h_alt_off.resize(ns); r->h_alt_len.resize(ns);
+  r->h_vflags.resize(ns); r->h_car_count.resize(ns);
+  uint64_t acc = 0;
+  for (uint64_t q = 0; q < d.Q; ++q) {
+    const VariantRow* src = r->h_rows.data() + r->h_var_begin[q];
+    for (uint64_t j = 0, a = r->h_view_begin[q]; j < r->h_nvar[q]; ++j, ++a) {
+      const VariantRow& v = src[j];
+      const uint32_t cnt = v.count_flags & ~kRowDropped;
+      r->h_pos[a] = v.pos; r->h_ref_off[a] = v.ref_off; r->h_ref_len[a] = v.ref_len; r->h_alt_off[a] = v.alt_off; r->h_alt_len[a] = v.alt_len;
+      r->h_vflags[a] = (v.count_flags & kRowDropped) ? VS_VAR_DROPPED : 0u;
+      r->h_car_count[a] = cnt; r->h_car_begin[a] = v.car_begin;
+      r->h_car_begin_view[a] = acc; acc += cnt;
+    }
   }
+  r->n_view_carriers = acc;
   r->have_headers = true;
   return VS_OK;
 }
@@ -999,6 +1002,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     VS_TRY(ralloc(r, bytes, &slab));
     small_result_layout(d, slab, n, capA, capS, car_width);
   }
+  r->n_rows_reported = capA; r->n_unique_sites = capA; r->shared_lists = false;
   const bool lat_debug = idx->opts.lat_debug;
   vs_timing& t = idx->timing;
   const auto host_prep = std::chrono::steady_clock::now();
@@ -1553,16 +1557,17 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
     std::vector<uint32_t> arena;
     VS_TRY(fetch_carriers(r, 0, r->d.S, arena));
     r->h_carriers.resize(r->n_view_carriers);
-    for (uint64_t a = 0; a < r->d.A; ++a)
+    const uint64_t ns = r->h_view_begin[r->d.Q];
+    for (uint64_t a = 0; a < ns; ++a)
       if (r->h_car_count[a])
         memcpy(r->h_carriers.data() + r->h_car_begin_view[a], arena.data() + r->h_car_begin[a], (size_t)r->h_car_count[a] * 4);
     r->have_carriers = true;
   }
   view->n_regions = r->d.Q;
   view->region_flags = r->h_flags.data();
-  view->var_begin = r->h_var_begin.data();
+  view->var_begin = r->h_view_begin.data();
   view->var_count = r->h_var_count.data();
-  view->n_slots = r->d.A;
+  view->n_slots = r->h_view_begin[r->d.Q];
   view->pos = r->h_pos.data();
   view->ref_off = r->h_ref_off.data(); view->ref_len = r->h_ref_len.data();
   view->alt_off = r->h_alt_off.data(); view->alt_len = r->h_alt_len.data();
@@ -1592,9 +1597,8 @@ int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_varia
     void* dt = nullptr;
     VS_TRY(dev_alloc(idx, 24, &dt, &tmp.bufs));
     HIP_TRY(hipMemsetAsync(dt, 0, 24, idx->stream));
-    if (r->d.A) {
-      const uint64_t blocks = std::min<uint64_t>((r->d.A + 255) / 256, 4096);
-      hipLaunchKernelGGL(k_result_totals, dim3((unsigned)blocks), dim3(256), 0, idx->stream, r->d, (unsigned long long*)dt);
+    if (r->d.Q) {
+      hipLaunchKernelGGL(k_result_totals, dim3((unsigned)((r->d.Q + 3) / 4)), dim3(256), 0, idx->stream, r->d, (unsigned long long*)dt);
       HIP_TRY(hipGetLastError());
     }
     uint64_t h[3] = {0, 0, 0};
@@ -1627,32 +1631,19 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   VS_TRY(fetch_region_meta(r));
   if (q >= r->d.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
   vs_index* idx = r->idx;
-  const uint64_t a0 = r->h_var_begin[q], a1 = r->h_var_begin[q + 1];
+  const uint64_t a0 = r->h_var_begin[q], a1 = a0 + r->h_nvar[q];
   const uint64_t c0 = r->h_car_base[q], c1 = c0 + r->h_car_len[q];
   const uint32_t* car = nullptr;
   const bool from_view = r->have_carriers;
   // the rows: the whole table when a view has already brought it over, otherwise this region's slice of it
-  const uint64_t *h_pos, *h_car_begin;
-  const uint32_t *h_ref_off, *h_ref_len, *h_alt_off, *h_alt_len, *h_vflags, *h_car_count;
-  if (r->have_headers) {
-    h_pos = r->h_pos.data(); h_car_begin = r->h_car_begin.data(); h_ref_off = r->h_ref_off.data(); h_ref_len = r->h_ref_len.data();
-    h_alt_off = r->h_alt_off.data(); h_alt_len = r->h_alt_len.data(); h_vflags = r->h_vflags.data(); h_car_count = r->h_car_count.data();
-  } else {
-    const DevResult& d = r->d;
-    const size_t na = a1 - a0;
-    VS_TRY(fetch(idx, r->sl_pos, (const uint64_t*)d.r_pos + a0, na));
-    VS_TRY(fetch(idx, r->sl_car_begin, (const uint64_t*)d.r_car_begin + a0, na));
-    VS_TRY(fetch(idx, r->sl_ref_off, (const uint32_t*)d.r_ref_off + a0, na));
-    VS_TRY(fetch(idx, r->sl_ref_len, (const uint32_t*)d.r_ref_len + a0, na));
-    VS_TRY(fetch(idx, r->sl_alt_off, (const uint32_t*)d.r_alt_off + a0, na));
-    VS_TRY(fetch(idx, r->sl_alt_len, (const uint32_t*)d.r_alt_len + a0, na));
-    VS_TRY(fetch(idx, r->sl_vflags, (const uint32_t*)d.r_flags + a0, na));
-    VS_TRY(fetch(idx, r->sl_car_count, (const uint32_t*)d.r_car_count + a0, na));
-    if (na == 0) HIP_TRY(hipStreamSynchronize(idx->stream));   // (fetch_carriers below synchronises otherwise)
-    h_pos = r->sl_pos.data(); h_car_begin = r->sl_car_begin.data(); h_ref_off = r->sl_ref_off.data(); h_ref_len = r->sl_ref_len.data();
-    h_alt_off = r->sl_alt_off.data(); h_alt_len = r->sl_alt_len.data(); h_vflags = r->sl_vflags.data(); h_car_count = r->sl_car_count.data();
+  const VariantRow* rows;
+  if (r->have_headers) rows = r->h_rows.data() + a0;
+  else {
+    VS_TRY(fetch(idx, r->sl_rows, (const VariantRow*)r->d.rows + a0, (size_t)(a1 - a0)));
+    if (a1 == a0) HIP_TRY(hipStreamSynchronize(idx->stream));   // (fetch_carriers below synchronises otherwise)
+    rows = r->sl_rows.data();
   }
-  const uint64_t ob = r->have_headers ? 0 : a0;   // index base of the row arrays above
+  const uint64_t vbase = r->have_headers ? r->h_view_begin[q] : 0;   // slot of the region's first row in the view
   if (!from_view) {
     VS_TRY(fetch_carriers(r, c0, c1 - c0, r->slice_carriers));
     car = r->slice_carriers.data();
@@ -1661,9 +1652,10 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   out.clear();
   if (r->kind == 7) {  // samples_has_var's output line, query.h:811-816: `name gt` pairs with nothing between them
     for (uint64_t a = a0; a < a1; ++a) {
-      if (h_vflags[a - ob] & kVarDropped) continue;
-      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (h_car_begin[a - ob] - c0);
-      for (uint32_t k = 0; k < h_car_count[a - ob]; ++k) {
+      const VariantRow& v = rows[a - a0];
+      if (v.count_flags & kRowDropped) continue;
+      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[vbase + (a - a0)] : car + (v.car_begin - c0);
+      for (uint32_t k = 0; k < v.count_flags; ++k) {
         const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
         out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
         out += ' ';
@@ -1684,15 +1676,16 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   }
   out += "Pos\tRef\tAlt\tSamples\n";  // print_header, query.h:38-41
   for (uint64_t a = a0; a < a1; ++a) {
-    if (h_vflags[a - ob] & kVarDropped) continue;
-    out += std::to_string(h_pos[a - ob]);  // print_var, query.h:43-50
+    const VariantRow& v = rows[a - a0];
+    if (v.count_flags & kRowDropped) continue;
+    out += std::to_string(v.pos);  // print_var, query.h:43-50
     out += '\t';
-    out.append(idx->seq_chars, h_ref_off[a - ob], h_ref_len[a - ob]);
+    out.append(idx->seq_chars, v.ref_off, v.ref_len);
     out += '\t';
-    out.append(idx->seq_chars, h_alt_off[a - ob], h_alt_len[a - ob]);
+    out.append(idx->seq_chars, v.alt_off, v.alt_len);
     out += '\t';
-    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[a] : car + (h_car_begin[a - ob] - c0);
-    for (uint32_t k = 0; k < h_car_count[a - ob]; ++k) {
+    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[vbase + (a - a0)] : car + (v.car_begin - c0);
+    for (uint32_t k = 0; k < v.count_flags; ++k) {
       const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
       out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
       out += '(';
@@ -1708,10 +1701,11 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   return VS_OK;
 }
 
-int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared) {
+int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
-  if (n_slots) *n_slots = r->d.A;
+  if (n_slots) *n_slots = r->n_rows_reported;
+  if (table_rows) *table_rows = r->d.A;
   if (arena_entries) *arena_entries = r->d.S;
   if (lists_expanded) *lists_expanded = r->n_unique_sites;
   if (shared) *shared = r->shared_lists ? 1 : 0;
@@ -1727,9 +1721,12 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   void* dd = nullptr;
   VS_TRY(dev_alloc(idx, 8, &dd, &tmp.bufs));
   HIP_TRY(hipMemsetAsync(dd, 0, 8, idx->stream));
-  if (r->d.A) {
-    uint64_t blocks = std::min<uint64_t>((r->d.A + 3) / 4, 8192);
-    hipLaunchKernelGGL(k_digest, dim3((unsigned)blocks), dim3(256), 0, idx->stream, idx->d, r->d, (uint64_t*)dd);
+  if (r->d.A && r->d.Q) {   // the carrier part of every table row once, then every (region, row) pair
+    void* rh = nullptr;
+    VS_TRY(dev_alloc(idx, r->d.A * 8, &rh, &tmp.bufs));
+    const uint64_t blocks = std::min<uint64_t>((r->d.A + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_digest_rows, dim3((unsigned)blocks), dim3(256), 0, idx->stream, r->d, (uint64_t*)rh);
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)((r->d.Q + 3) / 4)), dim3(256), 0, idx->stream, idx->d, r->d, (const uint64_t*)rh, (uint64_t*)dd);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(digest, dd, 8, hipMemcpyDeviceToHost, idx->stream));
@@ -1742,16 +1739,22 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
                            uint64_t* n_records) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
-  if (n_records) *n_records = r->d.A;
+  if (n_records) *n_records = r->n_rows_reported;   // rows over all regions (a shared row once per region reporting it)
   if (!device_dst) return VS_OK;  // size query
-  if (capacity_records < r->d.A) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
-                                             (unsigned long long)capacity_records, (unsigned long long)r->d.A);
+  if (capacity_records < r->n_rows_reported) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
+                                                        (unsigned long long)capacity_records, (unsigned long long)r->n_rows_reported);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
-  if (r->d.A) {
-    hipLaunchKernelGGL(k_pack_headers, dim3((unsigned)((r->d.A + 255) / 256)), dim3(256), 0, idx->stream, r->d,
-                       (uint64_t*)device_dst, region_base);
+  if (r->d.Q) {
+    ScratchBufs tmp(idx);
+    uint64_t* slot_begin = nullptr;
+    VS_TRY(dev_alloc(idx, (r->d.Q + 1) * 8, (void**)&slot_begin, &tmp.bufs));
+    VS_TRY(exclusive_scan<uint64_t>(idx, r->d.q_nvar, r->d.Q, slot_begin, &tmp.bufs));
+    hipLaunchKernelGGL(k_pack_headers, dim3((unsigned)((r->d.Q + 3) / 4)), dim3(256), 0, idx->stream, r->d,
+                       (uint64_t*)device_dst, (const uint64_t*)slot_begin, region_base);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    tmp.release();
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   return VS_OK;

@@ -106,23 +106,50 @@ struct DevImage {
   const uint2* rk_back;     // [R] per rank r: {first ref-path slot of r (= Index::previous(r + 1)), out-degree of that node}
 };
 
+// One row of a result's VARIANT TABLE (what the reference's `Variant` holds, query.h:30-36, with the strings and the
+// sample list as references): 32 bytes, written with two 16-byte stores.
+struct VariantRow {
+  uint32_t pos;            // Variant::var_pos
+  uint32_t ref_off, ref_len, alt_off, alt_len;   // Variant::ref / alt = sequence pool [off, off + len)
+  uint32_t count_flags;    // carriers | kRowDropped
+  uint64_t car_begin;      // first carrier of the row's list in the arena
+};
+static_assert(sizeof(VariantRow) == 32, "row layout");
+constexpr uint32_t kRowDropped = 0x80000000u;   // suppressed by the reference's "already seen" rule (or a branch it never reports)
+__device__ __forceinline__ void row_store(VariantRow* rows, uint64_t a, uint32_t pos, uint32_t ro, uint32_t rl, uint32_t ao, uint32_t al,
+                                          uint32_t count, bool dropped, uint64_t cb) {
+  uint4* p = reinterpret_cast<uint4*>(rows + a);
+  p[0] = uint4{pos, ro, rl, ao};
+  p[1] = uint4{al, count | (dropped ? kRowDropped : 0u), (uint32_t)cb, (uint32_t)(cb >> 32)};
+}
+__device__ __forceinline__ VariantRow row_load(const VariantRow* rows, uint64_t a) {
+  const uint4* p = reinterpret_cast<const uint4*>(rows + a);
+  const uint4 x = p[0], y = p[1];
+  return VariantRow{x.x, x.y, x.z, x.w, y.x, y.y, ((uint64_t)y.w << 32) | y.z};
+}
+__device__ __forceinline__ uint32_t row_count(const VariantRow& v) { return v.count_flags & ~kRowDropped; }
+__device__ __forceinline__ bool row_dropped(const VariantRow& v) { return (v.count_flags & kRowDropped) != 0; }
+
+// A result = per-region arrays + the variant table + the carrier arena.  Region q reports rows
+// [var_begin[q], var_begin[q] + q_nvar[q]) of the table.  In a sorted batch of overlapping regions the ranges of
+// different regions OVERLAP: every site the batch covers has one row and one carrier list, shared by the regions that
+// report it (k_share_*); otherwise every region has rows and lists of its own, back to back.
 struct DevResult {
-  uint64_t Q, A, S;
+  uint64_t Q, A, S;         // regions, rows of the table, arena entries
   const uint64_t* regions;  // [2Q] x,y
   uint8_t* q_flags;         // [Q]
   uint32_t* q_g0;           // [Q] first site of the region
   uint64_t* q_nvar;         // [Q] slots
   uint64_t* q_ncar;         // [Q] arena entries of the region (padded counts) until the offsets are scanned; afterwards the
                             //     header kernels overwrite it with the carriers of the region's REPORTED variants
-  uint64_t* var_begin;      // [Q+1]
+  uint64_t* var_begin;      // [Q+1] first row of each region ([Q] = A); monotone only when rows are private
   uint64_t* car_base;       // [Q+1] arena offset of each region's first site; with shared carrier lists NOT monotone ([Q] = arena entries used)
   uint64_t* q_car_len;      // [Q] shared carrier lists only: the region's padded arena extent (else NULL: car_base[q + 1] - car_base[q])
-  uint64_t* var_count;      // [Q]
-  uint64_t* r_pos;
-  uint32_t *r_ref_off, *r_ref_len, *r_alt_off, *r_alt_len, *r_flags, *r_car_count, *r_region;
-  uint32_t* r_class;        // DevImage::v_src of the slot's vertex: list group index or class id, by r_car_count
-  uint64_t* r_car_begin;
-  uint64_t* r_gt0;
+  uint64_t* var_count;      // [Q] variants the reference reports (rows minus dropped)
+  VariantRow* rows;         // [A]
+  // private-row results only: what k_fill_carriers needs per row beside count and arena offset
+  uint32_t* r_class;        // DevImage::v_src of the row's vertex: list group index or class id, by the count
+  uint64_t* r_gt0;          // carrier-pool index of its first carrier
   void* carriers;           // uint16 (id | gt << 13) for cohorts of at most 4032 samples, else uint32 (id | gt << 29)
   uint32_t car_width, pad3_; // bytes per carrier word in the arena: 2 or 4
   // latency path (k_query_small): the last block posts done_seq | any-slow << 62 | capacities-exceeded << 63 into
@@ -470,8 +497,8 @@ __global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const uint64_t* nvar
 // ---------------------------------------------------------------------------
 // Variant headers: one wave per region, lanes stride the region's site range.
 // ---------------------------------------------------------------------------
-// PARAMS: also write the per-slot parameters k_fill_carriers reads (source handle, genotype offset); a batch whose
-// carrier lists are shared between regions (k_fill_sites) expands straight from the site table and needs none.
+// Private rows of region q: its site range copied into the table at var_begin[q].  PARAMS: also the per-row parameters
+// k_fill_carriers reads (source handle, genotype offset) -- a batch with shared lists expands from the site table instead.
 template <bool PARAMS>
 __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult& r, uint64_t q, uint32_t lane) {
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
@@ -481,17 +508,10 @@ __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult&
   for (uint64_t j = lane; j < n; j += 64) {
     const uint64_t a = a0 + j;
     const uint32_t g = g0 + (uint32_t)j;
-    const uint32_t fl = im.s_flags[g];
-    kept += im.s_ncar[g];
-    // (plain stores: non-temporal ones made this kernel slower -- its pieces of 256 bytes per array and pass only
-    //  become whole lines in the L2)
-    r.r_pos[a] = im.s_pos[g];
-    r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
-    r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
-    r.r_flags[a] = (fl & kSiteAlwaysDrop) ? kVarDropped : 0u;
-    r.r_car_begin[a] = cb + (im.s_carpre[g] - pre0);
-    r.r_car_count[a] = im.s_ncar[g];
-    r.r_region[a] = (uint32_t)q;
+    const uint32_t cnt = im.s_ncar[g];
+    kept += cnt;
+    row_store(r.rows, a, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], cnt,
+              (im.s_flags[g] & kSiteAlwaysDrop) != 0, cb + (im.s_carpre[g] - pre0));
     if (PARAMS) {
       r.r_class[a] = im.s_class[g];
       r.r_gt0[a] = im.s_gt0[g];
@@ -567,30 +587,30 @@ __global__ void __launch_bounds__(kScanBlock) k_share_spine_max(ShareMax* tile_m
     carry = smax(carry, tot);
   }
 }
-struct Scan3 { uint64_t a, u, c; };   // slots, unique (newly covered) sites, arena entries of the new parts
-__device__ __forceinline__ Scan3 block_exclusive_scan3(Scan3 v, Scan3* total) {
-  __shared__ Scan3 wsum[kScanBlock / 64];
+struct Scan4 { uint64_t a, u, c, p; };   // rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule)
+__device__ __forceinline__ Scan4 block_exclusive_scan4(Scan4 v, Scan4* total) {
+  __shared__ Scan4 wsum[kScanBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  Scan3 incl = v;
+  Scan4 incl = v;
   for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t ta = __shfl_up(incl.a, d, 64), tu = __shfl_up(incl.u, d, 64), tc = __shfl_up(incl.c, d, 64);
-    if (lane >= d) { incl.a += ta; incl.u += tu; incl.c += tc; }
+    const uint64_t ta = __shfl_up(incl.a, d, 64), tu = __shfl_up(incl.u, d, 64), tc = __shfl_up(incl.c, d, 64), tp = __shfl_up(incl.p, d, 64);
+    if (lane >= d) { incl.a += ta; incl.u += tu; incl.c += tc; incl.p += tp; }
   }
   if (lane == 63) wsum[wid] = incl;
   __syncthreads();
-  Scan3 woff{0, 0, 0}, tot{0, 0, 0};
+  Scan4 woff{0, 0, 0, 0}, tot{0, 0, 0, 0};
   for (int w = 0; w < kScanBlock / 64; ++w) {
-    if (w < wid) { woff.a += wsum[w].a; woff.u += wsum[w].u; woff.c += wsum[w].c; }
-    tot.a += wsum[w].a; tot.u += wsum[w].u; tot.c += wsum[w].c;
+    if (w < wid) { woff.a += wsum[w].a; woff.u += wsum[w].u; woff.c += wsum[w].c; woff.p += wsum[w].p; }
+    tot.a += wsum[w].a; tot.u += wsum[w].u; tot.c += wsum[w].c; tot.p += wsum[w].p;
   }
   __syncthreads();
   *total = tot;
-  return Scan3{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c};
+  return Scan4{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c, woff.p + incl.p - v.p};
 }
 // what region q adds to the batch, given the largest site end before it
-struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back; };
+struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back, rback; };
 __device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, uint32_t nv, uint32_t e_prev) {
-  ShareNew o{g0, 0, 0, 0};
+  ShareNew o{g0, 0, 0, 0, 0};
   if (!nv) return o;
   const uint32_t g1 = g0 + nv;
   o.ns = e_prev > g0 ? (e_prev < g1 ? e_prev : g1) : g0;
@@ -598,10 +618,11 @@ __device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, u
   const uint64_t c0 = im.s_carpre[g0];
   o.arena_new = im.s_carpre[g1] - im.s_carpre[o.ns];
   o.back = e_prev > g0 ? im.s_carpre[e_prev] - c0 : 0;   // arena distance from site g0 to where the covered ground ends
+  o.rback = e_prev > g0 ? e_prev - g0 : 0;               // the same in rows
   return o;
 }
-// per element: E_prev (kept for the last pass) and the tile sums of {slots, new sites, new arena entries}
-__global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t* e_prev, Scan3* tile_sums,
+// per element: E_prev (kept for the last pass) and the tile sums
+__global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t* e_prev, Scan4* tile_sums,
                                                          uint32_t* status) {
   const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
   ShareMax loc[kScanItems], m{0, 0};
@@ -611,7 +632,7 @@ __global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult
   }
   ShareMax tot;
   ShareMax ex = smax(block_exclusive_max(m, &tot), tile_max[blockIdx.x]);
-  Scan3 s{0, 0, 0};
+  Scan4 s{0, 0, 0, 0};
   for (int i = 0; i < kScanItems; ++i) {
     if (base + i < r.Q) {
       const uint32_t nv = (uint32_t)r.q_nvar[base + i];
@@ -619,72 +640,88 @@ __global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult
       e_prev[base + i] = ex.g1;
       const ShareNew w = share_new(im, loc[i].g0, nv, ex.g1);
       s.a += nv; s.u += w.n_new; s.c += w.arena_new;
+      if (r.q_flags[base + i] & kRegionSlow) s.p += nv;
     }
     ex = smax(ex, loc[i]);
   }
-  Scan3 t3;
-  block_exclusive_scan3(s, &t3);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = t3;
+  Scan4 t4;
+  block_exclusive_scan4(s, &t4);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = t4;
 }
-__global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan3* tile_sums, uint64_t ntiles, DevResult r, uint64_t* u_begin, uint64_t* totals,
+// totals: {rows of the table (shared + private), arena entries, shared rows, not-sorted flag, rows reported over all regions}
+__global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan4* tile_sums, uint64_t ntiles, DevResult r, uint64_t* u_begin, uint64_t* totals,
                                                                const uint32_t* status) {
-  Scan3 carry{0, 0, 0};
+  Scan4 carry{0, 0, 0, 0};
   for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
     const uint64_t i = base + threadIdx.x;
-    const Scan3 v = i < ntiles ? tile_sums[i] : Scan3{0, 0, 0};
-    Scan3 tot;
-    const Scan3 ex = block_exclusive_scan3(v, &tot);
-    if (i < ntiles) tile_sums[i] = Scan3{carry.a + ex.a, carry.u + ex.u, carry.c + ex.c};
-    carry.a += tot.a; carry.u += tot.u; carry.c += tot.c;
+    const Scan4 v = i < ntiles ? tile_sums[i] : Scan4{0, 0, 0, 0};
+    Scan4 tot;
+    const Scan4 ex = block_exclusive_scan4(v, &tot);
+    if (i < ntiles) tile_sums[i] = Scan4{carry.a + ex.a, carry.u + ex.u, carry.c + ex.c, carry.p + ex.p};
+    carry.a += tot.a; carry.u += tot.u; carry.c += tot.c; carry.p += tot.p;
   }
   if (threadIdx.x == 0) {
-    r.var_begin[r.Q] = carry.a; r.car_base[r.Q] = carry.c; u_begin[r.Q] = carry.u;
-    totals[0] = carry.a; totals[1] = carry.c; totals[2] = carry.u; totals[3] = *status;
+    r.var_begin[r.Q] = carry.u + carry.p; r.car_base[r.Q] = carry.c; u_begin[r.Q] = carry.u;
+    totals[0] = carry.u + carry.p; totals[1] = carry.c; totals[2] = carry.u; totals[3] = *status; totals[4] = carry.a;
   }
 }
-__global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan3* tile_sums, uint32_t* new_start,
-                                                           uint64_t* u_begin, uint64_t* arena_new, uint64_t* q_car_len) {
+__global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan4* tile_sums, uint32_t* new_start,
+                                                           uint64_t* u_begin, uint64_t* arena_new) {
   const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  const uint64_t U = u_begin[r.Q];   // (written by the spine kernel before this launch)
   ShareNew loc[kScanItems];
   uint32_t nvs[kScanItems];
-  Scan3 s{0, 0, 0};
+  bool slow[kScanItems];
+  Scan4 s{0, 0, 0, 0};
   for (int i = 0; i < kScanItems; ++i) {
-    loc[i] = ShareNew{0, 0, 0, 0}; nvs[i] = 0;
+    loc[i] = ShareNew{0, 0, 0, 0, 0}; nvs[i] = 0; slow[i] = false;
     if (base + i < r.Q) {
       nvs[i] = (uint32_t)r.q_nvar[base + i];
+      slow[i] = (r.q_flags[base + i] & kRegionSlow) != 0;
       loc[i] = share_new(im, r.q_g0[base + i], nvs[i], e_prev[base + i]);
-      s.a += nvs[i]; s.u += loc[i].n_new; s.c += loc[i].arena_new;
+      s.a += nvs[i]; s.u += loc[i].n_new; s.c += loc[i].arena_new; s.p += slow[i] ? nvs[i] : 0;
     }
   }
-  Scan3 tot;
-  Scan3 ex = block_exclusive_scan3(s, &tot);
-  const Scan3 ts = tile_sums[blockIdx.x];
-  ex.a += ts.a; ex.u += ts.u; ex.c += ts.c;
+  Scan4 tot;
+  Scan4 ex = block_exclusive_scan4(s, &tot);
+  const Scan4 ts = tile_sums[blockIdx.x];
+  ex.a += ts.a; ex.u += ts.u; ex.c += ts.c; ex.p += ts.p;
   for (int i = 0; i < kScanItems; ++i) {
     if (base + i < r.Q) {
       const uint64_t q = base + i;
-      r.var_begin[q] = ex.a; u_begin[q] = ex.u; arena_new[q] = ex.c; new_start[q] = loc[i].ns;
+      u_begin[q] = ex.u; arena_new[q] = ex.c; new_start[q] = loc[i].ns;
+      // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
+      r.var_begin[q] = slow[i] ? U + ex.p : ex.u - loc[i].rback;
       r.car_base[q] = ex.c - loc[i].back;
-      q_car_len[q] = r.q_ncar[q];                    // the region's own padded arena extent (q_ncar is overwritten by the header kernels)
+      r.q_car_len[q] = r.q_ncar[q];                  // the region's own padded arena extent
+      if (!slow[i]) {                                // (dedup_region sets these for the others)
+        const uint32_t g0 = r.q_g0[q];
+        r.var_count[q] = nvs[i];
+        r.q_ncar[q] = im.s_kpre[g0 + nvs[i]] - im.s_kpre[g0];
+      }
     }
-    ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new;
+    ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new; ex.p += slow[i] ? nvs[i] : 0;
   }
 }
-// the owned sites of every region, in arena order: site index and arena offset per unique site (one wave per region)
-__global__ void __launch_bounds__(256) k_unique_sites(DevImage im, DevResult r, const uint32_t* new_start, const uint64_t* u_begin, const uint64_t* arena_new,
-                                                      uint32_t* u_site, uint64_t* u_cb) {
+// The shared rows: every region writes the rows of the sites it is the first to cover (one wave per region), and the
+// site index beside them for the expansion; regions under the duplicate rule also get their private copy.
+__global__ void __launch_bounds__(256) k_share_rows(DevImage im, DevResult r, const uint32_t* new_start, const uint64_t* u_begin, const uint64_t* arena_new,
+                                                    uint32_t* u_site) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t u0 = u_begin[q], n_new = u_begin[q + 1] - u0;
-  if (!n_new) return;
-  const uint32_t ns = new_start[q];
-  const uint64_t cb0 = arena_new[q], pre = im.s_carpre[ns];
-  for (uint64_t j = lane; j < n_new; j += 64) {
-    const uint32_t g = ns + (uint32_t)j;
-    u_site[u0 + j] = g;
-    u_cb[u0 + j] = cb0 + (im.s_carpre[g] - pre);
+  if (n_new) {
+    const uint32_t ns = new_start[q];
+    const uint64_t cb0 = arena_new[q], pre = im.s_carpre[ns];
+    for (uint64_t j = lane; j < n_new; j += 64) {
+      const uint32_t g = ns + (uint32_t)j;
+      row_store(r.rows, u0 + j, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], im.s_ncar[g],
+                (im.s_flags[g] & kSiteAlwaysDrop) != 0, cb0 + (im.s_carpre[g] - pre));
+      u_site[u0 + j] = g;
+    }
   }
+  if (r.q_flags[q] & kRegionSlow) emit_region<false>(im, r, q, lane);
 }
 
 // The reference's "only add var if not seen before" rule (query.h:397-414),
@@ -692,25 +729,28 @@ __global__ void __launch_bounds__(256) k_unique_sites(DevImage im, DevResult r, 
 __device__ __forceinline__ void dedup_region(const DevImage& im, const DevResult& r, uint64_t q) {
   const uint64_t a0 = r.var_begin[q], n = r.q_nvar[q];
   uint64_t kept = 0, back = 0, kept_car = 0;
+  VariantRow vb{};   // the last row kept (vars.back())
   for (uint64_t j = 0; j < n; ++j) {
     const uint64_t a = a0 + j;
-    if (r.r_flags[a] & kVarDropped) { r.r_car_count[a] = 0; continue; }
-    const uint64_t p = r.r_pos[a];
-    const uint32_t ao = r.r_alt_off[a], al = r.r_alt_len[a];
+    VariantRow v = row_load(r.rows, a);
+    if (row_dropped(v)) { if (row_count(v)) { v.count_flags = kRowDropped; r.rows[a].count_flags = v.count_flags; } continue; }
+    const uint64_t p = v.pos;
+    const uint32_t ao = v.alt_off, al = v.alt_len;
     bool push = true;
     if (kept >= 1) {
-      const bool same_back = r.r_pos[back] == p && r.r_alt_len[back] == al && seq_equal(im, r.r_alt_off[back], ao, al);
+      const bool same_back = vb.pos == p && vb.alt_len == al && seq_equal(im, vb.alt_off, ao, al);
       if (same_back) push = false;
-      else if (kept > 1 && r.r_pos[back] == p) {
+      else if (kept > 1 && vb.pos == p) {
         for (uint64_t i = back + 1; i-- > a0;) {
-          if (r.r_flags[i] & kVarDropped) continue;
-          if (r.r_pos[i] < p) break;
-          if (r.r_pos[i] == p && r.r_alt_len[i] == al && seq_equal(im, r.r_alt_off[i], ao, al)) { push = false; break; }
+          const VariantRow w = row_load(r.rows, i);
+          if (row_dropped(w)) continue;
+          if (w.pos < p) break;
+          if (w.pos == p && w.alt_len == al && seq_equal(im, w.alt_off, ao, al)) { push = false; break; }
         }
       }
     }
-    if (push) { kept++; back = a; kept_car += r.r_car_count[a]; }
-    else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
+    if (push) { kept++; back = a; vb = v; kept_car += row_count(v); }
+    else r.rows[a].count_flags = kRowDropped;   // dropped: no carriers reported
   }
   r.var_count[q] = kept;
   r.q_ncar[q] = kept_car;
@@ -1260,10 +1300,11 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
     if (a < A && lane < CH) {   // read once
-      cnt = __builtin_nontemporal_load(&r.r_car_count[a]);
+      const uint4 y = reinterpret_cast<const uint4*>(r.rows + a)[1];   // {alt_len, count | dropped, car_begin}
+      cnt = y.y & ~kRowDropped;
+      cb = ((uint64_t)y.w << 32) | y.z;
       cls = __builtin_nontemporal_load(&r.r_class[a]);
       gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
-      cb = __builtin_nontemporal_load(&r.r_car_begin[a]);
     }
     expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
@@ -1272,8 +1313,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
 // The same expansion over the UNIQUE sites of a batch whose carrier lists are shared: the slot parameters come straight
 // from the site table (sequential reads, each site once), the arena offset from k_unique_sites.
 template <bool WIDE, uint32_t CH, bool TUNE>
-__global__ void __launch_bounds__(256) k_fill_sites(DevImage im, void* arena, const uint32_t* u_site, const uint64_t* u_cb, uint64_t U,
-                                                    uint32_t ablate, uint32_t gt_words) {
+__global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, const uint32_t* u_site, uint64_t U, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nchunks = (U + CH - 1) / CH;
@@ -1285,12 +1325,13 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, void* arena, co
     uint64_t gt0 = 0, cb = 0;
     if (u < U && lane < CH) {
       const uint32_t g = __builtin_nontemporal_load(&u_site[u]);
-      cb = __builtin_nontemporal_load(&u_cb[u]);
-      cnt = im.s_ncar[g];
+      const uint4 y = reinterpret_cast<const uint4*>(r.rows + u)[1];   // {alt_len, count | dropped, car_begin}: the shared rows are table rows [0, U)
+      cnt = y.y & ~kRowDropped;
+      cb = ((uint64_t)y.w << 32) | y.z;
       cls = im.s_class[g];
       gt0 = im.s_gt0[g];
     }
-    expand_task<WIDE, false, TUNE>(im, arena, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
@@ -1321,19 +1362,14 @@ __host__ __device__ inline size_t small_result_layout(DevResult& d, uint8_t* sla
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   const size_t o_flags = take(n), o_g0 = take(n * 4), o_nvar = take(n * 8), o_ncar = take(n * 8), o_vb = take((n + 1) * 8),
-               o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_pos = take(capA * 8), o_ro = take(capA * 4),
-               o_rl = take(capA * 4), o_ao = take(capA * 4), o_al = take(capA * 4), o_fl = take(capA * 4), o_cc = take(capA * 4),
-               o_rg = take(capA * 4), o_cbg = take(capA * 8), o_cl = take(capA * 4), o_gt = take(capA * 8),
+               o_cb = take((n + 1) * 8), o_vc = take(n * 8), o_rows = take(capA * sizeof(VariantRow)),
                o_car = take(capS * car_width + 16);
   d.Q = n; d.A = capA; d.S = capS;
   d.regions = nullptr;
   d.q_flags = slab + o_flags; d.q_g0 = (uint32_t*)(slab + o_g0); d.q_nvar = (uint64_t*)(slab + o_nvar);
   d.q_ncar = (uint64_t*)(slab + o_ncar); d.var_begin = (uint64_t*)(slab + o_vb); d.car_base = (uint64_t*)(slab + o_cb);
   d.var_count = (uint64_t*)(slab + o_vc);
-  d.r_pos = (uint64_t*)(slab + o_pos); d.r_ref_off = (uint32_t*)(slab + o_ro); d.r_ref_len = (uint32_t*)(slab + o_rl);
-  d.r_alt_off = (uint32_t*)(slab + o_ao); d.r_alt_len = (uint32_t*)(slab + o_al); d.r_flags = (uint32_t*)(slab + o_fl);
-  d.r_car_count = (uint32_t*)(slab + o_cc); d.r_region = (uint32_t*)(slab + o_rg); d.r_car_begin = (uint64_t*)(slab + o_cbg);
-  d.r_class = (uint32_t*)(slab + o_cl); d.r_gt0 = (uint64_t*)(slab + o_gt); d.carriers = slab + o_car;
+  d.rows = (VariantRow*)(slab + o_rows); d.r_class = nullptr; d.r_gt0 = nullptr; d.q_car_len = nullptr; d.carriers = slab + o_car;
   d.car_width = car_width; d.pad3_ = 0;
   return off;
 }
@@ -1385,16 +1421,9 @@ __device__ __forceinline__ uint32_t small_batch_wave(const DevImage& im, const D
         cls = im.s_class[g];
         gt0 = im.s_gt0[g];
         cb = cb_q + im.s_carpre[g];
-        // the variant header (building std::vector<Variant>, query.h:736-771)
-        r.r_pos[a] = im.s_pos[g];
-        r.r_ref_off[a] = im.s_ref_off[g]; r.r_ref_len[a] = im.s_ref_len[g];
-        r.r_alt_off[a] = im.s_alt_off[g]; r.r_alt_len[a] = im.s_alt_len[g];
-        r.r_flags[a] = (fl & kSiteAlwaysDrop) ? kVarDropped : 0u;
-        r.r_car_begin[a] = cb;
-        r.r_car_count[a] = cnt;
-        r.r_region[a] = q;
-        r.r_class[a] = cls;
-        r.r_gt0[a] = gt0;
+        // the variant row (building std::vector<Variant>, query.h:736-771)
+        row_store(r.rows, a, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], cnt,
+                  (fl & kSiteAlwaysDrop) != 0, cb);
       }
       expand_task<WIDE, true>(im, r.carriers, lds_wave, lane, cnt, cls, gt0, cb, 0u, gt_words);
     }
@@ -1573,16 +1602,21 @@ __global__ void __launch_bounds__(256) k_query_server(DevImage im, const ServerR
   }
 }
 
-// Hit-list records for a collective: 4 x uint64 per slot
+// Hit-list records for a collective: 4 x uint64 per reported row of every region, regions back to back
 //   {pos | dropped << 63, ref_off | ref_len << 32, alt_off | alt_len << 32, region | car_count << 32}
-__global__ void __launch_bounds__(256) k_pack_headers(DevResult r, uint64_t* dst, uint64_t region_base) {
-  const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= r.A) return;
-  const uint64_t dropped = (r.r_flags[a] & kVarDropped) ? (1ULL << 63) : 0ULL;
-  dst[4 * a + 0] = r.r_pos[a] | dropped;
-  dst[4 * a + 1] = (uint64_t)r.r_ref_off[a] | ((uint64_t)r.r_ref_len[a] << 32);
-  dst[4 * a + 2] = (uint64_t)r.r_alt_off[a] | ((uint64_t)r.r_alt_len[a] << 32);
-  dst[4 * a + 3] = (region_base + r.r_region[a]) | ((uint64_t)r.r_car_count[a] << 32);
+// (one wave per region; slot_begin = exclusive scan of the regions' row counts)
+__global__ void __launch_bounds__(256) k_pack_headers(DevResult r, uint64_t* dst, const uint64_t* slot_begin, uint64_t region_base) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], o0 = slot_begin[q];
+  for (uint64_t j = threadIdx.x & 63; j < n; j += 64) {
+    const VariantRow v = row_load(r.rows, a0 + j);
+    uint64_t* d = dst + 4 * (o0 + j);
+    d[0] = (uint64_t)v.pos | (row_dropped(v) ? (1ULL << 63) : 0ULL);
+    d[1] = (uint64_t)v.ref_off | ((uint64_t)v.ref_len << 32);
+    d[2] = (uint64_t)v.alt_off | ((uint64_t)v.alt_len << 32);
+    d[3] = (region_base + q) | ((uint64_t)row_count(v) << 32);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2056,9 +2090,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       if (EMIT) {
         const WalkVariant wv = resolve_walk_variant(im, em.kind, em.cur, em.ref_pos, em.cur_ref_v);
         const uint64_t a = a0 + nvar;
-        r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
-        r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = em.c;
-        r.r_region[a] = (uint32_t)q;
+        row_store(r.rows, a, (uint32_t)wv.pos, wv.ro, wv.rl, wv.ao, wv.al, em.c, false, cb + ncar);
         r.r_class[a] = im.v_src[em.cur]; r.r_gt0[a] = im.v_car_begin[em.cur];
       }
       if (MODE == 2) {   // the walk's state at the vertex; k_emit_from_walk turns it into the row
@@ -2314,9 +2346,7 @@ __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r
       WalkVariant wv;
       if (RESOLVE) wv = resolve_walk_variant(im, ws.ro[s], cur, ws.pos[s], ws.rl[s]);
       else wv = WalkVariant{ws.pos[s], ws.ro[s], ws.rl[s], ws.ao[s], ws.al[s]};
-      r.r_pos[a] = wv.pos; r.r_ref_off[a] = wv.ro; r.r_ref_len[a] = wv.rl; r.r_alt_off[a] = wv.ao; r.r_alt_len[a] = wv.al;
-      r.r_flags[a] = 0; r.r_car_begin[a] = cb + (incl - pad_car(c)); r.r_car_count[a] = c;
-      r.r_region[a] = (uint32_t)q;
+      row_store(r.rows, a, (uint32_t)wv.pos, wv.ro, wv.rl, wv.ao, wv.al, c, false, cb + (incl - pad_car(c)));
       r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
     }
     cb += (uint32_t)__shfl((int)incl, (int)row_last, 64);
@@ -2468,15 +2498,16 @@ __global__ void __launch_bounds__(64) k_has_var_filter(DevImage im, DevResult r,
   uint64_t kept_car = 0;
   for (uint64_t j = 0; j < n; ++j) {
     const uint64_t a = a0 + j;
-    if (r.r_flags[a] & kVarDropped) continue;
-    bool match = !found && r.r_pos[a] == pos && r.r_ref_len[a] == ref_len && r.r_alt_len[a] == alt_len;
+    const VariantRow v = row_load(r.rows, a);
+    if (row_dropped(v)) continue;
+    bool match = !found && v.pos == pos && v.ref_len == ref_len && v.alt_len == alt_len;
     if (match) {
       const char dec[8] = {'A', 'C', 'T', 'G', 'N', 5, 5, 5};  // map_int, util.cc:32-41
-      for (uint64_t i = 0; match && i < ref_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_ref_off[a] + i] & 7] == ref[i];
-      for (uint64_t i = 0; match && i < alt_len; ++i) match = (uint8_t)dec[im.seq_codes[r.r_alt_off[a] + i] & 7] == alt[i];
+      for (uint64_t i = 0; match && i < ref_len; ++i) match = (uint8_t)dec[im.seq_codes[v.ref_off + i] & 7] == ref[i];
+      for (uint64_t i = 0; match && i < alt_len; ++i) match = (uint8_t)dec[im.seq_codes[v.alt_off + i] & 7] == alt[i];
     }
-    if (match) { found = true; kept_car = r.r_car_count[a]; }
-    else { r.r_flags[a] |= kVarDropped; r.r_car_count[a] = 0; }
+    if (match) { found = true; kept_car = row_count(v); }
+    else r.rows[a].count_flags = kRowDropped;
   }
   r.var_count[q] = found ? 1 : 0;
   r.q_ncar[q] = kept_car;
@@ -2639,9 +2670,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
         const uint32_t c = wc.ncar;
         if (EMIT) {
           const uint64_t a = a0 + nvar;
-          r.r_pos[a] = pos; r.r_ref_off[a] = ro; r.r_ref_len[a] = rl; r.r_alt_off[a] = ao; r.r_alt_len[a] = al;
-          r.r_flags[a] = 0; r.r_car_begin[a] = cb + ncar; r.r_car_count[a] = c;
-          r.r_region[a] = (uint32_t)q;
+          row_store(r.rows, a, (uint32_t)pos, ro, rl, ao, al, c, false, cb + ncar);
           r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
         if (MODE == 2) {
@@ -2812,12 +2841,16 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
   }
 }
 
-// Totals of a result without copying it: {variants reported, their carriers, their REF + ALT bases}
+// Totals of a result without copying it: {variants reported, their carriers, their REF + ALT bases}, one wave per region
 __global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned long long* out) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q];
   unsigned long long nv = 0, nc = 0, nb = 0;
-  for (uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; a < r.A; a += (uint64_t)gridDim.x * blockDim.x) {
-    if (r.r_flags[a] & kVarDropped) continue;
-    nv += 1; nc += r.r_car_count[a]; nb += (uint64_t)r.r_ref_len[a] + r.r_alt_len[a];
+  for (uint64_t j = threadIdx.x & 63; j < n; j += 64) {
+    const VariantRow v = row_load(r.rows, a0 + j);
+    if (row_dropped(v)) continue;
+    nv += 1; nc += row_count(v); nb += (uint64_t)v.ref_len + v.alt_len;
   }
   for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); nc += __shfl_down(nc, d, 64); nb += __shfl_down(nb, d, 64); }
   if ((threadIdx.x & 63) == 0 && (nv | nb)) { atomicAdd(out, nv); atomicAdd(out + 1, nc); atomicAdd(out + 2, nb); }
@@ -2842,33 +2875,42 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return x;
 }
-__global__ void __launch_bounds__(256) k_digest(DevImage im, DevResult r, uint64_t* digest) {
+// pass 1, one wave per TABLE row: the carrier part of the row's hash (shared rows: once for all regions reporting them)
+__global__ void __launch_bounds__(256) k_digest_rows(DevResult r, uint64_t* row_hash) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  uint64_t acc = 0;
   for (uint64_t a = wave; a < r.A; a += nwaves) {
-    if (r.r_flags[a] & kVarDropped) continue;
+    const VariantRow v = row_load(r.rows, a);
     uint64_t h = 0;
-    const uint32_t cnt = r.r_car_count[a];
-    const uint32_t* car32 = reinterpret_cast<const uint32_t*>(r.carriers) + r.r_car_begin[a];
-    const uint16_t* car16 = reinterpret_cast<const uint16_t*>(r.carriers) + r.r_car_begin[a];
+    const uint32_t cnt = row_count(v);
+    const uint32_t* car32 = reinterpret_cast<const uint32_t*>(r.carriers) + v.car_begin;
+    const uint16_t* car16 = reinterpret_cast<const uint16_t*>(r.carriers) + v.car_begin;
     for (uint32_t k = lane; k < cnt; k += 64) {   // the digest is defined over the 32-bit form of a carrier word
       const uint32_t c = r.car_width == 2 ? ((uint32_t)(car16[k] & 0x1FFFu) | ((uint32_t)(car16[k] >> 13) << 29)) : car32[k];
       h += mix64(((uint64_t)c << 32) | k);
     }
-    if (lane == 0) {
-      uint64_t s = mix64(r.r_region[a] * 0x9E3779B97F4A7C15ULL + r.r_pos[a]);
-      for (uint32_t i = 0; i < r.r_ref_len[a]; ++i) s = mix64(s ^ (im.seq_codes[r.r_ref_off[a] + i] + 1));
-      s = mix64(s ^ 0xABCDEFULL);
-      for (uint32_t i = 0; i < r.r_alt_len[a]; ++i) s = mix64(s ^ (im.seq_codes[r.r_alt_off[a] + i] + 1));
-      h += s;
-    }
     for (int d = 32; d >= 1; d >>= 1) h += __shfl_down(h, d, 64);
-    // per-variant hash is then mixed once more so carriers are tied to their variant
-    if (lane == 0) acc += mix64(h);
+    if (lane == 0) row_hash[a] = h;
   }
-  if (lane == 0 && acc) atomicAdd((unsigned long long*)digest, (unsigned long long)acc);
+}
+// pass 2, one wave per region: every reported (region, row) pair adds mix(row hash + mix(region, pos, ref bases, alt bases))
+__global__ void __launch_bounds__(256) k_digest(DevImage im, DevResult r, const uint64_t* row_hash, uint64_t* digest) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q];
+  uint64_t acc = 0;
+  for (uint64_t j = threadIdx.x & 63; j < n; j += 64) {
+    const VariantRow v = row_load(r.rows, a0 + j);
+    if (row_dropped(v)) continue;
+    uint64_t s = mix64((uint32_t)q * 0x9E3779B97F4A7C15ULL + v.pos);
+    for (uint32_t i = 0; i < v.ref_len; ++i) s = mix64(s ^ (im.seq_codes[v.ref_off + i] + 1));
+    s = mix64(s ^ 0xABCDEFULL);
+    for (uint32_t i = 0; i < v.alt_len; ++i) s = mix64(s ^ (im.seq_codes[v.alt_off + i] + 1));
+    acc += mix64(row_hash[a0 + j] + s);   // the row's hash is mixed once more so carriers are tied to their variant
+  }
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd((unsigned long long*)digest, (unsigned long long)acc);
 }
 
 }  // namespace vsamd
