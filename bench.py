@@ -166,6 +166,47 @@ def cpu_baseline_all_cores(sub, plain, td, budget_s=10.0):
             "sample": f"{done} regions over {cores} processes, {wall:.1f} s"}
 
 
+def cli_leg(vs, regions, w):
+    """The drop-in CLI on the same index and the same regions, timed by the line the reference's driver prints
+    (`Query<N>: (query_var_in_ref) Total Time Elapsed: ...seconds`, src/commands.cc:196-211, src/util.cc:67-80): the
+    index is saved as an index directory, `variantstore query -t 6 -r @file -m 1` loads it and answers the batch."""
+    import re
+    import subprocess
+    import tempfile
+    from variantstore_amd import build as vb
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            a = time.perf_counter()
+            vs.save(td)
+            out["save_s"] = time.perf_counter() - a
+            rfile = os.path.join(td, "regions.txt")
+            with open(rfile, "w") as f:
+                f.write("\n".join(f"{int(x)}:{int(y)}" for x, y in regions) + "\n")
+            for name, extra, nsub in (("all_regions", [], len(regions)), ("batch_out_2000_regions", ["--batch-out", os.path.join(td, "out.txt")], 2000)):
+                sub = rfile
+                if nsub != len(regions):
+                    sub = os.path.join(td, "regions_sub.txt")
+                    with open(sub, "w") as f:
+                        f.write("\n".join(f"{int(x)}:{int(y)}" for x, y in regions[:nsub]) + "\n")
+                a = time.perf_counter()
+                p = subprocess.run([vb.CLI, "query", "-p", td, "-t", "6", "-r", "@" + sub, "-m", "1"] + extra, stdout=subprocess.PIPE,
+                                   stderr=subprocess.STDOUT, text=True, timeout=900)
+                wall = time.perf_counter() - a
+                m = re.findall(r"Query(\d+): \(query_var_in_ref\) Total Time Elapsed: ([0-9.]+)seconds", p.stdout)
+                if p.returncode != 0 or not m:
+                    out[name] = {"error": p.stdout[-300:]}
+                    continue
+                nq, secs = int(m[-1][0]), float(m[-1][1])
+                out[name] = {"regions": nq, "query_seconds_by_its_own_line": secs, "queries_per_s": nq / secs if secs > 0 else None,
+                             "process_wall_s": wall}
+                if extra:
+                    out[name]["batch_out_bytes"] = os.path.getsize(extra[1])
+    except Exception as e:  # the CLI leg must not take the bench line down
+        out["error"] = repr(e)
+    return out
+
+
 def git_blob_hash(path):
     """`git hash-object` of a file without needing git: sha1("blob <len>\0" + content)."""
     import hashlib
@@ -235,7 +276,8 @@ def main():
     args = ap.parse_args()
     if args.skip_extras or os.environ.get("VS_BENCH_SKIP_T4") == "1":
         args.extras = "none"
-    extras = {"t4", "points", "sc", "delivery", "cli"} if args.extras == "all" else set(filter(None, args.extras.split(","))) - {"none"}
+    # ("cli" saves and reloads the index through the on-disk format -- minutes for the 5 M-site cohort: only when asked for by name)
+    extras = {"t4", "points", "sc", "delivery"} if args.extras == "all" else set(filter(None, args.extras.split(","))) - {"none"}
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -488,7 +530,53 @@ def main():
                 tsc["type5_variants_per_region"] = tot[1] / nsc
         vsc.close()
 
-    delivery = None   # (filled by the delivery legs)
+    # ---- delivery: what it costs to hand the batch's answer to the host (outside the timed region; the headline leaves results
+    #      in HBM).  (i) rows only, (ii) rows + carrier arena as ONE raw copy into page-locked memory, (iii) the streamed form
+    #      (chunks; the copy of one chunk runs beside the kernels of the next), (iv) the drop-in CLI timed by its own line ----
+    delivery = None
+    if "delivery" in extras and rank == 0:
+        PCIE_GBPS = 64.0   # PCIe 5.0 x16, per direction
+        warm = vs.get_var_in_ref(regions)
+        warm.raw(with_carriers=True)
+        warm.close()                      # (its page-locked buffer goes back to the handle's pool: allocation is not what is measured)
+        legs = {}
+        for name, wc in (("rows_only", False), ("rows_and_carriers", True)):
+            rr = vs.get_var_in_ref(regions)
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            raw = rr.raw(with_carriers=wc)
+            dt = time.perf_counter() - a
+            nbytes = raw["rows"].nbytes + (raw["arena"].nbytes if wc else 0) + 41 * nreg
+            legs[name] = {"bytes": int(nbytes), "ms": dt * 1e3, "GBps": nbytes / dt / 1e9, "frac_of_pcie5_x16": nbytes / dt / 1e9 / PCIE_GBPS}
+            del raw
+            rr.close()
+        # compute + copy, one after the other, per batch
+        a = time.perf_counter()
+        for _k in range(3):
+            rr = vs.get_var_in_ref(regions)
+            rr.raw(with_carriers=True)
+            rr.close()
+        legs["batch_then_copy_queries_per_s"] = 3 * nreg / (time.perf_counter() - a)
+        got = [0, 0]
+
+        def on_chunk(first, raw):
+            got[0] += int(raw.n_regions)
+            got[1] += int(raw.n_rows) * 32 + int(raw.arena_entries) * int(raw.carrier_bytes)
+
+        chunk = max(1, nreg // 8)
+        vs.stream_var_in_ref(regions, chunk, on_chunk)   # warm-up (second page-locked buffer)
+        got[:] = [0, 0]
+        a = time.perf_counter()
+        for _k in range(3):
+            vs.stream_var_in_ref(regions, chunk, on_chunk)
+        dt = (time.perf_counter() - a) / 3
+        assert got[0] == 3 * nreg
+        legs["streamed"] = {"chunk_regions": chunk, "queries_per_s": nreg / dt, "GBps": got[1] / 3 / dt / 1e9,
+                            "frac_of_pcie5_x16": got[1] / 3 / dt / 1e9 / PCIE_GBPS}
+        delivery = legs
+    if "cli" in extras and rank == 0:
+        delivery = delivery or {}
+        delivery["cli"] = cli_leg(vs, regions, w)
 
     if rank == 0:
         shard_note = (f"one sorted batch of {total_regions} regions cut into {world} contiguous shard(s)" if strong

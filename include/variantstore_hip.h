@@ -195,6 +195,48 @@ typedef struct {
   const char* seq_pool;          /* index-owned: one character per base */
 } vs_result_view;
 
+/* The RAW host copy: the result exactly as it lies in HBM -- per-region arrays, the variant table (32-byte rows) and, on
+ * request, the carrier arena -- copied with two transfers into page-locked memory owned by the result.  No repacking:
+ * region q reports rows [row_begin[q], row_begin[q] + row_count[q]) of the table (ranges of different regions overlap
+ * when `shared`), a row's carriers are arena[car_begin .. car_begin + VS_ROW_COUNT) in units of carrier_bytes
+ * (2: id | gt << 13, VS_CARRIER16_*; 4: id | gt << 29, VS_CARRIER_*).  This is the form to use when results leave the GPU
+ * in bulk; vs_result_get_view below expands it per region into the structure-of-arrays of round 1. */
+typedef struct {
+  uint32_t pos;                 /* Variant::var_pos */
+  uint32_t ref_off, ref_len;    /* Variant::ref = seq_pool[ref_off, ref_off + ref_len) */
+  uint32_t alt_off, alt_len;    /* Variant::alt likewise */
+  uint32_t count_flags;         /* VS_ROW_COUNT carriers | VS_ROW_DROPPED */
+  uint64_t car_begin;           /* first carrier of the row in the arena */
+} vs_variant_row;
+#define VS_ROW_COUNT(row) ((row).count_flags & 0x7FFFFFFFu)
+#define VS_ROW_DROPPED(row) ((row).count_flags >> 31)
+#define VS_CARRIER16_ID(c) ((uint32_t)(c) & 0x1FFFu)
+#define VS_CARRIER16_GT(c) ((uint32_t)(c) >> 13)
+typedef struct {
+  uint64_t n_regions;
+  const uint8_t* region_flags;   /* [n_regions] */
+  const uint64_t* row_begin;     /* [n_regions] first table row of each region */
+  const uint64_t* row_count;     /* [n_regions] rows it reports (including dropped ones) */
+  const uint64_t* var_count;     /* [n_regions] variants the reference reports */
+  const uint64_t* car_base;      /* [n_regions] arena offset of the region's first row */
+  const uint64_t* car_len;       /* [n_regions] arena extent of the region's rows */
+  uint64_t n_rows;
+  const vs_variant_row* rows;    /* [n_rows], page-locked */
+  uint64_t arena_entries;
+  uint32_t carrier_bytes;        /* 2 or 4 */
+  const void* arena;             /* [arena_entries], page-locked; NULL when carriers were not copied */
+  const char* seq_pool;
+  int shared;                    /* rows and lists shared between regions (vs_result_layout) */
+} vs_result_raw;
+int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw);
+
+/* Type 6 with delivery: the (sorted) batch is answered in chunks of `chunk_regions`, and while one chunk is computed the
+ * raw copy of the previous one crosses PCIe on a second stream into page-locked memory; `fn(user, first_region, raw)` is
+ * called once per chunk, in order, with a raw view that is valid during the call (return non-zero to stop). */
+typedef int (*vs_chunk_fn)(void* user, uint64_t first_region, const vs_result_raw* chunk);
+int vs_query_var_in_ref_stream(vs_index* idx, const vs_region* regions, uint64_t n, uint64_t chunk_regions, int with_carriers,
+                               vs_chunk_fn fn, void* user);
+
 /* Copy the result to host memory (owned by the vs_result).  with_carriers = 0
  * leaves the carrier lists in HBM (view->carriers == NULL). */
 int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view);

@@ -815,3 +815,64 @@ def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
         n, _, text = orc.get_var_in_ref(x, y) if x >= 1 else (-1, None, None)
         if n >= 0:
             assert a.region_text(q) == text, (q, x, y)
+
+
+def test_raw_copy_and_streamed_delivery(tmp_path):
+    """vs_result_get_raw hands the result over as it lies in HBM (variant table + arena, page-locked, no repacking);
+    vs_query_var_in_ref_stream delivers a sorted batch chunk by chunk while the next chunk is computed.  Both decode to
+    the rows of the structure-of-arrays view and to the oracle's text."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 707, n_rows=400, ref_len=6000, n_samples=90, carrier_p=0.35,
+                                        p_near=0.5, p_multi=0.2, p_same=0.2)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    names = [vs.sample_name(i) for i in range(vs.info().num_samples)]
+    regions = sorted(random_regions(np.random.default_rng(8), vs.info().ref_length, 600, max_len=700))
+    want = [orc.get_var_in_ref(x, y) for x, y in regions]
+
+    def decode(raw, k, seq_pool):
+        """text of region k of a raw view (python dict or ctypes struct fields as arrays)"""
+        rows = raw["rows"][int(raw["row_begin"][k]):int(raw["row_begin"][k]) + int(raw["row_count"][k])]
+        out = ["Pos\tRef\tAlt\tSamples\n"]
+        for v in rows:
+            if v["count_flags"] >> 31:
+                continue
+            cnt, cb = int(v["count_flags"]) & 0x7FFFFFFF, int(v["car_begin"])
+            cars = raw["arena"][cb:cb + cnt].astype(np.uint32)
+            ids, gts = (cars & 0x1FFF, cars >> 13) if raw["carrier_bytes"] == 2 else (cars & 0x1FFFFFFF, cars >> 29)
+            ref = seq_pool[int(v["ref_off"]):int(v["ref_off"]) + int(v["ref_len"])]
+            alt = seq_pool[int(v["alt_off"]):int(v["alt_off"]) + int(v["alt_len"])]
+            samples = "".join(f"{names[i]}({(g >> 1) & 1}{'|' if g & 1 else '/'}{(g >> 2) & 1}) " for i, g in zip(ids, gts))
+            out.append(f"{int(v['pos'])}\t{ref}\t{alt}\t{samples}\n")
+        return "".join(out)
+
+    res = vs.get_var_in_ref(regions)
+    assert res.layout()[4]
+    raw = res.raw(with_carriers=True)
+    assert raw["shared"] and raw["carrier_bytes"] == 2 and len(raw["rows"]) == res.layout()[1]
+    # the sequence pool: decode REF/ALT through the texts of the view for a few regions instead of exposing it twice
+    import ctypes as C
+    from variantstore_amd._lib import ResultRaw
+    rr = ResultRaw()
+    assert vs._lib.vs_result_get_raw(res._h, 1, C.byref(rr)) == 0
+    pool = C.string_at(rr.seq_pool, int(raw["rows"]["ref_off"].max()) + int(raw["rows"]["ref_len"].max()) + 64).decode("latin-1")
+    for k in range(0, len(regions), 7):
+        if want[k][0] >= 0:
+            assert decode(raw, k, pool) == want[k][2] == res.region_text(k), k
+    assert np.array_equal(raw["var_count"], res.view(False)["var_count"])
+    # streamed: chunks of 100 regions, each decoded inside its callback
+    seen = []
+
+    def on_chunk(first, chunk):
+        q, a, s = int(chunk.n_regions), int(chunk.n_rows), int(chunk.arena_entries)
+        view = {"row_begin": np.ctypeslib.as_array(chunk.row_begin, shape=(q,)), "row_count": np.ctypeslib.as_array(chunk.row_count, shape=(q,)),
+                "rows": np.ctypeslib.as_array(C.cast(chunk.rows, C.POINTER(C.c_uint8)), shape=(a * 32,)).view(res.ROW_DTYPE),
+                "arena": np.ctypeslib.as_array(C.cast(chunk.arena, C.POINTER(C.c_uint16)), shape=(max(s, 1),)), "carrier_bytes": int(chunk.carrier_bytes)}
+        for k in range(q):
+            if want[first + k][0] >= 0:
+                assert decode(view, k, pool) == want[first + k][2], first + k
+        seen.append((first, q))
+
+    vs.stream_var_in_ref(regions, 100, on_chunk)
+    assert seen == [(i, 100) for i in range(0, 600, 100)]
+    seen.clear()
+    vs.stream_var_in_ref(regions[:250], 100, on_chunk)
+    assert seen == [(0, 100), (100, 100), (200, 50)]

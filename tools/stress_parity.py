@@ -16,7 +16,7 @@ from variantstore_amd import VariantStore  # noqa: E402
 
 n_cohorts = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-bad = hang = ub = checked = slow_regions = 0
+bad = hang = ub = checked = slow_regions = shared_batches = 0
 for c in range(n_cohorts):
     seed = seed0 + c
     rng = np.random.default_rng(seed)
@@ -57,6 +57,21 @@ for c in range(n_cohorts):
                 bad += 1
                 print(f"MISMATCH t6 cohort {seed} region {x}:{y}\n--- gpu\n{res.region_text(q)}--- oracle\n{text}")
         slow_regions += int((flags["var_count"] != np.diff(flags["var_begin"].astype(np.int64))).sum())
+        # the same regions sorted: the batch then shares one row and one carrier list per covered site between its regions
+        order = sorted(range(len(regions)), key=lambda i: regions[i])
+        rsh = vs.get_var_in_ref([regions[i] for i in order])
+        shared_batches += int(rsh.layout()[4])
+        for k, i in enumerate(order):
+            if orc.get_var_in_ref(*regions[i])[0] < 0:
+                continue
+            checked += 1
+            if rsh.region_text(k) != res.region_text(i):
+                bad += 1
+                print(f"MISMATCH t6 shared-lists batch cohort {seed} region {regions[i]}")
+        if rsh.digest() != vs.get_var_in_ref([regions[i] for i in order][:64] + [regions[i] for i in order][64:]).digest():
+            bad += 1
+            print(f"MISMATCH digest of the shared batch, cohort {seed}")
+        rsh.close()
         # the same regions again through the single-launch latency path (up to 64 regions: kernel-argument forms of 8
         # and 64 regions) and a 70-region batch through the general path
         for lo, hi in ((0, 1), (1, 4), (4, 12), (12, 76), (20, 21), (30, 100)):
@@ -71,6 +86,23 @@ for c in range(n_cohorts):
                     bad += 1
                     print(f"MISMATCH t6 small batch cohort {seed} region {x}:{y}")
             rs.close()
+        # type 4 with one sample per region, through the cooperative walk, the serial walk and the literal (no-jump) walk
+        per = [names[int(i)] for i in rng.integers(0, len(names), size=100)]
+        want4 = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(regions[:100], per)]
+        for coop, skip in ((1, 1), (0, 1), (0, 0)):
+            vs.set_option("t4_coop", coop)
+            vs.set_option("t4_skip", skip)
+            rm = vs.get_sample_var_in_ref(regions[:100], per)
+            for q, (n, early, text) in enumerate(want4):
+                if n < 0:
+                    continue
+                checked += 1
+                if rm.region_text(q) != text:
+                    bad += 1
+                    print(f"MISMATCH t4 (coop {coop} skip {skip}) cohort {seed} sample {per[q]} region {regions[q]}")
+            rm.close()
+        vs.set_option("t4_coop", 1)
+        vs.set_option("t4_skip", 1)
         sample = names[int(rng.integers(0, len(names)))]
         r4 = vs.get_sample_var_in_ref(regions[:60], sample)
         for q, (x, y) in enumerate(regions[:60]):
@@ -136,5 +168,5 @@ for c in range(n_cohorts):
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
-      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions}")
+      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions} batches with shared rows/lists {shared_batches}")
 sys.exit(1 if bad else 0)

@@ -47,6 +47,22 @@ class ResultView(C.Structure):
                 ("carriers", C.POINTER(C.c_uint32)), ("seq_pool", C.c_void_p)]
 
 
+class VariantRow(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("ref_off", C.c_uint32), ("ref_len", C.c_uint32), ("alt_off", C.c_uint32),
+                ("alt_len", C.c_uint32), ("count_flags", C.c_uint32), ("car_begin", C.c_uint64)]
+
+
+class ResultRaw(C.Structure):
+    _fields_ = [("n_regions", C.c_uint64), ("region_flags", C.POINTER(C.c_uint8)), ("row_begin", C.POINTER(C.c_uint64)),
+                ("row_count", C.POINTER(C.c_uint64)), ("var_count", C.POINTER(C.c_uint64)), ("car_base", C.POINTER(C.c_uint64)),
+                ("car_len", C.POINTER(C.c_uint64)), ("n_rows", C.c_uint64), ("rows", C.POINTER(VariantRow)),
+                ("arena_entries", C.c_uint64), ("carrier_bytes", C.c_uint32), ("arena", C.c_void_p), ("seq_pool", C.c_void_p),
+                ("shared", C.c_int)]
+
+
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(ResultRaw))
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_bounds", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
                 ("ms_fill", C.c_float), ("fill_launches", C.c_uint64)]
@@ -83,6 +99,8 @@ SYMBOLS = {
     "vs_index_draw_subgraph": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p]),
     "vs_index_find": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),
     "vs_result_get_view": (C.c_int, [_P, C.c_int, C.POINTER(ResultView)]),
+    "vs_result_get_raw": (C.c_int, [_P, C.c_int, C.POINTER(ResultRaw)]),
+    "vs_query_var_in_ref_stream": (C.c_int, [_P, C.POINTER(Region), C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "vs_result_totals": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64)]),
     "vs_result_format_region": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),

@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import ConstructStats, IndexInfo, Region, ResultView, SynthParams, Timing
+from ._lib import ConstructStats, IndexInfo, Region, ResultRaw, ResultView, SynthParams, Timing
 
 REGION_EMPTY = 1
 REGION_INVALID = 2
@@ -119,6 +119,33 @@ class QueryResult:
             "car_begin": arr(rv.car_begin, a, np.uint64), "car_count": arr(rv.car_count, a, np.uint32),
             "carriers": arr(rv.carriers, s, np.uint32) if with_carriers else None,
         }
+
+    ROW_DTYPE = np.dtype([("pos", "<u4"), ("ref_off", "<u4"), ("ref_len", "<u4"), ("alt_off", "<u4"), ("alt_len", "<u4"),
+                          ("count_flags", "<u4"), ("car_begin", "<u8")])
+
+    def raw(self, with_carriers=True):
+        """The result as it lies in HBM, copied once into page-locked memory (vs_result_get_raw): numpy VIEWS (no copy; valid
+        until the result is closed) of the per-region arrays, the variant table (structured rows) and the carrier arena
+        (uint16 words id | gt << 13 for cohorts of at most 4032 samples, else uint32 id | gt << 29)."""
+        rr = ResultRaw()
+        _check(self._lib.vs_result_get_raw(self._h, 1 if with_carriers else 0, C.byref(rr)), "vs_result_get_raw")
+        q, a, s = int(rr.n_regions), int(rr.n_rows), int(rr.arena_entries)
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,))
+
+        rows = (np.ctypeslib.as_array(C.cast(rr.rows, C.POINTER(C.c_uint8)), shape=(a * 32,)).view(self.ROW_DTYPE)
+                if a else np.zeros(0, self.ROW_DTYPE))
+        arena = None
+        if with_carriers and rr.arena:
+            ct = C.c_uint16 if rr.carrier_bytes == 2 else C.c_uint32
+            arena = np.ctypeslib.as_array(C.cast(rr.arena, C.POINTER(ct)), shape=(s,)) if s else np.zeros(0, np.uint16)
+        return {"region_flags": arr(rr.region_flags, q, np.uint8), "row_begin": arr(rr.row_begin, q, np.uint64),
+                "row_count": arr(rr.row_count, q, np.uint64), "var_count": arr(rr.var_count, q, np.uint64),
+                "car_base": arr(rr.car_base, q, np.uint64), "car_len": arr(rr.car_len, q, np.uint64),
+                "rows": rows, "arena": arena, "carrier_bytes": int(rr.carrier_bytes), "shared": bool(rr.shared)}
 
     def num_header_records(self):
         n = C.c_uint64()
@@ -283,6 +310,19 @@ class VariantStore:
         if rc != 0:
             raise VariantStoreError(rc, "vs_query_var_in_ref")
         return QueryResult(self, h)
+
+    def stream_var_in_ref(self, regions, chunk_regions, on_chunk, with_carriers=True):
+        """Query type 6 with delivery (vs_query_var_in_ref_stream): `on_chunk(first_region, raw)` is called per chunk with the
+        ctypes ResultRaw of that chunk (valid during the call) while the next chunk is being computed."""
+        arr, ptr, n = _regions_array(regions)
+
+        def tramp(_user, first, raw):
+            on_chunk(int(first), raw.contents)
+            return 0
+
+        cb = _lib.CHUNK_FN(tramp)
+        _check(self._lib.vs_query_var_in_ref_stream(self._h, ptr, n, int(chunk_regions), 1 if with_carriers else 0,
+                                                    C.cast(cb, C.c_void_p), None), "vs_query_var_in_ref_stream")
 
     def get_var_in_ref_device(self, device_ptr, n) -> QueryResult:
         """Query type 6 over n (pos_x, pos_y) uint64 pairs that already live in this GPU's memory (`device_ptr`: an

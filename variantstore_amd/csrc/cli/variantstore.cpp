@@ -11,6 +11,9 @@
 //   --batch-out FILE    rows of ALL regions ("#region <i> <x>:<y>" before each), since the
 //                       reference's -o file only ever holds the last region (query.h:774-781)
 //   --device N          GPU ordinal (default 0)
+//   --ngpus N           shard the sorted region list over GPUs device .. device + N - 1 (query types 4, 5, 6): one handle
+//                       and one host thread per GPU, contiguous shards (the reference's serial loop, commands.cc:145,
+//                       carries no state between regions), results printed in region order
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <algorithm>
@@ -22,6 +25,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 #include "variantstore_hip.h"
@@ -96,7 +100,7 @@ struct Args {
   uint64_t hops = 0;
   bool have_hops = false;
   bool have_type = false, have_mode = false, verbose = false;
-  int device = 0;
+  int device = 0, ngpus = 1;
 };
 
 int usage() {
@@ -104,7 +108,7 @@ int usage() {
                "        variantstore construct -r <reference-file> -v <vcf-file> -p <output-prefix>\n"
                "        variantstore query -p <output-prefix> -t <query-type> -r <region> -m <mode> [-o <outfile>]\n"
                "                     [-s <sample-name>] [-a <alt-seq>] [-b <ref-seq>] [-v]\n"
-               "                     [--batch-out <file>] [--device <n>]\n"
+               "                     [--batch-out <file>] [--device <n>] [--ngpus <n>]\n"
                "        variantstore draw -p <output-prefix> -r <region> -h <hops> [-s <sample-name>]\n"
                "        variantstore help\n\n"
                "OPTIONS\n"
@@ -324,69 +328,97 @@ int query_main(const Args& a) {
   }
   std::vector<vs_region> batch;
   for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
-  vs_result* res = nullptr;
   if (a.type == 1 || a.type == 7) return point_query_main(a, idx, batch);
   if (a.type == 2 || a.type == 3) return sequence_query_main(a, idx, batch);
-  if (a.type == 6) rc = vs_query_var_in_ref(idx, batch.data(), batch.size(), &res);
-  else {
-    uint32_t sid = 0;
-    rc = vs_index_sample_id(idx, a.sample.c_str(), &sid);
-    if (rc != VS_OK) { error("Sample not found"); abort(); }  // variant_graph.h:2010-2013
-    if (a.type == 4) rc = vs_query_sample_var_in_ref(idx, batch.data(), batch.size(), sid, &res);
-    else {
-      std::vector<uint32_t> sids(batch.size(), sid);
-      rc = vs_query_sample_var_in_sample(idx, batch.data(), batch.size(), sids.data(), &res);
-    }
+  uint32_t sid = 0;
+  if (a.type != 6 && vs_index_sample_id(idx, a.sample.c_str(), &sid) != VS_OK) { error("Sample not found"); abort(); }  // variant_graph.h:2010-2013
+  // ---- shards: one per GPU (--ngpus), contiguous pieces of the sorted list ----
+  const int ng = (int)std::min<size_t>((size_t)a.ngpus, std::max<size_t>(batch.size(), 1));
+  struct Shard { vs_index* idx = nullptr; size_t lo = 0, hi = 0; vs_result* res = nullptr; vs_result_view v{}; int rc = VS_OK; std::string err; };
+  std::vector<Shard> shards(ng);
+  shards[0].idx = idx;
+  for (int g = 0; g < ng; ++g) {
+    const size_t base = batch.size() / ng, rem = batch.size() % ng;
+    shards[g].lo = g * base + std::min<size_t>(g, rem);
+    shards[g].hi = shards[g].lo + base + ((size_t)g < rem ? 1 : 0);
   }
-  if (rc != VS_OK) die(rc, "query");
-  vs_result_view v;
-  rc = vs_result_get_view(res, 0, &v);
-  if (rc != VS_OK) die(rc, "result");
+  auto run_shard = [&](Shard& sh, int g) {
+    if (!sh.idx) {
+      sh.rc = vs_index_open(a.prefix.c_str(), a.device + g, &sh.idx);
+      if (sh.rc != VS_OK) { sh.err = vs_last_error(); return; }
+    }
+    const vs_region* rg = batch.data() + sh.lo;
+    const uint64_t n = sh.hi - sh.lo;
+    if (a.type == 6) sh.rc = vs_query_var_in_ref(sh.idx, rg, n, &sh.res);
+    else if (a.type == 4) sh.rc = vs_query_sample_var_in_ref(sh.idx, rg, n, sid, &sh.res);
+    else {
+      std::vector<uint32_t> sids(n, sid);
+      sh.rc = vs_query_sample_var_in_sample(sh.idx, rg, n, sids.data(), &sh.res);
+    }
+    if (sh.rc == VS_OK) sh.rc = vs_result_get_view(sh.res, 0, &sh.v);
+    // the text of every region is wanted: bring rows and carriers over in ONE raw copy (not one copy per region)
+    if (sh.rc == VS_OK && !a.batch_out.empty()) { vs_result_raw raw; sh.rc = vs_result_get_raw(sh.res, 1, &raw); }
+    if (sh.rc != VS_OK) sh.err = vs_last_error();
+  };
+  if (ng == 1) run_shard(shards[0], 0);
+  else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < ng; ++g) th.emplace_back(run_shard, std::ref(shards[g]), g);
+    for (auto& t : th) t.join();
+  }
+  for (auto& sh : shards)
+    if (sh.rc != VS_OK) { error(std::string("query: ") + vs_strerror(sh.rc) + ": " + sh.err); abort(); }
   gettimeofday(&end, nullptr);
 
   std::ofstream batch_out;
   if (!a.batch_out.empty()) batch_out.open(a.batch_out);
   uint32_t query_num = 0;
-  for (uint64_t i = 0; i < v.n_regions; ++i) {
-    if (a.type == 6) info("6. Get variants in ref coordinate. " + std::to_string(i));
-    else if (a.type == 5) info("5. Get sample's variants in sample coordinate. " + std::to_string(i));
-    else info("4. Get sample's variants in ref coordinate. " + std::to_string(i));
-    if (v.region_flags[i] & VS_REGION_ENDLESS) {
-      error("the reference's backward search does not terminate on region " + std::to_string(batch[i].x) + ":" + std::to_string(batch[i].y));
-      return EXIT_FAILURE;
-    }
-    if (v.region_flags[i] & VS_REGION_INVALID) {  // index.h:151-154
-      error("Can't find node corresponding to pos " + std::to_string(batch[i].x));
-      abort();
-    }
-    // query.h:746 prints the type-4 label on the early-out of type 6 as well
-    const char* label = (a.type == 6 && !(v.region_flags[i] & VS_REGION_EMPTY)) ? "get_var_in_ref" : "get_sample_var_in_ref";
-    if (a.type == 5) label = "get_sample_var_in_sample";  // query.h:599
-    std::cout << "Number of variants " << label << ": " << v.var_count[i] << '\n';
-    if (batch_out.is_open()) {
-      const char* text; uint64_t len;
-      if (vs_result_format_region(res, i, &text, &len) == VS_OK) {
-        batch_out << "#region " << i << " " << batch[i].x << ":" << batch[i].y << "\n";
-        batch_out.write(text, len);
+  for (auto& sh : shards) {
+    const vs_result_view& v = sh.v;
+    for (uint64_t k = 0; k < v.n_regions; ++k) {
+      const uint64_t i = sh.lo + k;
+      if (a.type == 6) info("6. Get variants in ref coordinate. " + std::to_string(i));
+      else if (a.type == 5) info("5. Get sample's variants in sample coordinate. " + std::to_string(i));
+      else info("4. Get sample's variants in ref coordinate. " + std::to_string(i));
+      if (v.region_flags[k] & VS_REGION_ENDLESS) {
+        error("the reference's backward search does not terminate on region " + std::to_string(batch[i].x) + ":" + std::to_string(batch[i].y));
+        return EXIT_FAILURE;
       }
-    }
-    if (a.verbose && i + 1 == v.n_regions) {  // the -o file is reopened (truncated) per region: the last one stays
-      const char* text; uint64_t len;
-      if (vs_result_format_region(res, i, &text, &len) == VS_OK) {
-        std::ofstream out;
-        out.open(a.outfile);
-        out.write(text, len);
+      if (v.region_flags[k] & VS_REGION_INVALID) {  // index.h:151-154
+        error("Can't find node corresponding to pos " + std::to_string(batch[i].x));
+        abort();
       }
+      // query.h:746 prints the type-4 label on the early-out of type 6 as well
+      const char* label = (a.type == 6 && !(v.region_flags[k] & VS_REGION_EMPTY)) ? "get_var_in_ref" : "get_sample_var_in_ref";
+      if (a.type == 5) label = "get_sample_var_in_sample";  // query.h:599
+      std::cout << "Number of variants " << label << ": " << v.var_count[k] << '\n';
+      if (batch_out.is_open()) {
+        const char* text; uint64_t len;
+        if (vs_result_format_region(sh.res, k, &text, &len) == VS_OK) {
+          batch_out << "#region " << i << " " << batch[i].x << ":" << batch[i].y << "\n";
+          batch_out.write(text, len);
+        }
+      }
+      if (a.verbose && i + 1 == batch.size()) {  // the -o file is reopened (truncated) per region: the last one stays
+        const char* text; uint64_t len;
+        if (vs_result_format_region(sh.res, k, &text, &len) == VS_OK) {
+          std::ofstream out;
+          out.open(a.outfile);
+          out.write(text, len);
+        }
+      }
+      query_num += 1;
+      if (query_num == 10 || query_num == 100 || query_num == 1000)
+        print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
     }
-    query_num += 1;
-    if (query_num == 10 || query_num == 100 || query_num == 1000)
-      print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
   }
   std::string dsc = "Query" + std::to_string(query_num) + ": ";
   if (a.type == 6) dsc.append("(query_var_in_ref) ");
   print_time_elapsed(dsc, start, end);
-  vs_result_free(res);
-  vs_index_close(idx);
+  for (auto& sh : shards) {
+    vs_result_free(sh.res);
+    vs_index_close(sh.idx);
+  }
   return EXIT_SUCCESS;
 }
 
@@ -425,6 +457,7 @@ int main(int argc, char** argv) {
       else if (f == "-v" || f == "--verbose") a.verbose = true;
       else if (f == "--batch-out") a.batch_out = need(i);
       else if (f == "--device") a.device = atoi(need(i).c_str());
+      else if (f == "--ngpus") a.ngpus = std::max(1, atoi(need(i).c_str()));
       else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
     }
   }

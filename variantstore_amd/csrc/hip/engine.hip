@@ -80,6 +80,8 @@ struct vs_index {
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
   std::vector<DevBuf> pool;
+  std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
+  hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
   vs_timing timing{};
   vs_construct_stats cstats{};
   uint64_t live_results = 0;
@@ -129,6 +131,10 @@ struct vs_result {
   std::vector<uint64_t> h_car_len;
   // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
   std::vector<VariantRow> sl_rows;
+  // the RAW host copy (vs_result_get_raw): variant table and arena exactly as they lie in HBM, in page-locked memory
+  DevBuf raw_pin{nullptr, 0};
+  const VariantRow* raw_rows = nullptr;
+  const uint8_t* raw_arena = nullptr;   // NULL: carriers not copied
   int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line); 2 / 3: sequences
   // sequence results (query types 2 and 3)
   DevSeqResult sq{};
@@ -237,6 +243,31 @@ static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
       if (idx->pool[i].cap < idx->pool[k].cap) k = i;
     (void)hipFree(idx->pool[k].p);
     idx->pool.erase(idx->pool.begin() + k);
+  }
+}
+
+// Page-locked host memory for raw result copies: allocating it costs as much as copying into it, so buffers go back to a
+// small per-handle pool when their result is freed.
+static int pin_alloc(vs_index* idx, size_t bytes, DevBuf* out) {
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  int best = -1;
+  for (size_t i = 0; i < idx->pin_pool.size(); ++i)
+    if (idx->pin_pool[i].cap >= bytes && (best < 0 || idx->pin_pool[i].cap < idx->pin_pool[best].cap)) best = (int)i;
+  if (best >= 0) { *out = idx->pin_pool[best]; idx->pin_pool.erase(idx->pin_pool.begin() + best); return VS_OK; }
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  *out = DevBuf{p, bytes};
+  return VS_OK;
+}
+static void pin_release(vs_index* idx, DevBuf b) {
+  if (!b.p) return;
+  idx->pin_pool.push_back(b);
+  while (idx->pin_pool.size() > 4) {   // keep the largest few
+    size_t k = 0;
+    for (size_t i = 1; i < idx->pin_pool.size(); ++i)
+      if (idx->pin_pool[i].cap < idx->pin_pool[k].cap) k = i;
+    (void)hipHostFree(idx->pin_pool[k].p);
+    idx->pin_pool.erase(idx->pin_pool.begin() + k);
   }
 }
 
@@ -1163,6 +1194,8 @@ void vs_index_close(vs_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     for (auto p : idx->image_allocs) (void)hipFree(p);
     for (auto& b : idx->pool) (void)hipFree(b.p);
+    for (auto& b : idx->pin_pool) (void)hipHostFree(b.p);
+    if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     if (idx->pinned) (void)hipHostFree(idx->pinned);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1338,6 +1371,7 @@ void vs_result_free(vs_result* r) {
   if (r->idx) {
     (void)hipSetDevice(r->idx->device);
     release_bufs(r->idx, r->bufs);
+    pin_release(r->idx, r->raw_pin);
     r->idx->live_results--;
     if (r->idx->close_pending && r->idx->live_results == 0) vs_index_close(r->idx);
   }
@@ -1548,6 +1582,98 @@ int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vert
 }
 
 // ---------------------------------------------------------------- result access
+// Start (stream) the raw copy of a result: rows and -- on request -- the arena go into one page-locked block.
+static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) {
+  vs_index* idx = r->idx;
+  const DevResult& d = r->d;
+  const size_t row_bytes = (size_t)d.A * sizeof(VariantRow), arena_bytes = with_carriers ? (size_t)d.S * d.car_width : 0;
+  if (r->raw_rows && (r->raw_arena || !with_carriers)) return VS_OK;
+  if (r->raw_pin.p) { pin_release(idx, r->raw_pin); r->raw_pin = DevBuf{nullptr, 0}; r->raw_rows = nullptr; r->raw_arena = nullptr; }
+  VS_TRY(pin_alloc(idx, row_bytes + arena_bytes + 64, &r->raw_pin));
+  uint8_t* base = (uint8_t*)r->raw_pin.p;
+  if (row_bytes) HIP_TRY(hipMemcpyAsync(base, d.rows, row_bytes, hipMemcpyDeviceToHost, stream));
+  const size_t arena_at = (row_bytes + 63) & ~(size_t)63;
+  if (arena_bytes) HIP_TRY(hipMemcpyAsync(base + arena_at, d.carriers, arena_bytes, hipMemcpyDeviceToHost, stream));
+  r->raw_rows = (const VariantRow*)base;
+  r->raw_arena = with_carriers ? base + arena_at : nullptr;
+  return VS_OK;
+}
+static void fill_raw(vs_result* r, vs_result_raw* raw) {
+  raw->n_regions = r->d.Q;
+  raw->region_flags = r->h_flags.data();
+  raw->row_begin = r->h_var_begin.data();
+  raw->row_count = r->h_nvar.data();
+  raw->var_count = r->h_var_count.data();
+  raw->car_base = r->h_car_base.data();
+  raw->car_len = r->h_car_len.data();
+  raw->n_rows = r->d.A;
+  raw->rows = (const vs_variant_row*)r->raw_rows;
+  raw->arena_entries = r->d.S;
+  raw->carrier_bytes = r->d.car_width;
+  raw->arena = r->raw_arena;
+  raw->seq_pool = r->idx->seq_chars.data();
+  raw->shared = r->shared_lists ? 1 : 0;
+}
+
+int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw) {
+  if (r) { VS_NOT_SEQ(r); }
+  if (!r || !raw) return fail(VS_ERR_ARG, "null argument");
+  static_assert(sizeof(vs_variant_row) == sizeof(VariantRow), "row layout of the ABI");
+  vs_index* idx = r->idx;
+  HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(raw_copy_begin(r, with_carriers != 0, idx->stream));
+  VS_TRY(fetch_region_meta(r));   // (synchronises the stream)
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  fill_raw(r, raw);
+  return VS_OK;
+}
+
+// Type 6 over a large batch with the results leaving the GPU as they are produced: the batch is cut into chunks of
+// `chunk_regions`; while chunk k + 1 is computed, the raw copy of chunk k (rows + carrier arena) crosses PCIe on a
+// second stream into one of two page-locked buffers, and `fn` is called with it.  The regions must be sorted for the
+// chunks to share rows and lists (each chunk is a batch of its own).
+int vs_query_var_in_ref_stream(vs_index* idx, const vs_region* regions, uint64_t n, uint64_t chunk_regions, int with_carriers,
+                               vs_chunk_fn fn, void* user) {
+  if (!idx || (n && !regions) || !fn) return fail(VS_ERR_ARG, "null argument");
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
+  if (chunk_regions == 0) return fail(VS_ERR_ARG, "chunk_regions must be positive");
+  HIP_TRY(hipSetDevice(idx->device));
+  if (!idx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+  vs_result* in_flight = nullptr;   // chunk whose copy is under way
+  uint64_t in_flight_first = 0;
+  int rc = VS_OK;
+  auto deliver = [&]() -> int {
+    if (!in_flight) return VS_OK;
+    int rcd = VS_OK;
+    if (hipStreamSynchronize(idx->copy_stream) != hipSuccess) rcd = fail(VS_ERR_HIP, "copy of a result chunk failed");
+    if (rcd == VS_OK) {
+      vs_result_raw raw;
+      fill_raw(in_flight, &raw);
+      if (fn(user, in_flight_first, &raw) != 0) rcd = fail(VS_ERR_ARG, "the chunk callback asked to stop");
+    }
+    vs_result_free(in_flight);
+    in_flight = nullptr;
+    return rcd;
+  };
+  for (uint64_t first = 0; first < n && rc == VS_OK; first += chunk_regions) {
+    const uint64_t cn = std::min<uint64_t>(chunk_regions, n - first);
+    vs_result* r = new vs_result();
+    r->idx = idx;
+    idx->live_results++;
+    rc = run_var_in_ref(idx, regions + first, cn, r);   // (returns with the chunk's kernels complete; the previous chunk's copy ran beside them)
+    if (rc == VS_OK) rc = fetch_region_meta(r);
+    if (rc != VS_OK) { drop_result(r, rc); break; }
+    const int rcd = deliver();                           // the previous chunk
+    if (rcd != VS_OK) { vs_result_free(r); rc = rcd; break; }
+    rc = raw_copy_begin(r, with_carriers != 0, idx->copy_stream);
+    if (rc != VS_OK) { vs_result_free(r); break; }
+    in_flight = r;
+    in_flight_first = first;
+  }
+  const int rcd = deliver();
+  return rc != VS_OK ? rc : rcd;
+}
+
 int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
   if (r) { VS_NOT_SEQ(r); }
   if (!r || !view) return fail(VS_ERR_ARG, "null argument");
@@ -1635,28 +1761,43 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   const uint64_t c0 = r->h_car_base[q], c1 = c0 + r->h_car_len[q];
   const uint32_t* car = nullptr;
   const bool from_view = r->have_carriers;
-  // the rows: the whole table when a view has already brought it over, otherwise this region's slice of it
+  const bool from_raw = !from_view && r->raw_rows && r->raw_arena;   // a raw copy holds rows and arena: nothing to fetch
+  // the rows: the whole table when a view or a raw copy has already brought it over, otherwise this region's slice of it
   const VariantRow* rows;
   if (r->have_headers) rows = r->h_rows.data() + a0;
+  else if (r->raw_rows) rows = r->raw_rows + a0;
   else {
     VS_TRY(fetch(idx, r->sl_rows, (const VariantRow*)r->d.rows + a0, (size_t)(a1 - a0)));
     if (a1 == a0) HIP_TRY(hipStreamSynchronize(idx->stream));   // (fetch_carriers below synchronises otherwise)
     rows = r->sl_rows.data();
   }
   const uint64_t vbase = r->have_headers ? r->h_view_begin[q] : 0;   // slot of the region's first row in the view
-  if (!from_view) {
+  if (!from_view && !from_raw) {
     VS_TRY(fetch_carriers(r, c0, c1 - c0, r->slice_carriers));
     car = r->slice_carriers.data();
   }
+  const uint16_t* raw16 = reinterpret_cast<const uint16_t*>(r->raw_arena);
+  const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(r->raw_arena);
+  const bool narrow = r->d.car_width == 2;
+  // carrier k of row v as id | gt << 29, from whichever host copy there is
+  auto carrier = [&](const VariantRow& v, uint64_t slot, uint32_t k) -> uint32_t {
+    if (from_view) return r->h_carriers[r->h_car_begin_view[slot] + k];
+    if (from_raw) {
+      if (!narrow) return raw32[v.car_begin + k];
+      const uint32_t c = raw16[v.car_begin + k];
+      return (c & 0x1FFFu) | ((c >> 13) << 29);
+    }
+    return car[(v.car_begin - c0) + k];
+  };
   std::string& out = r->text;
   out.clear();
   if (r->kind == 7) {  // samples_has_var's output line, query.h:811-816: `name gt` pairs with nothing between them
     for (uint64_t a = a0; a < a1; ++a) {
       const VariantRow& v = rows[a - a0];
       if (v.count_flags & kRowDropped) continue;
-      const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[vbase + (a - a0)] : car + (v.car_begin - c0);
       for (uint32_t k = 0; k < v.count_flags; ++k) {
-        const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
+        const uint32_t cw = carrier(v, vbase + (a - a0), k);
+        const uint32_t id = VS_CARRIER_ID(cw), gt = VS_CARRIER_GT(cw);
         out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
         out += ' ';
         out += (gt & GT_1) ? '1' : '0';
@@ -1684,9 +1825,9 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
     out += '\t';
     out.append(idx->seq_chars, v.alt_off, v.alt_len);
     out += '\t';
-    const uint32_t* c = from_view ? r->h_carriers.data() + r->h_car_begin_view[vbase + (a - a0)] : car + (v.car_begin - c0);
     for (uint32_t k = 0; k < v.count_flags; ++k) {
-      const uint32_t id = VS_CARRIER_ID(c[k]), gt = VS_CARRIER_GT(c[k]);
+      const uint32_t cw = carrier(v, vbase + (a - a0), k);
+      const uint32_t id = VS_CARRIER_ID(cw), gt = VS_CARRIER_GT(cw);
       out += id < idx->g.sample_names.size() ? idx->g.sample_names[id] : std::string("?");
       out += '(';
       out += (gt & GT_1) ? '1' : '0';   // get_sample_phasing, variant_graph.h:882-900
