@@ -80,6 +80,8 @@ struct vs_index {
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
   std::vector<DevBuf> pool;
+  unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
+  uint64_t t4_gen = 0;
   std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
   hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
   vs_timing timing{};
@@ -128,6 +130,7 @@ struct vs_result {
   bool shared_lists = false;          // rows and carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
   uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the rows
   uint64_t n_rows_reported = 0;       // rows over all regions (shared rows counted once per region that reports them)
+  bool scattered_lists = false;       // lists shared per vertex (walking query types): a region's carriers are not one arena range
   std::vector<uint64_t> h_car_len;
   // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
   std::vector<VariantRow> sl_rows;
@@ -503,6 +506,14 @@ static size_t fill_lds_bytes(const vs_index* idx) {
   return 4 * (size_t)(idx->d.wpc <= 63 ? slice_lds_words(idx->d.num_samples) : fill_gt_words(idx) + kRingWords) * 4;
 }
 
+// one launch of the carrier expansion: over the rows of a private-row result or over the shared rows of a sorted batch
+template <bool WIDE, uint32_t CH, bool TUNE>
+static void launch_fill(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill, unsigned blocks, size_t lds_bytes,
+                        uint32_t ablate, uint32_t gt_words) {
+  if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_site, n_fill, ablate, gt_words);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+}
+
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
@@ -536,6 +547,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   // Type 4, single walk: capacities from the type-6 bounds of the same regions, one recording walk, headers from
   // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
   WalkScratch ws{};
+  uint64_t ws_capacity = 0;
   bool single_walk = false;
   DevImage dwalk = idx->d;   // what the type-4 walk sees: with or without the event bitmaps
   if (!idx->opts.t4_skip) dwalk.t4_events = nullptr;
@@ -548,6 +560,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     uint64_t cap_total = 0;
     HIP_TRY(hipMemcpyAsync(&cap_total, cap_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
+    ws_capacity = cap_total;
     ws.cap_begin = cap_begin;
     VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch.bufs));
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.cur, &scratch.bufs));
@@ -630,15 +643,40 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       HIP_TRY(hipGetLastError());
     }
   }
+  ListClaims lc{};
+  bool share_t4 = false;   // type 4, recording walk: one carrier list per reported VERTEX, shared by the rows that report it
+  uint64_t t4_arena = 0;
   if (!share) {
   VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
+  if (single_walk && walk_mode != 5 && idx->opts.share_lists && n > 64) {
+    // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
+    const uint64_t cap_rows = ws_capacity;
+    if (!idx->t4_claim) {
+      HIP_TRY(hipMalloc((void**)&idx->t4_claim, (idx->d.V + 1) * 8));
+      idx->image_allocs.push_back(idx->t4_claim);
+      HIP_TRY(hipMemsetAsync(idx->t4_claim, 0, (idx->d.V + 1) * 8, idx->stream));
+    }
+    uint64_t* own_base = nullptr;
+    VS_TRY(dev_alloc(idx, (cap_rows + 1) * 4, (void**)&lc.own_pad, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (cap_rows + 1) * 8, (void**)&lc.own_off, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&lc.q_own, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 2) * 8, (void**)&own_base, &scratch.bufs));
+    lc.claim = idx->t4_claim; lc.gen = ++idx->t4_gen; lc.own_base = own_base;
+    hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
+    hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, lc);
+    HIP_TRY(hipMemcpyAsync(&t4_arena, own_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
+    share_t4 = true;
+  }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   totals[0] = ((volatile uint64_t*)pin_totals)[0];
   totals[1] = ((volatile uint64_t*)pin_totals)[1];
+  if (share_t4 && !walk_overflow) totals[1] = t4_arena;
   }
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
+    share_t4 = false;
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
@@ -654,7 +692,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(ralloc(r, d.A, &d.r_gt0));
     r->n_rows_reported = d.A;
   }
-  r->shared_lists = share;
+  r->shared_lists = share || share_t4;
+  r->scattered_lists = share_t4;      // a region's lists are not one arena range: texts come from a raw copy
   r->n_unique_sites = share ? n_unique : d.A;
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
   {
@@ -665,8 +704,9 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   uint32_t* u_site = nullptr;
   if (n) {
-    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
-    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws);
+    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
@@ -699,7 +739,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
       // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
       uint32_t chunk = idx->opts.fill_chunk;
-      if (chunk == 0) chunk = (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256) ? 16 : 64;
+      if (chunk == 0) chunk = (share || (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256)) ? 16 : 64;
       const uint64_t nchunks = (n_fill + chunk - 1) / chunk;
       const uint64_t blocks = (nchunks + 3) / 4;
       if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
@@ -714,24 +754,17 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       const uint32_t ablate = 0;
       constexpr bool kTune = false;
 #endif
-      if (share) {
-        if (idx->d.wpc <= 63 && chunk == 64)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
-        else if (idx->d.wpc <= 63)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
-        else if (chunk == 64)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
-        else
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, (const uint32_t*)u_site, n_unique, ablate, gt_words);
-      } else
-      if (idx->d.wpc <= 63 && chunk == 64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
-      else if (idx->d.wpc <= 63)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<false, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
-      else if (chunk == 64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunk, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<true, kFillChunkDense, kTune>), dim3((unsigned)blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+      const bool wide = idx->d.wpc > 63;
+      switch (chunk) {
+        case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        case 16: wide ? launch_fill<true, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        case 32: wide ? launch_fill<true, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        default: wide ? launch_fill<true, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+      }
     }
     HIP_TRY(hipGetLastError());
   }
@@ -1343,7 +1376,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_coop") o.t4_coop = value != 0;
   else if (k == "share_lists") o.share_lists = value != 0;
   else if (k == "fill_chunk") {
-    if (value != 0 && value != 16 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 16 or 64");
+    if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
     o.fill_chunk = (uint32_t)value;
   }
   else if (k == "fill_ablate" || k == "fill_lds_pad" || k == "walk_stats") {
@@ -1761,6 +1794,11 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   const uint64_t c0 = r->h_car_base[q], c1 = c0 + r->h_car_len[q];
   const uint32_t* car = nullptr;
   const bool from_view = r->have_carriers;
+  if (!from_view && r->scattered_lists && !(r->raw_rows && r->raw_arena)) {   // lists all over the arena: bring it over once
+    HIP_TRY(hipSetDevice(idx->device));
+    VS_TRY(raw_copy_begin(r, true, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+  }
   const bool from_raw = !from_view && r->raw_rows && r->raw_arena;   // a raw copy holds rows and arena: nothing to fetch
   // the rows: the whole table when a view or a raw copy has already brought it over, otherwise this region's slice of it
   const VariantRow* rows;

@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(256) k_share_rows(DevImage im, DevResult r, co
       const uint32_t g = ns + (uint32_t)j;
       row_store(r.rows, u0 + j, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], im.s_ncar[g],
                 (im.s_flags[g] & kSiteAlwaysDrop) != 0, cb0 + (im.s_carpre[g] - pre));
-      u_site[u0 + j] = g;
+      u_site[u0 + j] = g;   // (the expansion takes source handle and genotype offset from the site table: writing them here as well cost more than the look-up)
     }
   }
   if (r.q_flags[q] & kRegionSlow) emit_region<false>(im, r, q, lane);
@@ -1305,6 +1305,7 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       cb = ((uint64_t)y.w << 32) | y.z;
       cls = __builtin_nontemporal_load(&r.r_class[a]);
       gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
+      if (cls == kNone) cnt = 0;   // the row shares another row's list (k_t4_claim): nothing to expand here
     }
     expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
@@ -2316,8 +2317,51 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
 // header writes; the arena offsets are a prefix sum inside each 16-lane row (four DPP steps).
 // RESOLVE: the scratch holds the type-4 walk's state per reported vertex {ref_pos, vertex, kind, cur_ref} and the row is
 // worked out here (resolve_walk_variant); otherwise (type 5) it holds finished rows.
-template <bool RESOLVE>
-__global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws) {
+// Shared carrier lists for the walking query types: a vertex that several regions of the batch report -- the same
+// common variant on the paths of different samples -- gets ONE list.  The first row to claim the vertex (a 64-bit
+// word per vertex, stamped with the batch's generation so that it never needs clearing) owns the list; `own_pad` holds
+// the owner rows' padded carrier counts (0 for the others), and its exclusive scan gives the owners their arena places.
+struct ListClaims {
+  unsigned long long* claim;   // [V] generation << 40 | owner row + 1
+  uint64_t gen;
+  uint32_t* own_pad;           // [rows] padded carrier count of an owner row, 0 otherwise
+  uint64_t* q_own;             // [Q] sum of own_pad over a region's rows; its exclusive scan own_base gives the region's part of the arena
+  const uint64_t* own_base;    // [Q + 1]
+  uint64_t* own_off;           // [rows] arena offset of an owner row's list
+};
+constexpr uint64_t kClaimRowMask = (1ULL << 40) - 1;
+__global__ void __launch_bounds__(256) k_t4_claim(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = q < r.Q;
+  const uint64_t n = live ? r.q_nvar[q] : 0, a0 = live ? r.var_begin[q] : 0, s0 = live ? ws.cap_begin[q] : 0;
+  uint64_t sum = 0;
+  for (uint64_t i = threadIdx.x & 15u; i < n; i += 16) {
+    const uint32_t v = ws.cur[s0 + i];
+    const unsigned long long mine = (lc.gen << 40) | (a0 + i + 1);
+    unsigned long long old = lc.claim[v];
+    while ((old >> 40) != lc.gen) {
+      const unsigned long long prev = atomicCAS(&lc.claim[v], old, mine);
+      if (prev == old) { old = mine; break; }
+      old = prev;
+    }
+    const uint32_t pad = old == mine ? pad_car(im.v_ncar[v]) : 0u;
+    lc.own_pad[a0 + i] = pad;
+    sum += pad;
+  }
+  for (int d = 8; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 16);
+  if (live && (threadIdx.x & 15u) == 0) lc.q_own[q] = sum;
+}
+// arena offsets of the owner rows: the region's base + the prefix of its own rows' pads (one lane per region: ~10 rows)
+__global__ void __launch_bounds__(256) k_t4_offsets(DevResult r, ListClaims lc) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q];
+  uint64_t at = lc.own_base[q];
+  for (uint64_t i = 0; i < n; ++i) { lc.own_off[a0 + i] = at; at += lc.own_pad[a0 + i]; }
+}
+
+template <bool RESOLVE, bool SHARED>
+__global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t l16 = threadIdx.x & 15u, row_last = (threadIdx.x & 63u) | 15u;
   const bool live = q < r.Q;
@@ -2346,8 +2390,15 @@ __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r
       WalkVariant wv;
       if (RESOLVE) wv = resolve_walk_variant(im, ws.ro[s], cur, ws.pos[s], ws.rl[s]);
       else wv = WalkVariant{ws.pos[s], ws.ro[s], ws.rl[s], ws.ao[s], ws.al[s]};
-      row_store(r.rows, a, (uint32_t)wv.pos, wv.ro, wv.rl, wv.ao, wv.al, c, false, cb + (incl - pad_car(c)));
-      r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+      uint64_t at = cb + (incl - pad_car(c));
+      bool owner = true;
+      if (SHARED) {   // the list lives where the vertex's owner row put it
+        const uint64_t o = (lc.claim[cur] & kClaimRowMask) - 1;
+        at = lc.own_off[o];
+        owner = o == a;
+      }
+      row_store(r.rows, a, (uint32_t)wv.pos, wv.ro, wv.rl, wv.ao, wv.al, c, false, at);
+      r.r_class[a] = owner ? im.v_src[cur] : kNone; r.r_gt0[a] = im.v_car_begin[cur];
     }
     cb += (uint32_t)__shfl((int)incl, (int)row_last, 64);
     kept += (uint32_t)__shfl((int)csum, (int)row_last, 64);
