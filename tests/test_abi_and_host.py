@@ -118,3 +118,20 @@ def test_host_code_under_sanitizers(golden_dir, tmp_path):
                           os.path.join(tmp_path, "ser")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok 213 143 ") and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_handle_options_are_checked():
+    """vs_index_set_option: known keys with in-range values only; tuning switches exist in tuning builds alone."""
+    from variantstore_amd import VariantStore
+    from variantstore_amd.api import VariantStoreError
+    vs = VariantStore.synthetic(device=-1, ref_length=20_000, num_variants=50, num_samples=4, seed=3, first_pos=10)
+    for key, good in (("latency_server", 0), ("latency_server", 2), ("server_blocks", 8), ("t4_skip", 0), ("t4_coop", 0),
+                      ("share_lists", 0), ("fill_chunk", 16), ("t4_two_walks", 1), ("seq_two_walks", 1), ("lat_debug", 0)):
+        vs.set_option(key, good)
+    for key, bad in (("latency_server", 3), ("server_blocks", 0), ("server_blocks", 65), ("fill_chunk", 5), ("no_such_switch", 1)):
+        with pytest.raises(VariantStoreError):
+            vs.set_option(key, bad)
+    with pytest.raises(VariantStoreError) as e:       # this is not a tuning build
+        vs.set_option("fill_ablate", 1)
+    assert e.value.code == -7
+    vs.close()

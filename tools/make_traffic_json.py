@@ -23,7 +23,7 @@ blob = None
 if dirs and dirs[0].startswith("--blob="):
     blob, dirs = dirs[0].split("=", 1)[1].strip(), dirs[1:]
 raw = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs))
-SHORT = {"k_fill_carriers": "k_fill_carriers", "k_fill_sites": "k_fill_sites", "k_unique_sites": "k_unique_sites", "k_sample_walk_coop": "k_sample_walk_coop", "k_emit_headers": "k_emit_headers", "k_sample_walk": "k_sample_walk",
+SHORT = {"k_fill_carriers": "k_fill_carriers", "k_fill_sites": "k_fill_sites", "k_share_rows": "k_share_rows", "k_sample_walk_coop": "k_sample_walk_coop", "k_emit_headers": "k_emit_headers", "k_sample_walk": "k_sample_walk",
          "k_emit_from_walk": "k_emit_from_walk", "k_region_bounds": "k_region_bounds"}
 kernels = {}
 for name, ctr in raw.items():

@@ -2895,8 +2895,8 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
 // Totals of a result without copying it: {variants reported, their carriers, their REF + ALT bases}, one wave per region
 __global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned long long* out) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (q >= r.Q) return;
-  const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q];
+  const bool live = q < r.Q;
+  const uint64_t n = live ? r.q_nvar[q] : 0, a0 = live ? r.var_begin[q] : 0;
   unsigned long long nv = 0, nc = 0, nb = 0;
   for (uint64_t j = threadIdx.x & 63; j < n; j += 64) {
     const VariantRow v = row_load(r.rows, a0 + j);
@@ -2904,7 +2904,13 @@ __global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned lon
     nv += 1; nc += row_count(v); nb += (uint64_t)v.ref_len + v.alt_len;
   }
   for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); nc += __shfl_down(nc, d, 64); nb += __shfl_down(nb, d, 64); }
-  if ((threadIdx.x & 63) == 0 && (nv | nb)) { atomicAdd(out, nv); atomicAdd(out + 1, nc); atomicAdd(out + 2, nb); }
+  __shared__ unsigned long long part[3][4];   // one atomic triple per block, not per wave: the three words are one hot line
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = nv; part[1][threadIdx.x >> 6] = nc; part[2][threadIdx.x >> 6] = nb; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (t) atomicAdd(out + threadIdx.x, t);
+  }
 }
 
 // Index::find batched (index.h:119-133)
