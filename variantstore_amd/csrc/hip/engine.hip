@@ -82,6 +82,7 @@ struct vs_index {
   std::vector<DevBuf> pool;
   unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
   uint64_t t4_gen = 0;
+  uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
   std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
   hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
   vs_timing timing{};
@@ -613,7 +614,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   uint64_t *sh_u_begin = nullptr, *sh_arena_new = nullptr;
   uint64_t n_unique = 0;
   if (share) {
-    const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
+    const uint64_t ntiles = (n + kShareTile - 1) / kShareTile;
     ShareMax* tile_max = nullptr;
     Scan4* tile_sums = nullptr;
     uint32_t *e_prev = nullptr, *status = nullptr;
@@ -629,9 +630,22 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     hipLaunchKernelGGL(k_share_tile_max, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, d, tile_max);
     hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
     hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
-    hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status);
+    const uint64_t share_seq = ++idx->share_seq;
+    hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status,
+                       share_seq);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    {  // the sizes arrive in mapped host memory: spin on the sequence word (the runtime's completion wait costs tens of
+       // microseconds more); a kernel that never posts -- a fault -- is caught by the synchronisation after the deadline
+      volatile uint64_t* seqw = pin_totals + 5;
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+      bool posted = false;
+      while (!(posted = (*seqw == share_seq))) {
+        __builtin_ia32_pause();
+        if (std::chrono::steady_clock::now() > deadline) break;
+      }
+      if (!posted) HIP_TRY(hipStreamSynchronize(idx->stream));
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
     totals[0] = ((volatile uint64_t*)pin_totals)[0];
     totals[1] = ((volatile uint64_t*)pin_totals)[1];
     n_unique = ((volatile uint64_t*)pin_totals)[2];

@@ -541,6 +541,9 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 // so a row's carrier offset keeps its form car_base[q] + carpre[g] - carpre[g0].  Needs g0 ascending over the
 // regions with any site; a batch that is not reports so (status) and takes the private-list path.
 // ---------------------------------------------------------------------------
+// (the scans over the regions keep 2 items per thread: their per-item work is a chain of dependent site-table reads, and
+//  100 k regions in tiles of 2048 would be 49 blocks on a 256-CU part)
+constexpr int kShareItems = 2, kShareTile = kScanBlock * kShareItems;
 struct ShareMax { uint32_t g1, g0; };
 __device__ __forceinline__ ShareMax smax(ShareMax a, ShareMax b) { return ShareMax{a.g1 > b.g1 ? a.g1 : b.g1, a.g0 > b.g0 ? a.g0 : b.g0}; }
 __device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* total) {
@@ -568,9 +571,9 @@ __device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {
   return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q]} : ShareMax{0, 0};
 }
 __global__ void __launch_bounds__(kScanBlock) k_share_tile_max(DevResult r, ShareMax* tile_max) {
-  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
   ShareMax m{0, 0};
-  for (int i = 0; i < kScanItems; ++i)
+  for (int i = 0; i < kShareItems; ++i)
     if (base + i < r.Q) m = smax(m, share_elem(r, base + i));
   ShareMax tot;
   block_exclusive_max(m, &tot);
@@ -624,16 +627,16 @@ __device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, u
 // per element: E_prev (kept for the last pass) and the tile sums
 __global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t* e_prev, Scan4* tile_sums,
                                                          uint32_t* status) {
-  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
-  ShareMax loc[kScanItems], m{0, 0};
-  for (int i = 0; i < kScanItems; ++i) {
+  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
+  ShareMax loc[kShareItems], m{0, 0};
+  for (int i = 0; i < kShareItems; ++i) {
     loc[i] = base + i < r.Q ? share_elem(r, base + i) : ShareMax{0, 0};
     m = smax(m, loc[i]);
   }
   ShareMax tot;
   ShareMax ex = smax(block_exclusive_max(m, &tot), tile_max[blockIdx.x]);
   Scan4 s{0, 0, 0, 0};
-  for (int i = 0; i < kScanItems; ++i) {
+  for (int i = 0; i < kShareItems; ++i) {
     if (base + i < r.Q) {
       const uint32_t nv = (uint32_t)r.q_nvar[base + i];
       if (nv && loc[i].g0 < ex.g0) *status = 1;          // a region that starts before an earlier one: not sorted
@@ -649,8 +652,10 @@ __global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = t4;
 }
 // totals: {rows of the table (shared + private), arena entries, shared rows, not-sorted flag, rows reported over all regions}
+// (totals lie in mapped host memory; totals[5] = seq is written last, with a system-scope release: the host spins on it
+//  instead of synchronising the stream)
 __global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan4* tile_sums, uint64_t ntiles, DevResult r, uint64_t* u_begin, uint64_t* totals,
-                                                               const uint32_t* status) {
+                                                               const uint32_t* status, uint64_t seq) {
   Scan4 carry{0, 0, 0, 0};
   for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
     const uint64_t i = base + threadIdx.x;
@@ -663,17 +668,18 @@ __global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan4* tile_sums
   if (threadIdx.x == 0) {
     r.var_begin[r.Q] = carry.u + carry.p; r.car_base[r.Q] = carry.c; u_begin[r.Q] = carry.u;
     totals[0] = carry.u + carry.p; totals[1] = carry.c; totals[2] = carry.u; totals[3] = *status; totals[4] = carry.a;
+    __hip_atomic_store(&totals[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan4* tile_sums, uint32_t* new_start,
                                                            uint64_t* u_begin, uint64_t* arena_new) {
-  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
   const uint64_t U = u_begin[r.Q];   // (written by the spine kernel before this launch)
-  ShareNew loc[kScanItems];
-  uint32_t nvs[kScanItems];
-  bool slow[kScanItems];
+  ShareNew loc[kShareItems];
+  uint32_t nvs[kShareItems];
+  bool slow[kShareItems];
   Scan4 s{0, 0, 0, 0};
-  for (int i = 0; i < kScanItems; ++i) {
+  for (int i = 0; i < kShareItems; ++i) {
     loc[i] = ShareNew{0, 0, 0, 0, 0}; nvs[i] = 0; slow[i] = false;
     if (base + i < r.Q) {
       nvs[i] = (uint32_t)r.q_nvar[base + i];
@@ -686,7 +692,7 @@ __global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResu
   Scan4 ex = block_exclusive_scan4(s, &tot);
   const Scan4 ts = tile_sums[blockIdx.x];
   ex.a += ts.a; ex.u += ts.u; ex.c += ts.c; ex.p += ts.p;
-  for (int i = 0; i < kScanItems; ++i) {
+  for (int i = 0; i < kShareItems; ++i) {
     if (base + i < r.Q) {
       const uint64_t q = base + i;
       u_begin[q] = ex.u; arena_new[q] = ex.c; new_start[q] = loc[i].ns;
@@ -2173,32 +2179,90 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (!fl) {
       ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
       hold.row = cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr;
-      uint32_t it = 0, lit = 0;
-      if (cx.use_ev) walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit);
-      n_search = it;
-      t_c1 = VS_WALK_CLOCK();
       if (!cx.use_ev) serial = true;
-      else {
-        // ---- head: literal steps from the start state until the walk is in step (redundant in the group) ----
-        bool done = false, term = false;
-        uint32_t steps = 0;
-        while (true) {
-          if (done || st.ref_pos >= cx.y) { term = true; break; }
-          if (walk_in_step(cx, st)) { cur_slot = st.cur_slot1 - 1; break; }
-          if (++steps > 64) { serial = true; break; }   // (a start state that never falls in step: walk it serially)
-          WalkEmit em;
-          if (walk_literal_step<true>(im, cx, hold, st, em, done)) {
-            if (nvar < scap) {
-              if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v; }
-            } else if (l == 0) *ws.overflow = 1;
-            nvar++; ncar += pad_car(em.c);
-          }
-        }
-        busy = !term && !serial;
-      }
-      t_c2 = VS_WALK_CLOCK();
     }
   }
+  // ---- get_prev_vertex_with_sample, 16 ranks of the chain at a time ----
+  // The search visits rank, rank - deg(previous(rank)), ... (one count per neighbour of each visited node).  The group
+  // reads the records of the 16 ranks below the current one together, follows the chain through them in registers
+  // (which of the 16 are visited), tests the visited nodes' event bits, and checks the candidates literally in
+  // parallel; the first visited node with a neighbour holding the sample is the answer.  Its ref_pos is the node's own
+  // last ref neighbour; a node without one (the end of the path) would need the history: serial loop.
+  bool searching = live && !fl && cx.use_ev;
+  uint64_t rank = rank0;
+  while (__any(searching)) {
+    if (searching && rank <= 1) {   // the head of the path (redundant in the group)
+      const uint32_t v = im.rp_vid[im.rk_back[rank == 0 ? 0 : rank - 1].x];
+      st.cur = v; st.wc = blob_vertex(im, v); st.ref_pos = 1; st.cur_ref_v = kNone;
+      st.cur_slot1 = im.w_vertex[2 * (uint64_t)v + 1].w;
+      searching = false;
+    }
+    ++n_search;
+    const bool valid = searching && rank >= (uint64_t)l + 2;
+    uint2 back{0, 1};
+    if (valid) back = im.rk_back[rank - l - 1];
+    uint32_t vis = 0, pos = 0;   // group-uniform: chain positions visited among the 16, next position
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) {
+      const int src = (int)gbase + (int)(pos < 16 ? pos : 15);
+      const uint32_t deg_c = (uint32_t)__shfl((int)back.y, src, 64);
+      const bool val_c = __shfl((int)valid, src, 64) != 0;
+      if (pos < 16 && val_c) { vis |= 1u << pos; pos += deg_c ? deg_c : 1u; }
+    }
+    const bool cand = valid && ((vis >> l) & 1) && ev.bit(back.x);
+    bool found = false, had_ref = false;
+    uint32_t f_ref_pos = 0, f_v = 0, f_slot1 = 0;
+    WalkVertex f_wc{};
+    if (cand) {
+      const uint32_t rb0 = im.blob_of_slot[back.x] + 1;   // the edge records follow the slot's header
+      for (uint32_t e = rb0; e < rb0 + back.y; ++e) {
+        const uint4 a = im.wblob[2 * (uint64_t)e];
+        if (a.y) { f_ref_pos = a.y; had_ref = true; }
+        if (hold.bit(a.x)) {
+          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+          f_v = a.x; found = true; f_slot1 = b.y;
+          f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
+        }
+      }
+    }
+    const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & 0xFFFFu);
+    const int fl_lane = (int)gbase + (fb ? __builtin_ctz(fb) : 0);
+    const uint32_t g_v = (uint32_t)__shfl((int)f_v, fl_lane, 64), g_slot1 = (uint32_t)__shfl((int)f_slot1, fl_lane, 64);
+    const uint32_t g_ref_pos = (uint32_t)__shfl((int)f_ref_pos, fl_lane, 64);
+    const bool g_had_ref = __shfl((int)had_ref, fl_lane, 64) != 0;
+    WalkVertex g_wc;
+    g_wc.row_begin = (uint32_t)__shfl((int)f_wc.row_begin, fl_lane, 64); g_wc.deg = (uint32_t)__shfl((int)f_wc.deg, fl_lane, 64);
+    g_wc.ridx = (uint32_t)__shfl((int)f_wc.ridx, fl_lane, 64); g_wc.off = 0;
+    g_wc.len = (uint32_t)__shfl((int)f_wc.len, fl_lane, 64); g_wc.cls = (uint32_t)__shfl((int)f_wc.cls, fl_lane, 64);
+    g_wc.ncar = (uint32_t)__shfl((int)f_wc.ncar, fl_lane, 64);
+    if (searching) {
+      if (fb) {
+        if (!g_had_ref) serial = true;   // (ref_pos would be an earlier iteration's: the serial loop knows)
+        st.cur = g_v; st.wc = g_wc; st.ref_pos = g_ref_pos; st.cur_ref_v = kNone; st.cur_slot1 = g_slot1;
+        searching = false;
+      } else rank = rank > pos ? rank - pos : 0;
+    }
+  }
+  t_c1 = VS_WALK_CLOCK();
+  if (live && !fl && cx.use_ev && !serial) {
+    // ---- head: literal steps from the start state until the walk is in step (redundant in the group) ----
+    bool done = false, term = false;
+    uint32_t steps = 0;
+    while (true) {
+      if (done || st.ref_pos >= cx.y) { term = true; break; }
+      if (walk_in_step(cx, st)) { cur_slot = st.cur_slot1 - 1; break; }
+      if (++steps > 64) { serial = true; break; }   // (a start state that never falls in step: walk it serially)
+      WalkEmit em;
+      if (walk_literal_step<true>(im, cx, hold, st, em, done)) {
+        if (nvar < scap) {
+          if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = em.ref_pos; ws.cur[s] = em.cur; ws.ro[s] = em.kind; ws.rl[s] = em.cur_ref_v; }
+        } else if (l == 0) *ws.overflow = 1;
+        nvar++; ncar += pad_car(em.c);
+      }
+    }
+    busy = !term && !serial;
+  }
+  t_c2 = VS_WALK_CLOCK();
   // ---- episodes, 16 events of a group at a time ----
   while (__any(busy)) {
     if (busy) ++n_chunks;
