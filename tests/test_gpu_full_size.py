@@ -150,6 +150,14 @@ def test_type4_event_bitmap_walk_equals_the_literal_walk_at_full_size(big):
     fast = vs.get_sample_var_in_ref(regions, sids)
     tf, df = fast.totals(), fast.digest()
     assert tf[1] > 500_000
+    for coop in (16, 0):                      # the 16-lane groups and the one-lane-per-region form of the same walk
+        vs.set_option("t4_coop", coop)
+        try:
+            other = vs.get_sample_var_in_ref(regions, sids)
+        finally:
+            vs.set_option("t4_coop", 8)
+        assert (other.totals(), other.digest()) == (tf, df), coop
+        other.close()
     vs.set_option("t4_skip", 0)
     try:
         slow = vs.get_sample_var_in_ref(regions, sids)

@@ -19,7 +19,7 @@ ns = vs.info().num_samples
 sids16 = [1 + (i * 157) % (ns - 1) for i in range(16)]
 per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)
 digests = {}
-for skip, coop in ((1, 1), (1, 0), (0, 0)):
+for skip, coop in ((1, 16), (1, 8), (1, 0), (0, 0)):
     vs.set_option("t4_skip", skip)
     vs.set_option("t4_coop", coop)
     try:

@@ -89,7 +89,7 @@ for c in range(n_cohorts):
         # type 4 with one sample per region, through the cooperative walk, the serial walk and the literal (no-jump) walk
         per = [names[int(i)] for i in rng.integers(0, len(names), size=100)]
         want4 = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(regions[:100], per)]
-        for coop, skip in ((1, 1), (0, 1), (0, 0)):
+        for coop, skip in ((8, 1), (16, 1), (0, 1), (0, 0)):
             vs.set_option("t4_coop", coop)
             vs.set_option("t4_skip", skip)
             rm = vs.get_sample_var_in_ref(regions[:100], per)

@@ -59,7 +59,7 @@ struct EngineOpts {
   bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
   bool seq_two_walks = false;   // the same for types 2 / 3
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
-  bool t4_coop = true;          // type 4: 16 lanes per region, episodes in parallel (k_sample_walk_coop); false: one lane per region
+  int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   bool share_lists = true;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
@@ -578,8 +578,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     }
 #endif
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
-    else if (dwalk.t4_events && idx->opts.t4_coop)   // 16 lanes per region: the episodes of a region run in parallel
-      hipLaunchKernelGGL(k_sample_walk_coop, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
+    else if (dwalk.t4_events && idx->opts.t4_coop == 8)   // 8 or 16 lanes per region: the episodes of a region run in parallel
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
+    else if (dwalk.t4_events && idx->opts.t4_coop)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<16>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
@@ -1387,7 +1389,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_two_walks") o.t4_two_walks = value != 0;
   else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
   else if (k == "t4_skip") o.t4_skip = value != 0;
-  else if (k == "t4_coop") o.t4_coop = value != 0;
+  else if (k == "t4_coop") o.t4_coop = value == 16 ? 16 : (value ? 8 : 0);
   else if (k == "share_lists") o.share_lists = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");

@@ -2121,7 +2121,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
 }
 
 // ---------------------------------------------------------------------------
-// Cooperative form of the recording walk: 16 lanes per region.
+// Cooperative form of the recording walk: SUB (16 or 8) lanes per region.
 //
 // Between two events a walk is in step with the ref path, and what it does from an event slot on depends only on
 // {slot's node, its index} (walk_arrive_at_slot) -- so the EPISODES of a region (event slot -> literal steps until the
@@ -2137,11 +2137,20 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEpEmits = 4, kEpSteps = 12;
 
-__device__ __forceinline__ uint32_t group_inclusive_scan16(uint32_t v) {   // prefix sum inside each row of 16 lanes (DPP)
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+template <uint32_t SUB>
+__device__ __forceinline__ uint32_t group_inclusive_scan(uint32_t l, uint32_t v) {   // prefix sum inside each group of SUB lanes (l = lane within the group)
+  if (SUB == 16) {   // a DPP row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
+  }
+#pragma unroll
+  for (uint32_t d = 1; d < SUB; d <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)v, (int)d, 64);
+    if (l >= d) v += t;
+  }
   return v;
 }
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
@@ -2153,10 +2162,13 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t word, uint32_t rank) {  
   return (uint32_t)__builtin_ctzll(word);
 }
 
+template <uint32_t SUB>
 __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                           WalkScratch ws) {
-  const uint32_t lane = threadIdx.x & 63, l = lane & 15, gbase = lane & 48;
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  static_assert(SUB == 8 || SUB == 16, "group width");
+  constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
+  const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
   const bool live = q < r.Q;
   WalkCtx cx{0, 0, 0, false, 0};
   if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
@@ -2203,11 +2215,11 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (valid) back = im.rk_back[rank - l - 1];
     uint32_t vis = 0, pos = 0;   // group-uniform: chain positions visited among the 16, next position
 #pragma unroll 1
-    for (int t = 0; t < 16; ++t) {
-      const int src = (int)gbase + (int)(pos < 16 ? pos : 15);
+    for (int t = 0; t < (int)SUB; ++t) {
+      const int src = (int)gbase + (int)(pos < SUB ? pos : SUB - 1);
       const uint32_t deg_c = (uint32_t)__shfl((int)back.y, src, 64);
       const bool val_c = __shfl((int)valid, src, 64) != 0;
-      if (pos < 16 && val_c) { vis |= 1u << pos; pos += deg_c ? deg_c : 1u; }
+      if (pos < SUB && val_c) { vis |= 1u << pos; pos += deg_c ? deg_c : 1u; }
     }
     const bool cand = valid && ((vis >> l) & 1) && ev.bit(back.x);
     bool found = false, had_ref = false;
@@ -2225,7 +2237,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
         }
       }
     }
-    const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & 0xFFFFu);
+    const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & kGroupMask);
     const int fl_lane = (int)gbase + (fb ? __builtin_ctz(fb) : 0);
     const uint32_t g_v = (uint32_t)__shfl((int)f_v, fl_lane, 64), g_slot1 = (uint32_t)__shfl((int)f_slot1, fl_lane, 64);
     const uint32_t g_ref_pos = (uint32_t)__shfl((int)f_ref_pos, fl_lane, 64);
@@ -2271,16 +2283,16 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     uint64_t word = (busy && wi < w_end) ? ev.row[wi] : 0;
     if (l == 0) word &= ~0ULL << (cur_slot & 63);
     if (busy && wi == (cx.limit >> 6) && (cx.limit & 63)) word &= (1ULL << (cx.limit & 63)) - 1;
-    const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan16(pc);
-    const uint32_t total = (uint32_t)__shfl((int)incl, (int)gbase + 15, 64);
+    const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)gbase + (int)SUB - 1, 64);
     uint32_t j = 0;                                   // the word holding this lane's event: #words whose inclusive count is <= l
 #pragma unroll
-    for (int t = 0; t < 16; ++t) j += (uint32_t)__shfl((int)incl, (int)gbase + t, 64) <= l ? 1u : 0u;
+    for (int t = 0; t < (int)SUB; ++t) j += (uint32_t)__shfl((int)incl, (int)gbase + t, 64) <= l ? 1u : 0u;
     const bool have = busy && l < total;
-    const int src = (int)gbase + (int)(j < 16 ? j : 15);
+    const int src = (int)gbase + (int)(j < SUB ? j : SUB - 1);
     const uint64_t wj = shfl64(word, src);
     const uint32_t excl_j = (uint32_t)__shfl((int)(incl - pc), src, 64);
-    const bool more = total > 16 || w0 + 16 < w_end;  // events beyond this chunk may exist
+    const bool more = total > SUB || w0 + SUB < w_end;  // events beyond this chunk may exist
     uint32_t slot = 0;
     if (have) slot = ((w0 + j) << 6) + select_bit(wj, l - excl_j);
     // ---- this lane's episode ----
@@ -2310,9 +2322,9 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     // ---- the chain of hand-overs (registers only) ----
     bool accepted = false, gdone = !busy, finished = false, fallback = false;
 #pragma unroll 1
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < (int)SUB; ++t) {
       const bool cand = !gdone && have && slot >= cur_slot;
-      const uint32_t gb = (uint32_t)((__ballot(cand) >> gbase) & 0xFFFFu);
+      const uint32_t gb = (uint32_t)((__ballot(cand) >> gbase) & kGroupMask);
       const int i = gb ? (int)gbase + __builtin_ctz(gb) : (int)gbase;
       const bool t_i = __shfl((int)ep_term, i, 64), o_i = __shfl((int)ep_ovf, i, 64);
       const uint32_t end_i = (uint32_t)__shfl((int)ep_end, i, 64);
@@ -2329,13 +2341,13 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     }
     if (busy && !fallback && !finished && !more) finished = true;   // nothing below the stop slot any more: the walk runs into it
     // events may remain beyond this chunk: the chain is in step at least up to where the chunk's enumeration ended
-    const uint32_t last_slot = (uint32_t)__shfl((int)slot, (int)gbase + 15, 64);
-    const uint32_t chunk_next = total > 16 ? last_slot + 1 : (w0 + 16) << 6;
+    const uint32_t last_slot = (uint32_t)__shfl((int)slot, (int)gbase + (int)SUB - 1, 64);
+    const uint32_t chunk_next = total > SUB ? last_slot + 1 : (w0 + SUB) << 6;
     if (busy && !fallback && !finished && chunk_next > cur_slot) cur_slot = chunk_next;
     // ---- the accepted episodes' reports, compacted in order ----
     const uint32_t mine = (accepted && !fallback) ? n_em : 0u;
-    const uint32_t inc_e = group_inclusive_scan16(mine), tot_e = (uint32_t)__shfl((int)inc_e, (int)gbase + 15, 64);
-    const uint32_t inc_p = group_inclusive_scan16((accepted && !fallback) ? ep_pad : 0u), tot_p = (uint32_t)__shfl((int)inc_p, (int)gbase + 15, 64);
+    const uint32_t inc_e = group_inclusive_scan<SUB>(l, mine), tot_e = (uint32_t)__shfl((int)inc_e, (int)gbase + (int)SUB - 1, 64);
+    const uint32_t inc_p = group_inclusive_scan<SUB>(l, (accepted && !fallback) ? ep_pad : 0u), tot_p = (uint32_t)__shfl((int)inc_p, (int)gbase + (int)SUB - 1, 64);
     if (mine) {
       const uint64_t at = nvar + (inc_e - mine);
 #pragma unroll
