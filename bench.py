@@ -421,6 +421,30 @@ def main():
     else:
         achieved, basis = layout_gbps, "layout_bytes"
 
+    # ---- the same batch with private rows and lists per region (round 2's result form; `share_lists = 0`), for comparison ----
+    private = None
+    if lists_shared:
+        vs.set_option("share_lists", 0)
+        try:
+            for _i in range(2):
+                vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg).close()
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            pf = 0.0
+            for _i in range(5):
+                rp = vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
+                pf += vs.last_timing().ms_fill
+                rp.close()
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - a) / 5
+            rp = vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
+            p_layout, p_digest = rp.layout(), rp.digest()
+            rp.close()
+            private = {"queries_per_s": nreg / dtp, "ms_per_step": dtp * 1e3, "fill_ms": pf / 5, "variant_table_rows": p_layout[1],
+                       "arena_entries": p_layout[2], "same_digest": p_digest == digest}
+        finally:
+            vs.set_option("share_lists", 1)
+
     # ---- p50 single-region latency (submit -> result resident), outside the timed region: a client that asks again
     #      the moment it has its answer (the resident server's case), and one paced at 1 query per millisecond ----
     lat = []
@@ -605,7 +629,8 @@ def main():
                                   "arena_entries": arena_entries, "shared_between_regions": lists_shared,
                                   "note": "a sorted batch holds one row and one carrier list per site it covers; every region reporting the "
                                           "site refers to them (its rows are a range of the shared table), as REF/ALT refer to the sequence "
-                                          "pool" if lists_shared else None},
+                                          "pool" if lists_shared else None,
+                                  "private_rows_and_lists_for_comparison": private},
                 "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,
