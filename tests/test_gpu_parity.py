@@ -878,3 +878,34 @@ def test_raw_copy_and_streamed_delivery(tmp_path):
     seen.clear()
     vs.stream_var_in_ref(regions[:250], 100, on_chunk)
     assert seen == [(0, 100), (100, 100), (200, 50)]
+
+
+def test_type4_regions_that_outgrow_their_scratch_capacity(tmp_path):
+    """The recording walk of type 4 gets the region's type-6 row count as scratch capacity; tiny regions report more than
+    that (their head episode lies in front of x's node), the batch then takes the two-walk path -- and the list claims of
+    the shared form must not read what the overflowing walk did not record (found by the round-3 stress campaign)."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 20027, ref_len=3352, n_rows=186, n_samples=130, p_ins=0.08, p_del=0.04,
+                                            p_multi=0.16, p_near=0.34, carrier_p=0.3)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(20027)
+    L = vs.info().ref_length
+    regions = [(int(x), int(x) + int(rng.integers(0, 6))) for x in rng.integers(1, L, size=300)]
+    per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
+    for coop in (8, 16, 0):
+        vs.set_option("t4_coop", coop)
+        res = vs.get_sample_var_in_ref(regions, per)
+        for q, (x, y) in enumerate(regions):
+            n, _, text = orc.get_sample_var_in_ref(x, y, per[q])
+            if n >= 0:
+                assert res.region_text(q) == text, (coop, q, x, y, per[q])
+        res.close()
+    vs.set_option("t4_coop", 8)
+    # and a batch of ordinary regions right afterwards (the claims' generation moves on)
+    regions = sorted(random_regions(rng, L, 200, max_len=700))
+    per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
+    res = vs.get_sample_var_in_ref(regions, per)
+    assert res.layout()[4]
+    for q, (x, y) in enumerate(regions):
+        n, _, text = orc.get_sample_var_in_ref(x, y, per[q])
+        if n >= 0:
+            assert res.region_text(q) == text, (q, x, y)

@@ -17,6 +17,13 @@ from variantstore_amd import VariantStore  # noqa: E402
 n_cohorts = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 bad = hang = ub = checked = slow_regions = shared_batches = 0
+VERBOSE = bool(os.environ.get("VS_STRESS_VERBOSE"))
+
+
+def stage(msg):
+    if VERBOSE:
+        print("  .. " + msg, file=sys.stderr, flush=True)
+
 for c in range(n_cohorts):
     seed = seed0 + c
     rng = np.random.default_rng(seed)
@@ -45,6 +52,7 @@ for c in range(n_cohorts):
         vs.export_plain(plain)
         orc = Oracle(plain)
         regions = random_regions(rng, vs.info().ref_length, 150, max_len=int(rng.choice([5, 60, 600, 5000])))
+        stage(f"cohort {seed} {kw} list_max {os.environ['VS_LIST_MAX']}: type 6")
         res = vs.get_var_in_ref(regions)
         flags = res.view(False)
         for q, (x, y) in enumerate(regions):
@@ -59,6 +67,7 @@ for c in range(n_cohorts):
         slow_regions += int((flags["var_count"] != np.diff(flags["var_begin"].astype(np.int64))).sum())
         # the same regions sorted: the batch then shares one row and one carrier list per covered site between its regions
         order = sorted(range(len(regions)), key=lambda i: regions[i])
+        stage("sorted batch")
         rsh = vs.get_var_in_ref([regions[i] for i in order])
         shared_batches += int(rsh.layout()[4])
         for k, i in enumerate(order):
@@ -92,6 +101,7 @@ for c in range(n_cohorts):
         for coop, skip in ((8, 1), (16, 1), (0, 1), (0, 0)):
             vs.set_option("t4_coop", coop)
             vs.set_option("t4_skip", skip)
+            stage(f"type 4 coop {coop} skip {skip}")
             rm = vs.get_sample_var_in_ref(regions[:100], per)
             for q, (n, early, text) in enumerate(want4):
                 if n < 0:
@@ -114,6 +124,7 @@ for c in range(n_cohorts):
             if r4.region_text(q) != text:
                 bad += 1
                 print(f"MISMATCH t4 cohort {seed} sample {sample} region {x}:{y}\n--- gpu\n{r4.region_text(q)}--- oracle\n{text}")
+        stage("types 1, 7, 2, 3, 5")
         # ---- types 1 and 7 ----
         L = vs.info().ref_length
         positions = [int(p) for p in rng.integers(0, L + 30, size=80)]

@@ -61,6 +61,7 @@ struct EngineOpts {
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
   int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
+  bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
   bool share_lists = true;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
@@ -82,6 +83,8 @@ struct vs_index {
   std::vector<DevBuf> pool;
   unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
   uint64_t t4_gen = 0;
+  hipStream_t fill_stream = nullptr;        // second stream of the split expansion (fill_split)
+  hipEvent_t fill_ev[2] = {nullptr, nullptr};
   uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
   std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
   hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
@@ -508,11 +511,12 @@ static size_t fill_lds_bytes(const vs_index* idx) {
 }
 
 // one launch of the carrier expansion: over the rows of a private-row result or over the shared rows of a sorted batch
-template <bool WIDE, uint32_t CH, bool TUNE>
+template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
 static void launch_fill(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill, unsigned blocks, size_t lds_bytes,
-                        uint32_t ablate, uint32_t gt_words) {
-  if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_site, n_fill, ablate, gt_words);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, ablate, gt_words);
+                        uint32_t ablate, uint32_t gt_words, hipStream_t stream = nullptr) {
+  if (!stream) stream = idx->stream;
+  if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, u_site, n_fill, ablate, gt_words);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, ablate, gt_words);
 }
 
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
@@ -678,7 +682,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, (cap_rows + 1) * 8, (void**)&lc.own_off, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&lc.q_own, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 2) * 8, (void**)&own_base, &scratch.bufs));
-    lc.claim = idx->t4_claim; lc.gen = ++idx->t4_gen; lc.own_base = own_base;
+    lc.claim = idx->t4_claim; lc.gen = ++idx->t4_gen; lc.own_base = own_base; lc.rows_cap = cap_rows;
     hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
     hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, lc);
@@ -771,6 +775,22 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       constexpr bool kTune = false;
 #endif
       const bool wide = idx->d.wpc > 63;
+      if (idx->opts.fill_split && share && !wide && idx->d.use_bv) {
+        // the listed variants (64 rows per task: lane per group of 8 carriers) and the denser ones (16 rows per task: wave per
+        // variant) as two launches side by side on two streams
+        if (!idx->fill_stream) {
+          HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
+          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
+          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
+        HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
+        const unsigned blocks64 = (unsigned)(((n_fill + 63) / 64 + 3) / 4), blocks16 = (unsigned)(((n_fill + 15) / 16 + 3) / 4);
+        launch_fill<false, 64, kTune, 1>(idx, d, share, u_site, n_fill, blocks64, lds_bytes, ablate, gt_words, idx->fill_stream);
+        launch_fill<false, 16, kTune, 2>(idx, d, share, u_site, n_fill, blocks16, lds_bytes, ablate, gt_words);
+        HIP_TRY(hipEventRecord(idx->fill_ev[1], idx->fill_stream));
+        HIP_TRY(hipStreamWaitEvent(idx->stream, idx->fill_ev[1], 0));
+      } else
       switch (chunk) {
         case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
                       : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
@@ -1245,6 +1265,8 @@ void vs_index_close(vs_index* idx) {
     for (auto& b : idx->pool) (void)hipFree(b.p);
     for (auto& b : idx->pin_pool) (void)hipHostFree(b.p);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
+    if (idx->fill_stream) (void)hipStreamDestroy(idx->fill_stream);
+    for (auto& e : idx->fill_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     if (idx->pinned) (void)hipHostFree(idx->pinned);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1391,6 +1413,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_skip") o.t4_skip = value != 0;
   else if (k == "t4_coop") o.t4_coop = value == 16 ? 16 : (value ? 8 : 0);
   else if (k == "share_lists") o.share_lists = value != 0;
+  else if (k == "fill_split") o.fill_split = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
     o.fill_chunk = (uint32_t)value;

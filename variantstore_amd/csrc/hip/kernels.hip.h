@@ -889,10 +889,12 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // one wave of occupancy -- is compiled out.
 // EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
 // per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
-template <bool WIDE, bool EARLY_NIB, bool TUNE = false>
+// PART: 0 = the whole task; 1 = only its listed variants, 2 = only its denser ones (the two halves of a launch pair that
+// runs side by side on two streams: the list half is loads and stores, the row half LDS and vector work).
+template <bool WIDE, bool EARLY_NIB, bool TUNE = false, int PART = 0>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
                                             uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words) {
-  const uint32_t ablate = TUNE ? ablate_arg : 0u;   // production instantiations carry no ablation tests
+  const uint32_t ablate = (TUNE ? ablate_arg : 0u) | (PART == 2 ? 1u : 0u);   // production instantiations carry no ablation tests
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
@@ -962,7 +964,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
 
   // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
   //                  list phase runs in the shadow of that memory latency ----------------
-  uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
+  uint64_t dmask = PART == 1 ? 0ULL : __ballot(cnt > list_max && !explicit_ids);
   uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
   uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
   if (dmask) {
@@ -1291,7 +1293,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   }
 }
 
-template <bool WIDE, uint32_t CH, bool TUNE>
+template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1313,13 +1315,13 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
       if (cls == kNone) cnt = 0;   // the row shares another row's list (k_t4_claim): nothing to expand here
     }
-    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
 // The same expansion over the UNIQUE sites of a batch whose carrier lists are shared: the slot parameters come straight
 // from the site table (sequential reads, each site once), the arena offset from k_unique_sites.
-template <bool WIDE, uint32_t CH, bool TUNE>
+template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
 __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, const uint32_t* u_site, uint64_t U, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1338,7 +1340,7 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, co
       cls = im.s_class[g];
       gt0 = im.s_gt0[g];
     }
-    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
@@ -2404,12 +2406,17 @@ struct ListClaims {
   uint64_t* q_own;             // [Q] sum of own_pad over a region's rows; its exclusive scan own_base gives the region's part of the arena
   const uint64_t* own_base;    // [Q + 1]
   uint64_t* own_off;           // [rows] arena offset of an owner row's list
+  uint64_t rows_cap;           // entries of own_pad / own_off (the walk's scratch capacity: more rows than that means an overflow, and the batch is redone)
 };
 constexpr uint64_t kClaimRowMask = (1ULL << 40) - 1;
 __global__ void __launch_bounds__(256) k_t4_claim(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const bool live = q < r.Q;
-  const uint64_t n = live ? r.q_nvar[q] : 0, a0 = live ? r.var_begin[q] : 0, s0 = live ? ws.cap_begin[q] : 0;
+  uint64_t n = live ? r.q_nvar[q] : 0;
+  const uint64_t a0 = live ? r.var_begin[q] : 0, s0 = live ? ws.cap_begin[q] : 0;
+  // a region that outgrew its scratch capacity recorded only the first rows (ws.overflow is set and the host redoes the
+  // batch with the two-walk path): nothing beyond the capacity may be read here
+  if (live && (n > ws.cap_begin[q + 1] - s0 || a0 + n > lc.rows_cap)) n = 0;
   uint64_t sum = 0;
   for (uint64_t i = threadIdx.x & 15u; i < n; i += 16) {
     const uint32_t v = ws.cur[s0 + i];
@@ -2432,6 +2439,7 @@ __global__ void __launch_bounds__(256) k_t4_offsets(DevResult r, ListClaims lc) 
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q];
+  if (a0 + n > lc.rows_cap) return;   // (overflowed batch: redone by the host)
   uint64_t at = lc.own_base[q];
   for (uint64_t i = 0; i < n; ++i) { lc.own_off[a0 + i] = at; at += lc.own_pad[a0 + i]; }
 }
