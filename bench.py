@@ -338,15 +338,25 @@ def main():
     regions_dev = torch.from_numpy(regions.astype(np.int64)).to(torch.device("cuda", local_rank)).contiguous()
     torch.cuda.synchronize()
 
+    in_flight = []   # collectives of earlier steps still running beside this step's kernels: (work handle, tensors kept alive)
+
     def step():
         res = vs.get_var_in_ref(regions) if host_regions else vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
         gathered = None
         if use_dist:
-            # the shard sizes are known to every rank without asking (shard_bounds / the fixed per-rank batch)
-            gathered = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True, counts=counts)
+            # the shard sizes are known to every rank without asking (shard_bounds / the fixed per-rank batch); the
+            # all-gather of this step's hit lists runs on RCCL's stream beside the next step's kernels, one step deep
+            recs, cnts, work = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True, counts=counts,
+                                                   async_op=True)
+            in_flight.append((work, recs))
+            while len(in_flight) > 1:
+                in_flight.pop(0)[0][0].wait()
+            gathered = recs
         return res, gathered
 
     def fence():
+        while in_flight:
+            in_flight.pop(0)[0][0].wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

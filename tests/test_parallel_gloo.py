@@ -63,6 +63,10 @@ def _worker(rank, world, port, q):
         ok &= bool(np.array_equal(parts[r]["pos"], want[:, 0]))
         ok &= bool(np.array_equal(parts[r]["region"], (want[:, 3] & np.uint64(0xFFFFFFFF)) + np.uint64(rlo)))
         ok &= bool(np.all(parts[r]["car_count"] == 11)) and bool(np.all(parts[r]["ref_len"] == 1))
+    # the asynchronous form (bench.py overlaps the collective with the next step): same records after work.wait()
+    out2, counts2, (work, _buf) = allgather_hit_lists(FakeResult(_records(rank)), lo, torch.device("cpu"), compact=True, async_op=True)
+    work.wait()
+    ok &= bool(torch.equal(out2, out)) and [int(c) for c in counts2] == [int(c) for c in counts]
     q.put((rank, ok, mine.shape[0], lo))
     dist.destroy_process_group()
 

@@ -26,7 +26,7 @@ def shard_regions(regions, rank, world):
     return regions[lo:hi], lo
 
 
-def allgather_hit_lists(result, region_base, device, compact=False, counts=None):
+def allgather_hit_lists(result, region_base, device, compact=False, counts=None, async_op=False):
     """All-gatherv of hit lists.
 
     compact=False: one 32-byte record per VARIANT (vs_result_pack_headers) -- self-contained rows.
@@ -35,6 +35,9 @@ def allgather_hit_lists(result, region_base, device, compact=False, counts=None)
                    For the bench cohort that is 3.2 MB per rank instead of 650 MB.
     counts: the per-rank record counts when every rank already knows them (compact records of a batch that was
             sharded with shard_bounds: the region counts) -- skips the count all-gather and its host round trip.
+    async_op: start the collective and return at once -- (records, counts, work); the records are valid after
+            work.wait().  The all-gather then runs on RCCL's stream beside whatever the caller launches next (the next
+            batch's kernels): the caller keeps `records` alive until it has waited.
     Returns (records[int64, world x max_n x 4], counts[int64, world]).
     """
     world = dist.get_world_size()
@@ -56,6 +59,9 @@ def allgather_hit_lists(result, region_base, device, compact=False, counts=None)
     else:
         result.pack_headers_into(buf.data_ptr(), max_n, region_base)
     out = torch.empty((world * max_n, 4), dtype=torch.int64, device=device)
+    if async_op:
+        work = dist.all_gather_into_tensor(out, buf, async_op=True)
+        return out.view(world, max_n, 4), counts, (work, buf)   # (buf travels with the handle: it must outlive the collective)
     dist.all_gather_into_tensor(out, buf)
     return out.view(world, max_n, 4), counts
 
