@@ -275,8 +275,8 @@ void vs_result_free(vs_result* r);
  * switch.  Keys: "latency_server" 0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first
  * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
  * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
- * chosen from the batch's shape); "share_lists" 0 = every region gets private copies of its carrier lists even in a
- * sorted batch; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * chosen from the batch's shape); "share_lists" 0 = every region gets private rows and carrier lists even in a sorted
+ * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whenever the batch is sorted; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
  * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
 int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 

@@ -340,7 +340,7 @@ int query_main(const Args& a) {
   if (a.type != 6 && vs_index_sample_id(idx, a.sample.c_str(), &sid) != VS_OK) { error("Sample not found"); abort(); }  // variant_graph.h:2010-2013
   // ---- shards: one per GPU (--ngpus), contiguous pieces of the sorted list ----
   const int ng = (int)std::min<size_t>((size_t)a.ngpus, std::max<size_t>(batch.size(), 1));
-  struct Shard { vs_index* idx = nullptr; size_t lo = 0, hi = 0; vs_result* res = nullptr; vs_result_view v{}; int rc = VS_OK; std::string err; };
+  struct Shard { vs_index* idx = nullptr; size_t lo = 0, hi = 0; vs_result* res = nullptr; vs_result_raw v{}; int rc = VS_OK; std::string err; };
   std::vector<Shard> shards(ng);
   shards[0].idx = idx;
   for (int g = 0; g < ng; ++g) {
@@ -361,9 +361,9 @@ int query_main(const Args& a) {
       std::vector<uint32_t> sids(n, sid);
       sh.rc = vs_query_sample_var_in_sample(sh.idx, rg, n, sids.data(), &sh.res);
     }
-    if (sh.rc == VS_OK) sh.rc = vs_result_get_view(sh.res, 0, &sh.v);
-    // the text of every region is wanted: bring rows and carriers over in ONE raw copy (not one copy per region)
-    if (sh.rc == VS_OK && !a.batch_out.empty()) { vs_result_raw raw; sh.rc = vs_result_get_raw(sh.res, 1, &raw); }
+    // the per-region counts and flags are all the log lines need (the raw form: no per-region expansion on the host); when
+    // the text of every region is wanted, rows and carriers come over in ONE raw copy (not one copy per region)
+    if (sh.rc == VS_OK) sh.rc = vs_result_get_raw(sh.res, a.batch_out.empty() ? 0 : 1, &sh.v);
     if (sh.rc != VS_OK) sh.err = vs_last_error();
   };
   if (ng == 1) run_shard(shards[0], 0);
@@ -380,7 +380,7 @@ int query_main(const Args& a) {
   if (!a.batch_out.empty()) batch_out.open(a.batch_out);
   uint32_t query_num = 0;
   for (auto& sh : shards) {
-    const vs_result_view& v = sh.v;
+    const vs_result_raw& v = sh.v;
     for (uint64_t k = 0; k < v.n_regions; ++k) {
       const uint64_t i = sh.lo + k;
       if (a.type == 6) info("6. Get variants in ref coordinate. " + std::to_string(i));

@@ -62,7 +62,7 @@ struct EngineOpts {
   int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
-  bool share_lists = true;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
+  int share_lists = 1;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
@@ -85,6 +85,8 @@ struct vs_index {
   uint64_t t4_gen = 0;
   hipStream_t fill_stream = nullptr;        // second stream of the split expansion (fill_split)
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
+  int share_hint = -1;                      // did sharing pay on the last shared batch (-1: not known yet)
+  uint32_t share_probe_in = 0;              // private batches until sharing is tried again
   uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
   std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
   hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
@@ -464,7 +466,7 @@ static void read_env_opts(vs_index* idx) {
   o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
-  if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = false;
+  if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = 0;
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 }
@@ -615,7 +617,14 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
   // Shared carrier lists (kernels.hip.h: k_share_*): a sorted type-6 batch expands every site it covers once and lets
   // all regions that report the site point at that one list.  Not for batches the latency path would take anyway.
+  // Sharing pays when the batch's regions overlap (its price: two more scans over the regions); whether they do is known
+  // only afterwards, so the handle remembers: a shared batch whose table came out nearly as long as the rows it stands
+  // for (> 80 %) sends the following batches down the private path, which looks again every 32nd batch.
+  // share_lists = 2 shares whenever the batch is sorted.
   bool share = !t4 && !point_mode && idx->opts.share_lists && n > 64;
+  if (share && idx->opts.share_lists == 1 && idx->share_hint == 0) {
+    if (idx->share_probe_in > 0) { --idx->share_probe_in; share = false; }
+  }
   uint32_t* sh_new_start = nullptr;
   uint64_t *sh_u_begin = nullptr, *sh_arena_new = nullptr;
   uint64_t n_unique = 0;
@@ -658,6 +667,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     r->n_rows_reported = ((volatile uint64_t*)pin_totals)[4];
     if (((volatile uint64_t*)pin_totals)[3]) { share = false; d.q_car_len = nullptr; }   // not sorted by first site: private rows and lists
     else {   // (only now: it overwrites the per-region counts the private path scans)
+      idx->share_hint = totals[0] * 5 <= r->n_rows_reported * 4 ? 1 : 0;
+      if (!idx->share_hint) idx->share_probe_in = 32;
       hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan4*)tile_sums,
                          sh_new_start, sh_u_begin, sh_arena_new);
       HIP_TRY(hipGetLastError());
@@ -1412,7 +1423,10 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
   else if (k == "t4_skip") o.t4_skip = value != 0;
   else if (k == "t4_coop") o.t4_coop = value == 16 ? 16 : (value ? 8 : 0);
-  else if (k == "share_lists") o.share_lists = value != 0;
+  else if (k == "share_lists") {
+    if (value < 0 || value > 2) return fail(VS_ERR_ARG, "share_lists takes 0 (never), 1 (when it pays, default) or 2 (whenever the batch is sorted)");
+    o.share_lists = (int)value; idx->share_hint = -1; idx->share_probe_in = 0;
+  }
   else if (k == "fill_split") o.fill_split = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
