@@ -770,6 +770,31 @@ def test_positions_far_beyond_the_reference(tmp_path):
         assert (n < 0) == bool(flags[q] & 4) and (n < 0 or res.region_text(q) == text), p
 
 
+def test_sharing_is_given_up_when_the_regions_barely_overlap(tmp_path):
+    """`share_lists` 1 (default): a sorted batch whose shared table is nearly as long as the rows it stands for tells the
+    handle that the two extra scans do not pay; the next batches take private rows (same answers), 2 shares regardless."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 611, n_rows=600, ref_len=30000, n_samples=20)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    L = vs.info().ref_length
+    regions = [(x, x + 260) for x in range(1, L - 300, 250)]           # neighbours share 10 of 260 bases
+    assert len(regions) > 64
+    first = vs.get_var_in_ref(regions)
+    second = vs.get_var_in_ref(regions)
+    assert first.layout()[4] and not second.layout()[4]
+    assert first.digest() == second.digest() and first.totals() == second.totals()
+    for q, (x, y) in enumerate(regions):
+        n, _, text = orc.get_var_in_ref(x, y)
+        if n >= 0:
+            assert first.region_text(q) == text and second.region_text(q) == text, (x, y)
+    vs.set_option("share_lists", 2)
+    forced = vs.get_var_in_ref(regions)
+    assert forced.layout()[4] and forced.digest() == first.digest()
+    vs.set_option("share_lists", 1)                                     # (forgets what the handle had learnt)
+    wide = sorted((x, x + 2000) for x in range(1, L - 2100, 150))       # 13 regions over every base: sharing pays
+    a, b = vs.get_var_in_ref(wide), vs.get_var_in_ref(wide)
+    assert a.layout()[4] and b.layout()[4] and a.digest() == b.digest()
+
+
 @pytest.mark.parametrize("seed,kw", [
     (601, dict(n_rows=400, ref_len=5000, n_samples=70, carrier_p=0.4)),                      # class rows wider than one word
     (602, dict(n_rows=400, ref_len=4000, p_near=0.7, p_multi=0.3, p_same=0.25)),              # crowded: the duplicate rule fires
