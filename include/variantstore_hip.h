@@ -226,7 +226,10 @@ typedef struct {
   uint32_t carrier_bytes;        /* 2 or 4 */
   const void* arena;             /* [arena_entries], page-locked; NULL when carriers were not copied */
   const char* seq_pool;
-  int shared;                    /* rows and lists shared between regions (vs_result_layout) */
+  int shared;                    /* bit 0: rows and lists shared between regions (vs_result_layout); bit 1: `arena` is the
+                                  * handle's host mirror of the index's RESIDENT carrier lists ("resident_lists"): nothing
+                                  * but the rows was copied for this result, and the pointer stays valid until the index
+                                  * is closed */
 } vs_result_raw;
 int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw);
 
@@ -277,6 +280,10 @@ void vs_result_free(vs_result* r);
  * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
  * chosen from the batch's shape); "share_lists" 0 = every region gets private rows and carrier lists even in a sorted
  * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whenever the batch is sorted; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * "resident_lists" 1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
+ * 4 bytes per carrier record; VS_ERR_UNSUPPORTED when that does not fit): batches of query types 6 and 4 then emit rows
+ * that point into it, expand nothing and own no arena, and a raw copy moves the rows only (default 0; VS_RESIDENT_LISTS=1
+ * in the environment builds it when the handle is opened);
  * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
 int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 

@@ -145,7 +145,8 @@ class QueryResult:
         return {"region_flags": arr(rr.region_flags, q, np.uint8), "row_begin": arr(rr.row_begin, q, np.uint64),
                 "row_count": arr(rr.row_count, q, np.uint64), "var_count": arr(rr.var_count, q, np.uint64),
                 "car_base": arr(rr.car_base, q, np.uint64), "car_len": arr(rr.car_len, q, np.uint64),
-                "rows": rows, "arena": arena, "carrier_bytes": int(rr.carrier_bytes), "shared": bool(rr.shared)}
+                "rows": rows, "arena": arena, "carrier_bytes": int(rr.carrier_bytes), "shared": bool(rr.shared & 1),
+                "resident": bool(rr.shared & 2)}
 
     def num_header_records(self):
         n = C.c_uint64()

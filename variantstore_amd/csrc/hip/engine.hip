@@ -62,6 +62,7 @@ struct EngineOpts {
   int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
+  bool resident_lists = false;  // carrier lists expanded once into an arena that stays with the index (build_resident_lists): results hold rows only
   int share_lists = 1;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
@@ -88,6 +89,11 @@ struct vs_index {
   int share_hint = -1;                      // did sharing pay on the last shared batch (-1: not known yet)
   uint32_t share_probe_in = 0;              // private batches until sharing is tried again
   uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
+  // resident carrier lists (DevImage::v_abegin): the arena, its length in entries, and -- once a caller has asked for
+  // carriers on the host -- its page-locked host mirror, shared by every result of the handle
+  void* res_arena = nullptr;
+  uint64_t res_entries = 0, res_site_entries = 0;
+  void* res_mirror = nullptr;
   std::vector<DevBuf> pin_pool;        // page-locked host buffers of raw result copies (vs_result_get_raw), reused between results
   hipStream_t copy_stream = nullptr;   // device-to-host copies of the streamed form run here, beside the next chunk's kernels
   vs_timing timing{};
@@ -136,6 +142,7 @@ struct vs_result {
   bool shared_lists = false;          // rows and carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
   uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the rows
   uint64_t n_rows_reported = 0;       // rows over all regions (shared rows counted once per region that reports them)
+  bool resident = false;              // the carrier arena is the index's (vs_index::res_arena), not this result's
   bool scattered_lists = false;       // lists shared per vertex (walking query types): a region's carriers are not one arena range
   std::vector<uint64_t> h_car_len;
   // the rows of ONE region, fetched when the whole table is not on the host (vs_result_format_region)
@@ -467,10 +474,12 @@ static void read_env_opts(vs_index* idx) {
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
   if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = 0;
+  o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 }
 
+static int build_resident_lists(vs_index* idx);
 static int finish_open(vs_index* idx, int device) {
   try {
     read_env_opts(idx);
@@ -486,7 +495,12 @@ static int finish_open(vs_index* idx, int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VS_ERR_NO_DEVICE, "no HIP device is visible");
   if (device >= ndev) return fail(VS_ERR_NO_DEVICE, "device %d requested, %d visible", device, ndev);
-  return build_device_image(idx);
+  VS_TRY(build_device_image(idx));
+  if (idx->opts.resident_lists) {   // VS_RESIDENT_LISTS: over budget is not an error at open, the lists are then expanded per batch
+    idx->opts.resident_lists = false;
+    if (build_resident_lists(idx) == VS_OK) idx->opts.resident_lists = true;
+  }
+  return VS_OK;
 }
 
 template <typename T>
@@ -519,6 +533,147 @@ static void launch_fill(vs_index* idx, const DevResult& d, bool share, const uin
   if (!stream) stream = idx->stream;
   if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, u_site, n_fill, ablate, gt_words);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, ablate, gt_words);
+}
+
+// The carrier expansion of one result (or of the resident arena): one launch over n_fill rows.
+static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill) {
+  if (n_fill) {
+    {
+      // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
+      // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time).
+      // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
+      // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
+      uint32_t chunk = idx->opts.fill_chunk;
+      if (chunk == 0) chunk = (share || (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256)) ? 16 : 64;
+      const uint64_t nchunks = (n_fill + chunk - 1) / chunk;
+      const uint64_t blocks = (nchunks + 3) / 4;
+      if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
+      // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
+      const uint32_t gt_words = fill_gt_words(idx);
+#ifdef VS_TUNING   // tuning builds: one regime of the kernel can be skipped, the LDS block padded (tools/exp_fill.py)
+      const size_t lds_bytes = fill_lds_bytes(idx) + std::min<size_t>(idx->opts.fill_lds_pad, 96 << 10);
+      const uint32_t ablate = idx->opts.fill_ablate;
+      constexpr bool kTune = true;
+#else
+      const size_t lds_bytes = fill_lds_bytes(idx);
+      const uint32_t ablate = 0;
+      constexpr bool kTune = false;
+#endif
+      const bool wide = idx->d.wpc > 63;
+      if (idx->opts.fill_split && share && !wide && idx->d.use_bv) {
+        // the listed variants (64 rows per task: lane per group of 8 carriers) and the denser ones (16 rows per task: wave per
+        // variant) as two launches side by side on two streams
+        if (!idx->fill_stream) {
+          HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
+          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
+          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
+        HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
+        const unsigned blocks64 = (unsigned)(((n_fill + 63) / 64 + 3) / 4), blocks16 = (unsigned)(((n_fill + 15) / 16 + 3) / 4);
+        launch_fill<false, 64, kTune, 1>(idx, d, share, u_site, n_fill, blocks64, lds_bytes, ablate, gt_words, idx->fill_stream);
+        launch_fill<false, 16, kTune, 2>(idx, d, share, u_site, n_fill, blocks16, lds_bytes, ablate, gt_words);
+        HIP_TRY(hipEventRecord(idx->fill_ev[1], idx->fill_stream));
+        HIP_TRY(hipStreamWaitEvent(idx->stream, idx->fill_ev[1], 0));
+      } else
+      switch (chunk) {
+        case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        case 16: wide ? launch_fill<true, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        case 32: wide ? launch_fill<true, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        default: wide ? launch_fill<true, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
+                      : launch_fill<false, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return VS_OK;
+}
+
+// Resident carrier lists (option "resident_lists"): every carrier list a query can report is a function of the index
+// alone -- a site's list is its vertex's -- so it can be expanded ONCE, with the kernel the queries would run, into an
+// arena that stays with the handle: 2 (4) bytes per carrier record of HBM bought back as the whole expansion of every
+// later batch, and as 9/10 of what a result sends across PCIe (rows only; the host keeps one mirror of the arena).
+// Layout: the sites' lists in site-table order at s_carpre[g] -- a region's lists stay ONE range, everything downstream
+// of car_base is unchanged -- followed by the lists of vertices that only the walking query types report (no site, or
+// a site the reference never reports).
+static int build_resident_lists(vs_index* idx) {
+  if (idx->res_arena) return VS_OK;
+  if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
+  HIP_TRY(hipSetDevice(idx->device));
+  if (idx->srv_alive) VS_TRY(server_stop(idx));
+  const HostImage& im = idx->im;
+  const uint64_t G = idx->d.G, V = idx->d.V;
+  std::vector<uint32_t> s_vid(G), s_ncar(G);
+  if (G) {
+    HIP_TRY(hipMemcpyAsync(s_vid.data(), idx->d.s_vid, G * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(s_ncar.data(), idx->d.s_ncar, G * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+  }
+  std::vector<uint64_t> v_abegin(V, ~0ull), x_begin;
+  std::vector<uint32_t> x_vid;
+  for (uint64_t g = 0; g < G; ++g) {
+    const uint32_t v = s_vid[g];
+    if (s_ncar[g] && s_ncar[g] == im.v_ncar[v] && v_abegin[v] == ~0ull) v_abegin[v] = idx->h_carpre[g];
+  }
+  uint64_t total = idx->h_carpre[G];
+  idx->res_site_entries = total;
+  for (uint64_t v = 0; v < V; ++v)
+    if (im.v_ncar[v] && v_abegin[v] == ~0ull) {
+      v_abegin[v] = total; x_vid.push_back((uint32_t)v); x_begin.push_back(total);
+      total += pad_car(im.v_ncar[v]);
+    }
+  const uint64_t X = x_vid.size(), A = G + X;
+  const uint32_t width = idx->d.wpc <= 63 ? 2 : 4;
+  const uint64_t arena_bytes = total * width + 16, temp_bytes = A * (sizeof(VariantRow) + 12) + X * 12;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (arena_bytes + temp_bytes + V * 8 > free_b / 2)
+    return fail(VS_ERR_UNSUPPORTED, "resident carrier lists need %.1f GB of HBM, %.1f GB are free", (arena_bytes + temp_bytes + V * 8) / 1e9, free_b / 1e9);
+  void* arena = nullptr;
+  HIP_TRY(hipMalloc(&arena, arena_bytes));
+  idx->image_allocs.push_back(arena);
+  const uint64_t* d_abegin = nullptr;
+  VS_TRY(upload_image(idx, v_abegin, &d_abegin));
+  if (A) {
+    ScratchBufs tmp(idx);
+    DevResult d{};
+    uint32_t* dx_vid = nullptr; uint64_t* dx_begin = nullptr;
+    VS_TRY(dev_alloc(idx, A * sizeof(VariantRow), (void**)&d.rows, &tmp.bufs));
+    VS_TRY(dev_alloc(idx, A * 4, (void**)&d.r_class, &tmp.bufs));
+    VS_TRY(dev_alloc(idx, A * 8, (void**)&d.r_gt0, &tmp.bufs));
+    VS_TRY(dev_alloc(idx, X * 4, (void**)&dx_vid, &tmp.bufs));
+    VS_TRY(dev_alloc(idx, X * 8, (void**)&dx_begin, &tmp.bufs));
+    if (X) {
+      HIP_TRY(hipMemcpyAsync(dx_vid, x_vid.data(), X * 4, hipMemcpyHostToDevice, idx->stream));
+      HIP_TRY(hipMemcpyAsync(dx_begin, x_begin.data(), X * 8, hipMemcpyHostToDevice, idx->stream));
+    }
+    d.A = A; d.S = total; d.carriers = arena; d.car_width = width;
+    hipLaunchKernelGGL(k_resident_params, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, idx->stream, idx->d, (const uint32_t*)dx_vid, (const uint64_t*)dx_begin, X,
+                       d.rows, d.r_class, d.r_gt0);
+    HIP_TRY(hipGetLastError());
+    VS_TRY(fill_lists(idx, d, false, nullptr, A));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    tmp.release();
+  }
+  idx->device_bytes += arena_bytes;
+  idx->d.v_abegin = d_abegin;
+  idx->res_entries = total;
+  idx->res_arena = arena;
+  return VS_OK;
+}
+// the arena's host mirror: page-locked, copied over once, shared by the handle's results
+static int ensure_resident_mirror(vs_index* idx) {
+  if (idx->res_mirror) return VS_OK;
+  const uint32_t width = idx->d.wpc <= 63 ? 2 : 4;
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, idx->res_entries * width + 16, hipHostMallocDefault));
+  const hipError_t e = hipMemcpy(p, idx->res_arena, idx->res_entries * width, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { (void)hipHostFree(p); return fail(VS_ERR_HIP, "copy of the resident carrier lists failed: %s", hipGetErrorString(e)); }
+  idx->res_mirror = p;
+  return VS_OK;
 }
 
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
@@ -615,6 +770,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
   uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
+  // Resident carrier lists: the rows point into the index's arena; nothing is expanded, the result owns no arena.
+  bool resident = idx->opts.resident_lists && idx->res_arena && !point_mode && !(t4 && (walk_mode == 5 || !single_walk));
   // Shared carrier lists (kernels.hip.h: k_share_*): a sorted type-6 batch expands every site it covers once and lets
   // all regions that report the site point at that one list.  Not for batches the latency path would take anyway.
   // Sharing pays when the batch's regions overlap (its price: two more scans over the regions); whether they do is known
@@ -671,6 +828,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       if (!idx->share_hint) idx->share_probe_in = 32;
       hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan4*)tile_sums,
                          sh_new_start, sh_u_begin, sh_arena_new);
+      if (resident) {
+        hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start, sh_arena_new, idx->res_entries);
+        totals[1] = idx->res_entries;
+      }
       HIP_TRY(hipGetLastError());
     }
   }
@@ -680,7 +841,11 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (!share) {
   VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
-  if (single_walk && walk_mode != 5 && idx->opts.share_lists && n > 64) {
+  if (resident && !t4) {
+    VS_TRY(ralloc(r, n, &d.q_car_len));   // (before the header kernels overwrite q_ncar with the reported carriers)
+    hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)nullptr, (uint64_t*)nullptr, idx->res_entries);
+  }
+  if (single_walk && walk_mode != 5 && idx->opts.share_lists && n > 64 && !resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
     const uint64_t cap_rows = ws_capacity;
     if (!idx->t4_claim) {
@@ -704,10 +869,12 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   totals[0] = ((volatile uint64_t*)pin_totals)[0];
   totals[1] = ((volatile uint64_t*)pin_totals)[1];
   if (share_t4 && !walk_overflow) totals[1] = t4_arena;
+  if (resident && !(single_walk && walk_overflow)) totals[1] = idx->res_entries;
   }
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     share_t4 = false;
+    resident = false;
     if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
@@ -719,15 +886,19 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   d.S = totals[1];
   VS_TRY(ralloc(r, d.A, &d.rows));
   if (!share) {   // row parameters of k_fill_carriers (shared lists are expanded from the site table)
-    VS_TRY(ralloc(r, d.A, &d.r_class));
-    VS_TRY(ralloc(r, d.A, &d.r_gt0));
+    if (!resident) {
+      VS_TRY(ralloc(r, d.A, &d.r_class));
+      VS_TRY(ralloc(r, d.A, &d.r_gt0));
+    }
     r->n_rows_reported = d.A;
   }
   r->shared_lists = share || share_t4;
-  r->scattered_lists = share_t4;      // a region's lists are not one arena range: texts come from a raw copy
-  r->n_unique_sites = share ? n_unique : d.A;
+  r->resident = resident;
+  r->scattered_lists = share_t4 || (resident && t4);   // a region's lists are not one arena range: texts come from a raw copy
+  r->n_unique_sites = resident ? 0 : (share ? n_unique : d.A);
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
-  {
+  if (resident) d.carriers = idx->res_arena;
+  else {
     uint8_t* arena = nullptr;
     VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
     d.carriers = arena;
@@ -735,9 +906,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   uint32_t* u_site = nullptr;
   if (n) {
-    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, false>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
@@ -745,7 +917,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
         VS_TRY(dev_alloc(idx, n_unique * 4 + 8, (void**)&u_site, &scratch.bufs));
         hipLaunchKernelGGL(k_share_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start,
                            (const uint64_t*)sh_u_begin, (const uint64_t*)sh_arena_new, u_site);
-      } else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      } else if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
       if (strings) {
         uint8_t* dchars = nullptr;
@@ -762,59 +935,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
-  const uint64_t n_fill = share ? n_unique : d.A;   // lists to expand: shared rows resp. all rows
-  if (n_fill) {
-    {
-      // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
-      // hardware's block scheduler balances that better than a static round-robin (8192-block grid: +8 % kernel time).
-      // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
-      // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
-      uint32_t chunk = idx->opts.fill_chunk;
-      if (chunk == 0) chunk = (share || (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256)) ? 16 : 64;
-      const uint64_t nchunks = (n_fill + chunk - 1) / chunk;
-      const uint64_t blocks = (nchunks + 3) / 4;
-      if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
-      // per-wave LDS: one genotype byte per carrier of the widest variant the staged paths take, plus the ring
-      const uint32_t gt_words = fill_gt_words(idx);
-#ifdef VS_TUNING   // tuning builds: one regime of the kernel can be skipped, the LDS block padded (tools/exp_fill.py)
-      const size_t lds_bytes = fill_lds_bytes(idx) + std::min<size_t>(idx->opts.fill_lds_pad, 96 << 10);
-      const uint32_t ablate = idx->opts.fill_ablate;
-      constexpr bool kTune = true;
-#else
-      const size_t lds_bytes = fill_lds_bytes(idx);
-      const uint32_t ablate = 0;
-      constexpr bool kTune = false;
-#endif
-      const bool wide = idx->d.wpc > 63;
-      if (idx->opts.fill_split && share && !wide && idx->d.use_bv) {
-        // the listed variants (64 rows per task: lane per group of 8 carriers) and the denser ones (16 rows per task: wave per
-        // variant) as two launches side by side on two streams
-        if (!idx->fill_stream) {
-          HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
-          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
-          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
-        HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
-        const unsigned blocks64 = (unsigned)(((n_fill + 63) / 64 + 3) / 4), blocks16 = (unsigned)(((n_fill + 15) / 16 + 3) / 4);
-        launch_fill<false, 64, kTune, 1>(idx, d, share, u_site, n_fill, blocks64, lds_bytes, ablate, gt_words, idx->fill_stream);
-        launch_fill<false, 16, kTune, 2>(idx, d, share, u_site, n_fill, blocks16, lds_bytes, ablate, gt_words);
-        HIP_TRY(hipEventRecord(idx->fill_ev[1], idx->fill_stream));
-        HIP_TRY(hipStreamWaitEvent(idx->stream, idx->fill_ev[1], 0));
-      } else
-      switch (chunk) {
-        case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        case 16: wide ? launch_fill<true, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        case 32: wide ? launch_fill<true, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        default: wide ? launch_fill<true, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-      }
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  const uint64_t n_fill = resident ? 0 : (share ? n_unique : d.A);   // lists to expand: shared rows resp. all rows; none with resident lists
+  VS_TRY(fill_lists(idx, d, share, u_site, n_fill));
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   scratch.release();
@@ -1275,6 +1397,7 @@ void vs_index_close(vs_index* idx) {
     for (auto p : idx->image_allocs) (void)hipFree(p);
     for (auto& b : idx->pool) (void)hipFree(b.p);
     for (auto& b : idx->pin_pool) (void)hipHostFree(b.p);
+    if (idx->res_mirror) (void)hipHostFree(idx->res_mirror);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->fill_stream) (void)hipStreamDestroy(idx->fill_stream);
     for (auto& e : idx->fill_ev) if (e) (void)hipEventDestroy(e);
@@ -1426,6 +1549,11 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "share_lists") {
     if (value < 0 || value > 2) return fail(VS_ERR_ARG, "share_lists takes 0 (never), 1 (when it pays, default) or 2 (whenever the batch is sorted)");
     o.share_lists = (int)value; idx->share_hint = -1; idx->share_probe_in = 0;
+  }
+  else if (k == "resident_lists") {
+    if (value != 0 && value != 1) return fail(VS_ERR_ARG, "resident_lists takes 0 or 1");
+    if (value) VS_TRY(build_resident_lists(idx));   // (kept once built: switching back to 0 only stops results from using it)
+    o.resident_lists = value != 0;
   }
   else if (k == "fill_split") o.fill_split = value != 0;
   else if (k == "fill_chunk") {
@@ -1672,8 +1800,9 @@ int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vert
 static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) {
   vs_index* idx = r->idx;
   const DevResult& d = r->d;
-  const size_t row_bytes = (size_t)d.A * sizeof(VariantRow), arena_bytes = with_carriers ? (size_t)d.S * d.car_width : 0;
+  const size_t row_bytes = (size_t)d.A * sizeof(VariantRow), arena_bytes = with_carriers && !r->resident ? (size_t)d.S * d.car_width : 0;
   if (r->raw_rows && (r->raw_arena || !with_carriers)) return VS_OK;
+  if (with_carriers && r->resident) VS_TRY(ensure_resident_mirror(idx));   // the rows point into the handle's mirror of the resident arena
   if (r->raw_pin.p) { pin_release(idx, r->raw_pin); r->raw_pin = DevBuf{nullptr, 0}; r->raw_rows = nullptr; r->raw_arena = nullptr; }
   VS_TRY(pin_alloc(idx, row_bytes + arena_bytes + 64, &r->raw_pin));
   uint8_t* base = (uint8_t*)r->raw_pin.p;
@@ -1681,7 +1810,7 @@ static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) 
   const size_t arena_at = (row_bytes + 63) & ~(size_t)63;
   if (arena_bytes) HIP_TRY(hipMemcpyAsync(base + arena_at, d.carriers, arena_bytes, hipMemcpyDeviceToHost, stream));
   r->raw_rows = (const VariantRow*)base;
-  r->raw_arena = with_carriers ? base + arena_at : nullptr;
+  r->raw_arena = !with_carriers ? nullptr : r->resident ? (const uint8_t*)idx->res_mirror : base + arena_at;
   return VS_OK;
 }
 static void fill_raw(vs_result* r, vs_result_raw* raw) {
@@ -1698,7 +1827,7 @@ static void fill_raw(vs_result* r, vs_result_raw* raw) {
   raw->carrier_bytes = r->d.car_width;
   raw->arena = r->raw_arena;
   raw->seq_pool = r->idx->seq_chars.data();
-  raw->shared = r->shared_lists ? 1 : 0;
+  raw->shared = (r->shared_lists ? 1 : 0) | (r->resident ? 2 : 0);
 }
 
 int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw) {
@@ -1766,13 +1895,26 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view) {
   VS_TRY(fetch_headers(r));
   if (with_carriers && !r->have_carriers) {
     // the arena pads every variant's range; the view packs the lists back to back
-    std::vector<uint32_t> arena;
-    VS_TRY(fetch_carriers(r, 0, r->d.S, arena));
     r->h_carriers.resize(r->n_view_carriers);
     const uint64_t ns = r->h_view_begin[r->d.Q];
+    if (r->resident) {   // from the handle's mirror of the resident arena
+      HIP_TRY(hipSetDevice(r->idx->device));
+      VS_TRY(ensure_resident_mirror(r->idx));
+      const uint16_t* m16 = (const uint16_t*)r->idx->res_mirror;
+      const uint32_t* m32 = (const uint32_t*)r->idx->res_mirror;
+      for (uint64_t a = 0; a < ns; ++a) {
+        uint32_t* dst = r->h_carriers.data() + r->h_car_begin_view[a];
+        const uint64_t src = r->h_car_begin[a];
+        if (r->d.car_width == 4) { if (r->h_car_count[a]) memcpy(dst, m32 + src, (size_t)r->h_car_count[a] * 4); }
+        else for (uint32_t k = 0; k < r->h_car_count[a]; ++k) { const uint32_t c = m16[src + k]; dst[k] = (c & 0x1FFFu) | ((c >> 13) << 29); }
+      }
+    } else {
+    std::vector<uint32_t> arena;
+    VS_TRY(fetch_carriers(r, 0, r->d.S, arena));
     for (uint64_t a = 0; a < ns; ++a)
       if (r->h_car_count[a])
         memcpy(r->h_carriers.data() + r->h_car_begin_view[a], arena.data() + r->h_car_begin[a], (size_t)r->h_car_count[a] * 4);
+    }
     r->have_carriers = true;
   }
   view->n_regions = r->d.Q;
@@ -1938,7 +2080,7 @@ int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows
   VS_NOT_SEQ(r);
   if (n_slots) *n_slots = r->n_rows_reported;
   if (table_rows) *table_rows = r->d.A;
-  if (arena_entries) *arena_entries = r->d.S;
+  if (arena_entries) *arena_entries = r->resident ? 0 : r->d.S;   // (a result over resident lists owns no arena)
   if (lists_expanded) *lists_expanded = r->n_unique_sites;
   if (shared) *shared = r->shared_lists ? 1 : 0;
   return VS_OK;

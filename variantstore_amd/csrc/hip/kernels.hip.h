@@ -104,6 +104,11 @@ struct DevImage {
   const uint32_t* blob_of_slot;   // [P + 1] header record of each ref-path slot
   const uint32_t* blob_row;       // [V] first edge record of each vertex
   const uint2* rk_back;     // [R] per rank r: {first ref-path slot of r (= Index::previous(r + 1)), out-degree of that node}
+  // RESIDENT carrier lists (option "resident_lists"; engine.hip: build_resident_lists): every list a query can report,
+  // expanded once into an arena that stays with the index -- the lists of the sites in site-table order at s_carpre[g]
+  // (so a region's lists are ONE arena range, [s_carpre[g0], s_carpre[g1])), then the lists of the vertices only the
+  // walking query types report.  A result then holds rows that point into this arena and no arena of its own.
+  const uint64_t* v_abegin;   // [V] arena offset of each vertex's list (~0: the vertex has no carriers); NULL: not built
 };
 
 // One row of a result's VARIANT TABLE (what the reference's `Variant` holds, query.h:30-36, with the strings and the
@@ -168,6 +173,19 @@ __host__ __device__ __forceinline__ uint32_t pad_car(uint32_t n) { return (n + k
 __global__ void __launch_bounds__(256) k_pad_counts(const uint32_t* in, uint32_t* out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = pad_car(in[i]);
+}
+
+// Rows + parameters of the ONE expansion that builds the resident arena (k_fill_carriers over them): the G sites, then
+// the X vertices without a usable site (x_vid, lists at x_begin).
+__global__ void __launch_bounds__(256) k_resident_params(DevImage im, const uint32_t* x_vid, const uint64_t* x_begin, uint64_t X,
+                                                         VariantRow* rows, uint32_t* r_class, uint64_t* r_gt0) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= im.G + X) return;
+  uint32_t cnt, cls; uint64_t gt0, cb;
+  if (i < im.G) { cnt = im.s_ncar[i]; cls = im.s_class[i]; gt0 = im.s_gt0[i]; cb = im.s_carpre[i]; }
+  else { const uint32_t v = x_vid[i - im.G]; cnt = im.v_ncar[v]; cls = im.v_src[v]; gt0 = im.v_car_begin[v]; cb = x_begin[i - im.G]; }
+  row_store(rows, i, 0, 0, 0, 0, 0, cnt, false, cb);
+  r_class[i] = cls; r_gt0[i] = gt0;
 }
 
 // ones in bit positions [0, p): number of ref-node start indexes <= p
@@ -709,6 +727,20 @@ __global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResu
     ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new; ex.p += slow[i] ? nvs[i] : 0;
   }
 }
+// Resident carrier lists: a region's lists ARE the arena range of its sites -- car_base = s_carpre[g0] whatever the
+// scans made of it (and the start of the region's new part likewise, for k_share_rows).
+__global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r, const uint32_t* new_start, uint64_t* arena_new, uint64_t arena_entries) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == r.Q) r.car_base[q] = arena_entries;
+  if (q >= r.Q) return;
+  const uint64_t n = r.q_nvar[q];
+  const uint32_t g0 = n ? r.q_g0[q] : 0u;
+  const uint64_t pre = im.s_carpre[g0];
+  r.car_base[q] = pre;
+  r.q_car_len[q] = im.s_carpre[g0 + n] - pre;
+  if (arena_new) arena_new[q] = im.s_carpre[new_start[q]];
+}
+
 // The shared rows: every region writes the rows of the sites it is the first to cover (one wave per region), and the
 // site index beside them for the expansion; regions under the duplicate rule also get their private copy.
 __global__ void __launch_bounds__(256) k_share_rows(DevImage im, DevResult r, const uint32_t* new_start, const uint64_t* u_begin, const uint64_t* arena_new,
@@ -2444,7 +2476,8 @@ __global__ void __launch_bounds__(256) k_t4_offsets(DevResult r, ListClaims lc) 
   for (uint64_t i = 0; i < n; ++i) { lc.own_off[a0 + i] = at; at += lc.own_pad[a0 + i]; }
 }
 
-template <bool RESOLVE, bool SHARED>
+// LISTS 0: private list per row, 1: the list of the vertex's owner row (claims), 2: the index's resident list of the vertex
+template <bool RESOLVE, int LISTS>
 __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t l16 = threadIdx.x & 15u, row_last = (threadIdx.x & 63u) | 15u;
@@ -2476,13 +2509,14 @@ __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r
       else wv = WalkVariant{ws.pos[s], ws.ro[s], ws.rl[s], ws.ao[s], ws.al[s]};
       uint64_t at = cb + (incl - pad_car(c));
       bool owner = true;
-      if (SHARED) {   // the list lives where the vertex's owner row put it
+      if (LISTS == 1) {   // the list lives where the vertex's owner row put it
         const uint64_t o = (lc.claim[cur] & kClaimRowMask) - 1;
         at = lc.own_off[o];
         owner = o == a;
       }
+      if (LISTS == 2) at = c ? im.v_abegin[cur] : 0;
       row_store(r.rows, a, (uint32_t)wv.pos, wv.ro, wv.rl, wv.ao, wv.al, c, false, at);
-      r.r_class[a] = owner ? im.v_src[cur] : kNone; r.r_gt0[a] = im.v_car_begin[cur];
+      if (LISTS != 2) { r.r_class[a] = owner ? im.v_src[cur] : kNone; r.r_gt0[a] = im.v_car_begin[cur]; }
     }
     cb += (uint32_t)__shfl((int)incl, (int)row_last, 64);
     kept += (uint32_t)__shfl((int)csum, (int)row_last, 64);
