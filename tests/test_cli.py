@@ -165,3 +165,30 @@ def test_draw_writes_graph_dot(golden_dir, tmp_path):
     assert "Chromosome: x #Vertices: 212 #Edges: 0 Seq length: 1074" in msgs
     text = open(os.path.join(d, "graph.dot")).read()
     assert text.startswith("digraph {\n") and text.endswith("}") and " -> " in text and "ref i:" in text
+
+
+@pytest.mark.gpu
+def test_query_batch_file_with_resident_lists(golden_dir, tmp_path):
+    """`-r @FILE --batch-out` over more regions than the latency path takes, with and without `--resident-lists`
+    (every carrier list of the index expanded once at open; rows only cross PCIe): same counts, same texts."""
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    rfile = str(tmp_path / "regions.txt")
+    with open(rfile, "w") as f:
+        for i in range(150):
+            f.write(f"{1 + 13 * i}:{1 + 13 * i + 40 + (i % 7) * 30}\n")
+    outs = []
+    for typ, extra in (("6", []), ("4", ["-s", "1"])):
+        texts = []
+        for flag in ([], ["--resident-lists"]):
+            bfile = str(tmp_path / f"b{typ}{len(flag)}.txt")
+            out = subprocess.run([CLI, "query", "-p", d, "-t", typ, "-r", "@" + rfile, "-m", "1", "-o", str(tmp_path / "o.txt"),
+                                  "--batch-out", bfile] + extra + flag, capture_output=True, text=True)
+            assert out.returncode == 0, out.stdout + out.stderr
+            counts = [m for m in _msgs(out.stdout) if m.startswith("Number of variants")]
+            assert len(counts) == 150
+            texts.append((counts, open(bfile).read()))
+        assert texts[0] == texts[1]
+        assert texts[0][1].count("#region ") == 150
+        outs.append(texts[0][1])
+    assert outs[0] != outs[1]

@@ -11,6 +11,8 @@
 //   --batch-out FILE    rows of ALL regions ("#region <i> <x>:<y>" before each), since the
 //                       reference's -o file only ever holds the last region (query.h:774-781)
 //   --device N          GPU ordinal (default 0)
+//   --resident-lists    expand every carrier list of the index once, when it is opened, into an arena that stays in
+//                       HBM (vs_index_set_option "resident_lists"): batches then copy rows only across PCIe
 //   --ngpus N           shard the sorted region list over GPUs device .. device + N - 1 (query types 4, 5, 6): one handle
 //                       and one host thread per GPU, contiguous shards (the reference's serial loop, commands.cc:145,
 //                       carries no state between regions), results printed in region order
@@ -101,6 +103,7 @@ struct Args {
   bool have_hops = false;
   bool have_type = false, have_mode = false, verbose = false;
   int device = 0, ngpus = 1;
+  bool resident_lists = false;
 };
 
 int usage() {
@@ -108,7 +111,7 @@ int usage() {
                "        variantstore construct -r <reference-file> -v <vcf-file> -p <output-prefix>\n"
                "        variantstore query -p <output-prefix> -t <query-type> -r <region> -m <mode> [-o <outfile>]\n"
                "                     [-s <sample-name>] [-a <alt-seq>] [-b <ref-seq>] [-v]\n"
-               "                     [--batch-out <file>] [--device <n>] [--ngpus <n>]\n"
+               "                     [--batch-out <file>] [--device <n>] [--ngpus <n>] [--resident-lists]\n"
                "        variantstore draw -p <output-prefix> -r <region> -h <hops> [-s <sample-name>]\n"
                "        variantstore help\n\n"
                "OPTIONS\n"
@@ -353,6 +356,8 @@ int query_main(const Args& a) {
       sh.rc = vs_index_open(a.prefix.c_str(), a.device + g, &sh.idx);
       if (sh.rc != VS_OK) { sh.err = vs_last_error(); return; }
     }
+    if (a.resident_lists && vs_index_set_option(sh.idx, "resident_lists", 1) != VS_OK)
+      log_line("warning", std::string("--resident-lists: ") + vs_last_error() + " (lists are expanded per batch)");
     const vs_region* rg = batch.data() + sh.lo;
     const uint64_t n = sh.hi - sh.lo;
     if (a.type == 6) sh.rc = vs_query_var_in_ref(sh.idx, rg, n, &sh.res);
@@ -467,6 +472,7 @@ int main(int argc, char** argv) {
       else if (f == "--batch-out") a.batch_out = need(i);
       else if (f == "--device") a.device = atoi(need(i).c_str());
       else if (f == "--ngpus") a.ngpus = std::max(1, atoi(need(i).c_str()));
+      else if (f == "--resident-lists") a.resident_lists = true;
       else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
     }
   }
