@@ -113,6 +113,32 @@ for c in range(n_cohorts):
             rm.close()
         vs.set_option("t4_coop", 1)
         vs.set_option("t4_skip", 1)
+        # resident carrier lists: the whole unsorted batch, its sorted form and the type-4 batch again, rows only
+        stage("resident lists")
+        vs.set_option("resident_lists", 1)
+        for form, idxs in (("unsorted", list(range(len(regions)))), ("sorted", order)):
+            rr = vs.get_var_in_ref([regions[i] for i in idxs])
+            if rr.layout()[2] != 0:
+                bad += 1
+                print(f"resident batch with an arena of its own, cohort {seed} ({form})")
+            for k, i in enumerate(idxs):
+                if orc.get_var_in_ref(*regions[i])[0] < 0:
+                    continue
+                checked += 1
+                if rr.region_text(k) != res.region_text(i):
+                    bad += 1
+                    print(f"MISMATCH t6 resident lists ({form}) cohort {seed} region {regions[i]}")
+            rr.close()
+        rm = vs.get_sample_var_in_ref(regions[:100], per)
+        for q, (n, early, text) in enumerate(want4):
+            if n < 0:
+                continue
+            checked += 1
+            if rm.region_text(q) != text:
+                bad += 1
+                print(f"MISMATCH t4 resident lists cohort {seed} sample {per[q]} region {regions[q]}")
+        rm.close()
+        vs.set_option("resident_lists", 0)
         sample = names[int(rng.integers(0, len(names)))]
         r4 = vs.get_sample_var_in_ref(regions[:60], sample)
         for q, (x, y) in enumerate(regions[:60]):
