@@ -214,20 +214,30 @@ def git_blob_hash(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-KERNEL_SOURCE = os.path.join(ROOT, "variantstore_amd", "csrc", "hip", "kernels.hip.h")
+KERNEL_DIR = os.path.join(ROOT, "variantstore_amd", "csrc", "hip")
+
+
+def kernels_hash():
+    """One hash for the device code of this tree: sha1 over (file name, git blob hash) of every csrc/hip/*.hip.h in name
+    order (kernels.hip.h is the umbrella over the k_*.hip.h parts)."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(f for f in os.listdir(KERNEL_DIR) if f.endswith(".hip.h")):
+        h.update(name.encode() + b" " + git_blob_hash(os.path.join(KERNEL_DIR, name)).encode() + b"\n")
+    return h.hexdigest()
 
 
 def committed_traffic(workload, nreg_matches):
     """HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/traffic_<workload>.json, written by
     tools/make_traffic_json.py).  Counters cannot be read from inside a run, so the figure is only attached when the
-    kernels it was measured on are the kernels of THIS tree (git blob hash of kernels.hip.h) and the batch is the
+    kernels it was measured on are the kernels of THIS tree (kernels_hash: the blob hashes of csrc/hip/*.hip.h) and the batch is the
     workload's own; otherwise every traffic field is null."""
     tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     if not (os.path.exists(tpath) and nreg_matches):
         return None
     with open(tpath) as tf:
         t = json.load(tf)
-    if t.get("kernels_blob") != git_blob_hash(KERNEL_SOURCE):
+    if t.get("kernels_blob") != kernels_hash():
         return None
     return t
 
@@ -717,7 +727,7 @@ def main():
                          "emit_kernel_ms": emit_ms / args.steps,
                          "pipeline_ms": tot_ms / args.steps,
                          "other_kernels": ({k: v for k, v in tj["kernels"].items() if k != fill_kernel} if tj else None),
-                         "kernels_blob": git_blob_hash(KERNEL_SOURCE)},
+                         "kernels_blob": kernels_hash()},
             "p50_latency_us": p50,
             "p50_latency_paced_1ms_us": p50_paced,
             "type4": t4,

@@ -43,7 +43,7 @@ for name, ctr in raw.items():
         if k.startswith("SQ_") or k.startswith("GRBM_"):
             e[k] = v
     kernels[short] = e
-out = {"workload": workload, "tag": tag, "kernels_blob": blob or bench.git_blob_hash(bench.KERNEL_SOURCE),
+out = {"workload": workload, "tag": tag, "kernels_blob": blob or bench.kernels_hash(),
        "note": "separate rocprofv3 --pmc passes of `python3 bench.py --steps 6 --warmup 2 --extras t4` (tools/profile_round.sh); "
                "means over all launches of a kernel; traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; an "
                "upper bound where reads are narrow)",

@@ -16,7 +16,7 @@ ARGS0="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras none 
 ARGS="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras t4 --workload $wl"
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
-python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.git_blob_hash(bench.KERNEL_SOURCE))" > $O/kernels_blob.txt
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernels_hash())" > $O/kernels_blob.txt
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py $ARGS0 > $R/gpurun_out/prof_$tag.log 2>&1
 echo "kernel-trace rc=$?"
 python3 $R/tools/prof_summary.py $R/gpurun_out/prof_$tag/p_results.db "rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS0" > $O/${tag}_kernel_stats.txt

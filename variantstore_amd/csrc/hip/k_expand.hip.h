@@ -1,0 +1,584 @@
+// k_expand.hip.h -- carrier expansion (expand_task, k_fill_carriers, k_fill_sites) -- the dominant kernel.
+// Part of kernels.hip.h (the kernel index with reference file:line is there).
+#pragma once
+#include "k_rows.hip.h"
+
+namespace vsamd {
+
+// ---------------------------------------------------------------------------
+// Carrier expansion (expand_task: k_fill_carriers, k_query_small, k_query_server).  One wave owns CH consecutive
+// variant slots (64; 4 in latency launches); every lane first gathers the parameters of "its" slot, then the wave
+// works through the task:
+//
+//  cohorts of at most 4032 samples with class rows (WIDE=false, use_bv) -- the main case:
+//    listed  (<= list_max = 640 carriers): LANE PER GROUP of 8 carriers from the class's decoded 16-bit id list; the
+//            groups of all listed variants of the task form one list, a lane finds its variant by bisection over the
+//            64 offsets (LDS) and produces one finished 16-byte arena group.
+//    denser  WAVE PER VARIANT, two rounds of half a row: every lane peels its own ceil(wpc / 2) bits into a 16-bit id
+//            list in LDS at its prefix-sum position; the complete groups leave in 128-byte-aligned blocks, one
+//            16-byte store per lane (8 carriers of 16 bits: id | gt << 13), genotypes merged from the raw nibble
+//            stream on the way out.  Rows are requested two variants ahead, nibbles one.
+//  explicit-id cohorts: LANE PER GROUP for every variant (ids from the carrier pool).
+//  cohorts above 4032 samples with class rows (WIDE=true): the list path with 32-bit entries and 32-bit carrier words
+//    (id | gt << 29); denser variants keep the round-1 row code -- medium ones lane per row word with an LDS id
+//    list, dense ones bit per lane (exec = row word, v_mbcnt rank) through a 512-entry LDS ring; rows wider than one
+//    wave take the out-of-line generic path.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kFillChunk = 64;          // variant slots per wave task, throughput launches
+constexpr uint32_t kFillChunkDense = 16;     // throughput launches over few, carrier-heavy variants (type-4 batches)
+constexpr uint32_t kFillChunkSmall = 4;      // latency launches (a handful of regions): more waves per region
+constexpr uint32_t kRingWords = 512;             // per wave: output ring of the dense path (flushed 1 KiB at a time)
+// per-wave LDS = gt_words (one genotype byte per carrier, sized from the cohort) + kRingWords, passed at launch
+constexpr uint32_t kMidMax = 640;            // <= this many carriers: ids are staged in LDS and copied out coalesced
+// Slice path (cohorts of at most 4032 samples): per-wave LDS = row staging + raw genotype nibbles + 16-bit id list
+constexpr uint32_t kRowWords = 132;          // 65 x uint64 (the row and one zero word behind it), padded
+// layout: [raw nibbles][id list; the row staging aliases its start -- the slices are cut before the list is written]
+__host__ __device__ inline uint32_t slice_gt_words(uint32_t n_samples) {
+  uint32_t b = 16 + (n_samples + 32) / 2;   // the bias, then the nibbles of one variant starting anywhere in a 16-byte group
+  b = (b + 15) & ~15u;
+  if (b < 1024 + 16) b = 1024 + 16;         // the first 1 KiB is written by all lanes
+  return b / 4;
+}
+constexpr uint32_t kListWindow = 64;         // the id list is laid out by arena position modulo 64 entries (128 bytes)
+__host__ __device__ inline uint32_t slice_ids_words(uint32_t n_samples) {
+  // one round of the slice path: half a row (64 lanes x ceil(wpc / 2) bits) behind the alignment window, plus the
+  // incomplete group carried over from the first round
+  const uint32_t wpc = (n_samples + 63) / 64, round_bits = 64 * ((wpc + 1) / 2);
+  const uint32_t w = ((kListWindow + round_bits + 16 + 7) & ~7u) / 2;
+  return w < kRowWords ? kRowWords : w;
+}
+__host__ __device__ inline uint32_t slice_lds_words(uint32_t n_samples) {
+  const uint32_t w = slice_gt_words(n_samples) + slice_ids_words(n_samples);
+  return w < 384 ? 384 : w;                  // the sparse phase keeps 6 x 64 words at the start of the region
+}
+constexpr uint32_t kMidIdsAt = 256;          // medium path: ids live at word 256.. (genotype bytes need < 1 KiB there)
+
+// one 16-byte arena group, written once and not read again by this kernel
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_group_nt(uint4* p, uint4 v) {
+  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+}
+
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint32_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src_lane) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// 32 packed genotype nibbles (one uint4) -> 32 bytes in LDS, nibble order preserved.
+__device__ __forceinline__ void stage_unpacked(uint8_t* dst, uint4 n) {
+  uint32_t in[4] = {n.x, n.y, n.z, n.w};
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t a = in[i] & 0x07070707u, b = (in[i] >> 4) & 0x07070707u;
+    o[2 * i] = __builtin_amdgcn_perm(b, a, 0x05010400u);      // a0 b0 a1 b1
+    o[2 * i + 1] = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+  }
+  reinterpret_cast<uint4*>(dst)[0] = uint4{o[0], o[1], o[2], o[3]};
+  reinterpret_cast<uint4*>(dst)[1] = uint4{o[4], o[5], o[6], o[7]};
+}
+
+// Generic (slow) expansion of one variant by a whole wave: any row width, genotype
+// nibbles read straight from global memory.  Kept out of line so that its loads do
+// not force memory waits into the tuned loops of k_fill_carriers.
+__device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, const uint8_t* gtp, uint64_t gt0,
+                                            uint32_t* out, uint32_t lane) {
+  uint32_t base = 0;
+  for (uint32_t wb = 0; wb < wpc; wb += 64) {
+    uint64_t mine = (wb + lane < wpc) ? row[wb + lane] : 0ULL;
+    if (wb == 0 && lane == 0) mine &= ~1ULL;
+    uint64_t nz = __ballot(mine != 0);
+    while (nz) {
+      const int w = __builtin_ctzll(nz);
+      nz &= nz - 1;
+      const uint64_t word = wave_bcast64(mine, w);
+      if ((word >> lane) & 1) {
+        const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, 0));
+        const uint64_t c = gt0 + k;
+        const uint32_t nib = (gtp[c >> 1] >> ((c & 1) * 4)) & 7u;
+        out[k] = ((wb + w) * 64 + lane) | (nib << 29);
+      }
+      base += __popcll(word);
+    }
+  }
+}
+
+// Expansion of one task: the lanes hold (cnt, cls, gt0, cb) of up to 64 variant slots (cnt == 0: nothing to do for the
+// lane) and the wave writes their carrier words into the arena.  Shared by k_fill_carriers (slots whose headers an
+// earlier kernel wrote) and k_query_small (single-launch latency path, slots read straight from the site table).
+// `lds_wave` is the wave's LDS block (slice_lds_words / gt_words + kRingWords words).
+// `ablate_arg` is a profiling aid of tuning builds (TUNE: bit0 skip listed/sparse, bit1 skip medium, bit2 skip dense).
+// WIDE=false is instantiated for cohorts of at most 4032 samples (<= 63 row words): every variant then
+// fits the staged paths and the out-of-line generic call -- whose calling convention costs registers and
+// one wave of occupancy -- is compiled out.
+// EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
+// per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
+// PART: 0 = the whole task; 1 = only its listed variants, 2 = only its denser ones (the two halves of a launch pair that
+// runs side by side on two streams: the list half is loads and stores, the row half LDS and vector work).
+template <bool WIDE, bool EARLY_NIB, bool TUNE = false, int PART = 0>
+__device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
+                                            uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words) {
+  const uint32_t ablate = (TUNE ? ablate_arg : 0u) | (PART == 2 ? 1u : 0u);   // production instantiations carry no ablation tests
+  const uint32_t wpc = im.wpc;
+  const uint64_t* __restrict__ class_rows = im.class_rows;
+  const uint8_t* __restrict__ gtp = im.gt_nibbles;
+  // carrier word in the arena: 16 bits when every sample id fits 13 bits (the non-WIDE instantiation), else 32
+  using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
+  CT* __restrict__ carriers = reinterpret_cast<CT*>(arena);
+  uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi));
+  const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
+  if (explicit_ids) {
+    // Explicit-id cohorts (somatic-like: a handful of carriers per variant, ids in the carrier pool): LANE PER GROUP of
+    // 8 carriers for every variant whatever its size, exactly like the list path below -- the groups of the task form
+    // one list, a lane finds its variant by bisection, loads the 8 ids (32 bytes of car_sid) and their 32 genotype bits
+    // and stores one finished group (16 bytes of 16-bit words, or 32 bytes of 32-bit words above 4032 samples).  The
+    // last group of a variant reads up to 7 ids of the next one: they land in the padding the range owns.
+    uint32_t* s_off = lds_wave;
+    const uint32_t c = cnt && !(ablate & 1) ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t L = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_off[L + step] <= e) L += step;
+        const uint32_t k8 = (e - s_off[L]) * kCarAlign;
+        const uint64_t g = s_gt0[L] + k8;                        // carrier record of the group's first entry
+        uint4 ia, ib;
+        __builtin_memcpy(&ia, im.car_sid + g, 16);
+        __builtin_memcpy(&ib, im.car_sid + g + 4, 16);
+        uint2 nw;
+        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
+        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        const uint32_t id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        CT* dst = carriers + (s_cb[L] + k8);
+        if constexpr (WIDE) {
+          uint4 lo, hi;
+          lo.x = id[0] | (((n >> 0) & 7u) << 29); lo.y = id[1] | (((n >> 4) & 7u) << 29);
+          lo.z = id[2] | (((n >> 8) & 7u) << 29); lo.w = id[3] | (((n >> 12) & 7u) << 29);
+          hi.x = id[4] | (((n >> 16) & 7u) << 29); hi.y = id[5] | (((n >> 20) & 7u) << 29);
+          hi.z = id[6] | (((n >> 24) & 7u) << 29); hi.w = id[7] | (((n >> 28) & 7u) << 29);
+          store_group_nt(reinterpret_cast<uint4*>(dst), lo);
+          store_group_nt(reinterpret_cast<uint4*>(dst) + 1, hi);
+        } else {
+          // (every word of car_sid is a valid sample id < 4032 or zero padding: 13 bits, nothing to mask)
+          uint4 v;
+          const uint32_t p0 = id[0] | (id[1] << 16), p1 = id[2] | (id[3] << 16), p2 = id[4] | (id[5] << 16), p3 = id[6] | (id[7] << 16);
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, p0));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, p1));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, p2));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, p3));
+          store_group_nt(reinterpret_cast<uint4*>(dst), v);
+        }
+      }
+    }
+    return;
+  }
+
+  const bool lists = true;   // (explicit-id cohorts returned above) every class of at most list_max carriers has a decoded id list
+  const uint32_t list_max = im.list_max;
+
+  // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
+  //                  list phase runs in the shadow of that memory latency ----------------
+  uint64_t dmask = PART == 1 ? 0ULL : __ballot(cnt > list_max && !explicit_ids);
+  uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
+  uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
+  if (dmask) {
+    const int t0 = __builtin_ctzll(dmask);
+    const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
+    const uint64_t gt0_0 = wave_bcast64(gt0, t0);
+    if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
+    if (!lists || EARLY_NIB) {
+      const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
+      const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+    }
+    const uint64_t d1 = dmask & (dmask - 1);
+    if (d1) {
+      const uint32_t cls_1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d1));
+      if (lane < wpc) word_n1 = class_rows[(uint64_t)cls_1 * wpc + lane];
+    }
+  }
+
+  // Cohorts of at most 4032 samples with class rows: every variant of at most list_max carriers is expanded from its
+  // class's decoded 16-bit id list, LANE PER GROUP of 8 carriers (= one 16-byte arena group; every variant's arena
+  // range and every list start on a group boundary and own their padding).  The groups of all such variants of the
+  // task form one list: a DPP prefix sum over the group counts gives every variant its slice, a lane takes entry e,
+  // finds its variant by bisection over the 64 offsets (LDS), loads the 8 ids (one 16-byte load) and the 32
+  // genotype bits that go with them (one 8-byte load of the nibble pool), and stores one finished 16-byte group.
+  // No bit row is read, nothing is staged, no lane idles: a rare variant is one group, a 640-carrier one is 80.
+  // Two entries per lane and pass, so that four independent loads are in flight per lane.
+  if constexpr (WIDE) {
+    // the same with 32-bit list entries and 32-bit carrier words (id | gt << 29): a group is two loads and two stores
+    uint32_t* s_off = lds_wave;
+    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint32_t* s_idb = s_off + 64;
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list_ids);
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t L = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_off[L + step] <= e) L += step;
+        const uint32_t k = e - s_off[L];
+        const uint64_t g = s_gt0[L] + (uint64_t)k * kCarAlign;
+        const uint4 ia = list_groups[2 * ((uint64_t)s_idb[L] + k)], ib = list_groups[2 * ((uint64_t)s_idb[L] + k) + 1];
+        uint2 nw;
+        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
+        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        uint4 lo, hi;
+        lo.x = ia.x | (((n >> 0) & 7u) << 29); lo.y = ia.y | (((n >> 4) & 7u) << 29);
+        lo.z = ia.z | (((n >> 8) & 7u) << 29); lo.w = ia.w | (((n >> 12) & 7u) << 29);
+        hi.x = ib.x | (((n >> 16) & 7u) << 29); hi.y = ib.y | (((n >> 20) & 7u) << 29);
+        hi.z = ib.z | (((n >> 24) & 7u) << 29); hi.w = ib.w | (((n >> 28) & 7u) << 29);
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(arena) + (s_cb[L] + (uint64_t)k * kCarAlign));
+        store_group_nt(dst, lo);
+        store_group_nt(dst + 1, hi);
+      }
+    }
+  } else {
+    uint32_t* s_off = lds_wave;   // aliases the genotype staging area
+    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total) {
+      uint32_t* s_idb = s_off + 64;
+      uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
+      uint64_t* s_cb = reinterpret_cast<uint64_t*>(s_off + 256);
+      s_off[lane] = incl - c;
+      s_idb[lane] = cls;      // listed variants: group index of the class's list (DevImage::v_src)
+      s_gt0[lane] = gt0;
+      s_cb[lane] = cb;
+      const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list16);
+      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      uint4* __restrict__ arena_groups = reinterpret_cast<uint4*>(arena);
+      for (uint32_t e0 = lane; e0 < total; e0 += 128) {
+        const uint32_t e1 = e0 + 64;
+        const bool two = e1 < total;
+        uint32_t L0 = 0, L1 = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) {
+          if (s_off[L0 + step] <= e0) L0 += step;
+          if (s_off[L1 + step] <= e1) L1 += step;
+        }
+        const uint32_t k0 = e0 - s_off[L0], k1 = e1 - s_off[L1];   // group within its variant
+        const uint64_t g0 = s_gt0[L0] + (uint64_t)k0 * kCarAlign;   // its first genotype nibble: 32 bits from bit 4g
+        const uint64_t g1 = s_gt0[L1] + (uint64_t)k1 * kCarAlign;
+        const uint4 iw0 = list_groups[(uint64_t)s_idb[L0] + k0];
+        uint2 nw0, nw1 = {0, 0};
+        __builtin_memcpy(&nw0, gt32 + (g0 >> 3), 8);
+        uint4 iw1 = {0, 0, 0, 0};
+        if (two) {
+          iw1 = list_groups[(uint64_t)s_idb[L1] + k1];
+          __builtin_memcpy(&nw1, gt32 + (g1 >> 3), 8);
+        }
+        const uint64_t dst0 = (s_cb[L0] >> 3) + k0, dst1 = (s_cb[L1] >> 3) + k1;   // arena ranges start on group boundaries
+        {
+          const uint32_t n = __builtin_amdgcn_alignbit(nw0.y, nw0.x, ((uint32_t)g0 & 7u) * 4);
+          uint4 v;
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw0.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
+          store_group_nt(&arena_groups[dst0], v);
+        }
+        if (two) {
+          const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
+          uint4 v;
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw1.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
+          store_group_nt(&arena_groups[dst1], v);
+        }
+      }
+    }
+  }
+
+  if (dmask == 0) return;
+  if (lists && !EARLY_NIB) {   // the first dense variant's nibbles (8 registers) are requested after the list phase: its peak register
+                 // demand decides how many waves a SIMD holds
+    const int t0 = __builtin_ctzll(dmask);
+    const uint32_t cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
+    const uint64_t gt0_0 = wave_bcast64(gt0, t0);
+    const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;
+    const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;
+    if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+    if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+  }
+  // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
+  // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
+  // cohorts, the output ring.
+  uint8_t* gt_lds = reinterpret_cast<uint8_t*>(lds_wave);
+  uint32_t* ids_lds = lds_wave + kMidIdsAt;
+  uint32_t* ring = lds_wave + gt_words;
+  while (dmask) {
+    const int t = __builtin_ctzll(dmask);
+    dmask &= dmask - 1;
+    const uint32_t cnt_t = __builtin_amdgcn_readlane(cnt, t);
+    const uint32_t cls_t = __builtin_amdgcn_readlane(cls, t);
+    const uint64_t gt0_t = wave_bcast64(gt0, t);
+    const uint64_t cb_t = wave_bcast64(cb, t);
+    const uint64_t b0 = (gt0_t >> 1) & ~15ULL;
+    const uint32_t nshift = (uint32_t)(gt0_t - 2 * b0);               // staged index of carrier 0
+    const bool staged = (uint64_t)nshift + cnt_t <= gt_words * 4;     // fits the staging block
+    // stage this variant's genotypes (fetched during the previous variant)
+    if (WIDE) {   // one byte per carrier
+      stage_unpacked(gt_lds + lane * 32, nq0);
+      if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
+    } else {      // raw nibbles, behind the row staging area
+      uint8_t* nib_st = gt_lds + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
+      *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
+      if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
+    }
+    // request the next variant's nibbles and the row of the one after it before expanding this one (rows are the
+    // random 320-byte reads of this kernel: two of them stay in flight per wave)
+    if (WIDE) { nq0 = uint4{0, 0, 0, 0}; nq1 = uint4{0, 0, 0, 0}; }   // (the slice path never reads nibbles it did not load)
+    word_n2 = 0;
+    if (dmask) {
+      const int tn = __builtin_ctzll(dmask);
+      const uint64_t gt0_n = wave_bcast64(gt0, tn);
+      const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
+      const uint64_t bn = (gt0_n >> 1) & ~15ULL;
+      const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
+      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
+      const uint64_t d2 = dmask & (dmask - 1);
+      if (d2) {
+        const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
+        if (lane < wpc) word_n2 = class_rows[(uint64_t)cls_2 * wpc + lane];
+      }
+    }
+    const uint64_t word_this = word_cur;
+    word_cur = word_n1; word_n1 = word_n2;   // the queue advances here: every `continue` below leaves it consistent
+    if constexpr (WIDE) {
+      if (!staged || wpc > 64) {
+        // rows wider than one wave or more than 4096 staged genotypes: generic path
+        expand_generic(class_rows + (uint64_t)cls_t * wpc, wpc, gtp, gt0_t, carriers + cb_t, lane);
+        continue;
+      }
+    }
+    uint64_t mine = word_this;
+    if (lane == 0) mine &= ~1ULL;  // bit 0 is "ref"
+    if ((ablate & 2) && cnt_t <= kMidMax) continue;
+    if ((ablate & 4) && cnt_t > kMidMax) continue;
+    if constexpr (!WIDE) {
+      // ---- slice path: the row is expanded in TWO rounds of 64 x sb bits (sb = ceil(wpc / 2) <= 32): in a round
+      //      every lane owns sb consecutive bits, peels them into a 16-bit id list in LDS at its prefix-sum position,
+      //      then the complete 16-byte groups of the list leave in 128-byte-aligned blocks, one store per lane,
+      //      genotypes merged from the raw nibble stream on the way out; the (< 8) ids of the last, incomplete group
+      //      move to the front of the list and the second round continues behind them.  The list therefore holds
+      //      half a row at most -- the per-wave LDS block is what limits this kernel's occupancy. ----
+      const uint8_t* nib_lds = gt_lds;
+      uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
+      uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
+      rowq[lane] = mine;
+      if (lane == 0) rowq[64] = 0;
+      const uint32_t sb = (wpc + 1) >> 1;                                       // bits per lane and round
+      const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1u;
+      const uint32_t* rowd = reinterpret_cast<const uint32_t*>(rowq);
+      const uint32_t bp0 = sb * lane, bp1 = bp0 + 64 * sb;                      // first bit of the lane's slice per round
+      uint32_t bits0 = __builtin_amdgcn_alignbit(rowd[(bp0 >> 5) + 1], rowd[bp0 >> 5], bp0 & 31u) & smask;
+      uint32_t bits1 = __builtin_amdgcn_alignbit(rowd[(bp1 >> 5) + 1], rowd[bp1 >> 5], bp1 & 31u) & smask;
+      const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
+      uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+      // nibble index = list index + D; the staging is biased by 32 nibbles
+      uint32_t D = nshift + 32 - a1k;
+      uint32_t pos = a1k;                                 // list index of the round's first carrier
+      uint32_t done8 = a1k;                               // groups below this list index have been written
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        uint32_t bits = round ? bits1 : bits0;
+        const uint32_t idb = round ? bp1 : bp0;
+        const uint32_t pc = __popc(bits);
+        uint32_t incl = wave_inclusive_scan(pc);
+        asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
+        const uint32_t end = pos + __builtin_amdgcn_readlane(incl, 63);
+        uint32_t j = pos + incl - pc;                     // list index of this lane's first carrier of the round
+        while (bits) {
+          ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
+          bits &= bits - 1;
+        }
+        // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32 consecutive
+        // bits of the stream.  Round 0 writes complete groups only, round 1 everything (the range owns its padding).
+        const uint32_t flush = round ? ((end + 7u) & ~7u) : (end & ~7u);
+        for (uint32_t q8 = done8 + lane * 8; q8 < flush; q8 += 512) {
+          const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
+          const uint32_t n0 = q8 + D;
+          const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
+          const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
+          uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
+                     // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
+          store_group_nt(reinterpret_cast<uint4*>(g1k + q8), v);   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+        }
+        if (round == 0) {
+          // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
+          const uint32_t o = flush & ~(kListWindow - 1);
+          if (o) {
+            if (lane == 0) *reinterpret_cast<uint4*>(ids16 + (flush - o)) = *reinterpret_cast<const uint4*>(ids16 + flush);
+            g1k += o;
+            D += o;
+          }
+          pos = end - o;
+          done8 = flush - o;
+        }
+      }
+    } else if (cnt_t <= kMidMax) {
+      const uint32_t a0 = (uint32_t)(cb_t & 63);        // offset of the variant inside its first aligned block
+      uint32_t* gbase = carriers + (cb_t - a0);         // that block's base: gbase[a0 + k] is carrier k
+      const uint32_t endpos = a0 + cnt_t;
+      // ---- medium density: lane per row word, ids staged in LDS, coalesced copy-out ----
+      const uint32_t pc = __popcll(mine);
+      uint32_t incl = pc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+      }
+      uint32_t k = incl - pc;
+      const uint32_t idbase = lane * 64;
+      while (mine) {
+        const uint32_t bit = __builtin_ctzll(mine);
+        mine &= mine - 1;
+        ids_lds[k] = idbase + bit;
+        ++k;
+      }
+      // copy-out in 256-byte-aligned blocks of the arena
+      for (uint32_t pos = lane; pos < endpos; pos += 64)
+        if (pos >= a0) gbase[pos] = ids_lds[pos - a0] | ((uint32_t)gt_lds[nshift + pos - a0] << 29);
+    } else {
+      // ---- dense: bit per lane, two row words per step.  The lanes whose bit is set (exec mask =
+      //      the word itself) rank themselves with v_mbcnt and drop id|gt into a 512-entry LDS ring
+      //      indexed by arena position; the ring leaves 1 KiB at a time as one 16-byte store per lane
+      //      on a 1 KiB-aligned arena block (aligned full stores run at twice the rate of partial ones,
+      //      tools/microbench/write_bw.hip) ----
+      const uint32_t a1k = (uint32_t)(cb_t & 255);        // offset of the variant inside its 1 KiB block
+      uint32_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
+      const uint32_t end1k = a1k + cnt_t;
+      const uint32_t gtoff = nshift - a1k;                // staged genotype index = arena position + gtoff
+      uint32_t bpos = a1k;                                // arena position of the step's first carrier
+      uint32_t nfl = 0;                                   // 256-entry blocks already written
+      for (uint32_t w = 0; w < wpc; w += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint64_t word = (w + i < wpc) ? wave_bcast64(mine, w + i) : 0ULL;
+          if (__builtin_amdgcn_inverse_ballot_w64(word)) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, bpos));
+            ring[pos & 511u] = ((w + i) * 64 + lane) | ((uint32_t)gt_lds[pos + gtoff] << 29);
+          }
+          bpos += __popcll(word);
+        }
+        while (nfl < (bpos >> 8)) {                        // a complete 256-entry block is ready
+          const uint32_t p4 = nfl * 256 + lane * 4;
+          const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+          if (p4 >= a1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+          else if (p4 + 4 > a1k) {                         // the variant starts inside this lane's quad
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (p4 + j >= a1k) g1k[p4 + j] = e[j];
+          }
+          ++nfl;
+        }
+      }
+      for (uint32_t p4 = nfl * 256 + lane * 4; p4 < end1k; p4 += 256) {   // tail (at most 2 passes)
+        const uint4 v = *reinterpret_cast<const uint4*>(&ring[p4 & 511u]);
+        if (p4 >= a1k && p4 + 4 <= end1k) *reinterpret_cast<uint4*>(g1k + p4) = v;
+        else {
+          const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (p4 + j >= a1k && p4 + j < end1k) g1k[p4 + j] = e[j];
+        }
+      }
+    }
+  }
+}
+
+template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
+__global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t A = r.A;
+  const uint64_t nchunks = (A + CH - 1) / CH;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  // one task per wave (the launch covers every task): with no loop around it the compiler has no lane-dependent
+  // invariants to keep alive, and the hardware's block scheduler balances the tenfold spread of task costs
+  if (wave < nchunks) {
+    const uint64_t a = wave * CH + lane;
+    uint32_t cnt = 0, cls = 0;
+    uint64_t gt0 = 0, cb = 0;
+    if (a < A && lane < CH) {   // read once
+      const uint4 y = reinterpret_cast<const uint4*>(r.rows + a)[1];   // {alt_len, count | dropped, car_begin}
+      cnt = y.y & ~kRowDropped;
+      cb = ((uint64_t)y.w << 32) | y.z;
+      cls = __builtin_nontemporal_load(&r.r_class[a]);
+      gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
+      if (cls == kNone) cnt = 0;   // the row shares another row's list (k_t4_claim): nothing to expand here
+    }
+    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+  }
+}
+
+// The same expansion over the UNIQUE sites of a batch whose carrier lists are shared: the slot parameters come straight
+// from the site table (sequential reads, each site once), the arena offset from k_unique_sites.
+template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
+__global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, const uint32_t* u_site, uint64_t U, uint32_t ablate, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nchunks = (U + CH - 1) / CH;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  if (wave < nchunks) {
+    const uint64_t u = wave * CH + lane;
+    uint32_t cnt = 0, cls = 0;
+    uint64_t gt0 = 0, cb = 0;
+    if (u < U && lane < CH) {
+      const uint32_t g = __builtin_nontemporal_load(&u_site[u]);
+      const uint4 y = reinterpret_cast<const uint4*>(r.rows + u)[1];   // {alt_len, count | dropped, car_begin}: the shared rows are table rows [0, U)
+      cnt = y.y & ~kRowDropped;
+      cb = ((uint64_t)y.w << 32) | y.z;
+      cls = im.s_class[g];
+      gt0 = im.s_gt0[g];
+    }
+    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+  }
+}
+
+}  // namespace vsamd

@@ -1,0 +1,367 @@
+// k_sample_coords.hip.h -- sample-coordinate queries (types 2, 3, 5), result totals, batched find.
+// Part of kernels.hip.h (the kernel index with reference file:line is there).
+#pragma once
+#include "k_walk.hip.h"
+
+namespace vsamd {
+
+// ---------------------------------------------------------------------------
+// Sample-coordinate queries (types 2, 3 and 5).  They need the per-carrier `index` of
+// sample_info (variantgraphvertex.proto:12) -- DevImage::car_index.
+// ---------------------------------------------------------------------------
+
+// get_sample_from_vertex_if_exists(v, sample, out) -> out.index (variant_graph.h:1296-1339).  The s_info
+// entry of a sample is found by its position in the class's ascending id list (bit-vector mode) or by a
+// linear search (explicit ids); the carrier pool holds the non-ref entries in s_info order.
+// (ridx, cls: the vertex's ref index and class, which the caller already holds in a walk record)
+__device__ __forceinline__ bool sample_entry_rec(const DevImage& im, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t sid, uint32_t& index) {
+  if (sid == 0) {
+    if (!ridx) return false;
+    index = ridx;
+    return true;
+  }
+  if (im.use_bv) {
+    const uint64_t* row = im.class_rows + (uint64_t)cls * im.wpc;
+    const uint32_t w = sid >> 6, bit = sid & 63;
+    const uint64_t word = row[w];
+    if (!((word >> bit) & 1)) return false;
+    uint32_t rank = __popcll(word & ((1ULL << bit) - 1));
+    for (uint32_t i = 0; i < w; ++i) rank += __popcll(row[i]);
+    rank -= (uint32_t)(row[0] & 1);  // the ref entry is not part of the pool
+    index = im.car_index[im.v_car_begin[v] + rank];
+    return true;
+  }
+  const uint64_t b = im.v_car_begin[v];
+  for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
+    if (im.car_sid[b + i] == sid) { index = im.car_index[b + i]; return true; }
+  return false;
+}
+__device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {
+  return sample_entry_rec(im, v, im.v_ridx[v], im.use_bv ? im.v_class[v] : 0u, sid, index);
+}
+
+// get_neighbor_vertex (variant_graph.h:1402-1451): first out-neighbour holding the sample, else the ref
+// neighbour with the smallest ref index; 0 = none (the path iterator is done)
+__device__ __forceinline__ uint32_t next_on_path(const DevImage& im, uint32_t cur, uint32_t sid) {
+  uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+  const uint4 wc = im.w_vertex[2 * (uint64_t)cur];   // {row_begin, degree, ..}
+  for (uint32_t e = wc.x; e < wc.x + wc.y; ++e) {
+    const WalkEdge ed = walk_edge(im, e);
+    if (sid != 0 && record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) return ed.nbr;
+    if (ed.ridx && min_idx > ed.ridx) { nxt = ed.nbr; min_idx = ed.ridx; }
+  }
+  return nxt;
+}
+
+// get_prev_vertex_with_sample (query.h:57-113) including the sample-coordinate output
+__device__ __forceinline__ uint32_t prev_vertex_with_sample(const DevImage& im, uint64_t pos, uint32_t sid, uint64_t& ref_pos,
+                                                            uint64_t& sample_pos) {
+  uint64_t rank;  // find(pos, rank), index.h:135-148 (rank is left unset for pos == 0 there: defined as 0)
+  if (pos >= im.ref_length) rank = im.R - 1;
+  else { const uint32_t k = rank1(im, pos); rank = k == 0 ? 0 : k - 1; }
+  uint32_t v_find = 0;
+  while (true) {
+    const uint32_t v = im.rp_vid[im.rank_to_slot[rank == 0 ? 0 : rank - 1]];  // Index::previous
+    if (rank <= 1) { ref_pos = 1; v_find = v; sample_pos = im.v_ridx[v]; break; }
+    bool found = false;
+    const uint4 wv = im.w_vertex[2 * (uint64_t)v];   // {row_begin, degree, ..}
+    for (uint32_t e = wv.x; e < wv.x + wv.y; ++e) {
+      const WalkEdge ed = walk_edge(im, e);
+      if (ed.ridx) ref_pos = ed.ridx;
+      uint32_t idx;
+      if (sample_entry_rec(im, ed.nbr, ed.ridx, ed.cls, sid, idx)) { v_find = ed.nbr; found = true; sample_pos = idx; }
+      rank = rank ? rank - 1 : 0;  // unsigned wrap in the reference: clamped
+    }
+    if (found) break;
+  }
+  return v_find;
+}
+
+// the backward search of query.h:213-218 / :507-512; false when the reference would loop forever
+__device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_t x, uint32_t sid, uint32_t& closest_v,
+                                                     uint64_t& ref_pos, uint64_t& sample_pos) {
+  closest_v = prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  uint64_t guard = 0;
+  while (sample_pos >= x && closest_v > 0) {
+    const uint64_t pos = ref_pos, before_ref = ref_pos, before_sample = sample_pos;
+    const uint32_t before_v = closest_v;
+    closest_v = prev_vertex_with_sample(im, pos, sid, ref_pos, sample_pos);
+    if (ref_pos == before_ref && sample_pos == before_sample && closest_v == before_v) return false;
+    if (++guard > 4 * im.V + 64) return false;
+  }
+  return true;
+}
+
+// Capacities of the single recording walk of type 5: branch sites of the reference range [x, y) widened by the
+// region's own length (the sample's coordinates are shifted against the reference's by its net indel length).
+__global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t margin = (y > x ? y - x : 0) + 256;
+  const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
+  const uint32_t s0 = slot_of_find(im, lo), s1 = slot_of_find(im, hi);
+  r.q_nvar[q] = (s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0) + 8;
+}
+
+// Query type 5.  One thread per region; MODE as in k_sample_walk (0 count, 1 emit, 2 record once).
+template <int MODE>
+__global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+  constexpr bool EMIT = MODE == 1;
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint32_t sid = sid_per_region[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  uint8_t fl = 0;
+  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
+  uint64_t ref_pos = 0, sample_pos = 0;
+  uint32_t closest_v = 0;
+  if (!rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
+  else {
+    closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
+    if (im.v_ridx[closest_v]) {
+      const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
+      ref_pos = im.v_ridx[closest_v];
+      sample_pos -= seq_len;
+    }
+    uint32_t cur = closest_v;
+    uint32_t cur_ref_v = kNone;
+    bool done = false;
+    const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
+    const uint64_t cb = EMIT ? r.car_base[q] : 0;
+    while (!done) {
+      if (sample_pos >= y) break;
+      const WalkVertex wc = walk_vertex(im, cur);   // one record per vertex, one per neighbour; ONE pass over the edges
+      const uint32_t l = wc.len;
+      uint64_t next_ref_pos = ref_pos + l;
+      uint32_t next_ref_v = kNone;                  // the last ref neighbour (its sequence becomes cur_ref)
+      uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;      // get_neighbor_vertex (next_on_path) in the same pass
+      bool nxt_by_sample = false;
+      for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+        const WalkEdge ed = walk_edge(im, e);
+        if (ed.ridx) { next_ref_pos = ed.ridx; next_ref_v = ed.nbr; }
+        if (!nxt_by_sample) {
+          if (sid != 0 && record_has_sample(im, ed.nbr, ed.ridx, ed.cls, sid)) { nxt = ed.nbr; nxt_by_sample = true; }
+          else if (ed.ridx && min_idx > ed.ridx) { nxt = ed.nbr; min_idx = ed.ridx; }
+        }
+      }
+      uint32_t sidx = 0;
+      if (sample_pos > x && sample_entry_rec(im, cur, wc.ridx, wc.cls, sid, sidx)) {
+        uint64_t pos;
+        uint32_t ro, rl, ao, al;
+        if (ref_pos == next_ref_pos) {        // insertion
+          pos = ref_pos; ro = 0; rl = 0; ao = wc.off; al = l;
+        } else if (wc.ridx) {                 // deletion: ref = sequence of find(ref_pos - 1)
+          const uint32_t fv = im.rp_vid[slot_of_find(im, ref_pos - 1)];
+          pos = sidx; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
+        } else {                              // substitution: ref = sequence of the previous step's last ref neighbour
+          pos = sidx; ro = 0; rl = 0; ao = wc.off; al = l;
+          if (cur_ref_v != kNone) { const WalkVertex wr = walk_vertex(im, cur_ref_v); ro = wr.off; rl = wr.len; }
+        }
+        const uint32_t c = wc.ncar;
+        if (EMIT) {
+          const uint64_t a = a0 + nvar;
+          row_store(r.rows, a, (uint32_t)pos, ro, rl, ao, al, c, false, cb + ncar);
+          r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+        }
+        if (MODE == 2) {
+          const uint64_t s0 = ws.cap_begin[q];
+          if (nvar < ws.cap_begin[q + 1] - s0) {
+            const uint64_t s = s0 + nvar;
+            ws.pos[s] = pos; ws.cur[s] = cur; ws.ro[s] = ro; ws.rl[s] = rl; ws.ao[s] = ao; ws.al[s] = al;
+          } else *ws.overflow = 1;
+        }
+        nvar++; ncar += pad_car(c); ncar_kept += c;
+        // the insertion branch clears cur_ref before it is copied into the variant (query.h:564-566)
+      }
+      cur_ref_v = next_ref_v;
+      ref_pos = next_ref_pos;
+      sample_pos += l;
+      if (nxt == 0) done = true;
+      cur = nxt;
+    }
+  }
+  if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
+  else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
+}
+
+// Query types 2 and 3: the sequence of a sample over [x, y).  The walk produces the list of (pool offset,
+// length) pieces; seg_begin / byte_begin are the exclusive scans of the counting pass.
+struct DevSeqResult {
+  uint64_t Q;
+  const uint64_t* regions;
+  const uint32_t* sids;
+  uint8_t* q_flags;
+  uint64_t *q_nseg, *q_nbytes;      // [Q] counting pass
+  uint64_t *seg_begin, *byte_begin; // [Q+1]
+  uint32_t *seg_src, *seg_len;      // [nseg]
+  uint64_t* seg_dst;                // [nseg] byte offset in chars (relative to the region's first byte when `relative`)
+  uint8_t* chars;
+  uint64_t* overflow;               // single-walk mode: set when a region outgrew its piece capacity
+  uint32_t relative, pad_;          // single-walk mode: pieces sit at seg_begin[q] .. + q_nseg[q], seg_begin = capacities' scan
+};
+
+struct SeqSink {
+  uint64_t nseg, nbytes;
+};
+
+// PASS 0 counts, PASS 1 writes the pieces at their scanned places (second walk), PASS 2 is the single walk: pieces go
+// to the region's slice of a capacity-sized list with byte offsets relative to the region's first byte.
+template <int PASS>
+__device__ __forceinline__ void seq_append(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint32_t off,
+                                           uint64_t len, uint64_t cap) {
+  if (len == 0) return;
+  if (PASS == 1 || (PASS == 2 && s.nseg < cap)) {
+    r.seg_src[seg0 + s.nseg] = off; r.seg_len[seg0 + s.nseg] = (uint32_t)len; r.seg_dst[seg0 + s.nseg] = byte0 + s.nbytes;
+  } else if (PASS == 2) *r.overflow = 1;
+  s.nseg++; s.nbytes += len;
+}
+
+// the window logic of query.h:160-177 / :236-247 on (off, l) instead of a std::string.
+// Returns 0 continue, 1 stop, 2 std::out_of_range (uncaught in the reference).
+template <int PASS>
+__device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint64_t cap, bool& record,
+                                          uint32_t off, uint64_t l, uint64_t cur, uint64_t next, uint64_t x, uint64_t y) {
+  if (record && next < y) {
+    seq_append<PASS>(r, s, seg0, byte0, off, l, cap);
+  } else if (record && next >= y) {
+    const uint64_t n = y - cur;  // substr(0, n): n may have wrapped, it is clipped to the string
+    seq_append<PASS>(r, s, seg0, byte0, off, n < l ? n : l, cap);
+    return 1;
+  } else if (next >= x && next < y) {
+    record = true;
+    const uint64_t p = x - cur;
+    if (p > l) return 2;
+    seq_append<PASS>(r, s, seg0, byte0, off + (uint32_t)p, l - p, cap);
+  } else if (next >= x && next >= y) {
+    const uint64_t p = x - cur;
+    if (p > l) return 2;
+    const uint64_t n = y - x;
+    seq_append<PASS>(r, s, seg0, byte0, off + (uint32_t)p, n < l - p ? n : l - p, cap);
+    return 1;
+  }
+  return 0;
+}
+
+template <int MODE, int PASS>
+__global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  if (PASS == 1 && r.q_flags[q]) return;
+  const uint32_t sid = r.sids[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t seg0 = PASS ? r.seg_begin[q] : 0, byte0 = PASS == 1 ? r.byte_begin[q] : 0;
+  const uint64_t cap = PASS == 2 ? r.seg_begin[q + 1] - seg0 : 0;
+  SeqSink s{0, 0};
+  uint8_t fl = 0;
+  uint64_t ref_pos = 0, sample_pos = 0;
+  uint32_t cur = 0;
+  bool ok = true;
+  if (MODE == 2) cur = prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  else ok = rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
+  if (!ok) fl = kRegionEndless;
+  else {
+    bool record = false, done = false;
+    while (!done) {
+      const WalkVertex wc = walk_vertex(im, cur);
+      const uint32_t off = wc.off;
+      const uint64_t l = wc.len;
+      int st;
+      if (MODE == 2) {
+        uint64_t next_ref_pos = ref_pos + l;
+        for (uint32_t e = wc.row_begin; e < wc.row_begin + wc.deg; ++e) {
+          const uint32_t nr = walk_edge(im, e).ridx;
+          if (nr) { next_ref_pos = nr; break; }  // the FIRST ref neighbour here (query.h:150-153)
+        }
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, l, ref_pos, next_ref_pos, x, y);
+        ref_pos = next_ref_pos;
+      } else {
+        const uint64_t next_sample_pos = sample_pos + l;
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, l, sample_pos, next_sample_pos, x, y);
+        sample_pos = next_sample_pos;
+      }
+      if (st == 2) { fl = kRegionInvalid; break; }
+      if (st == 1) break;
+      const uint32_t nxt = next_on_path(im, cur, sid);
+      if (nxt == 0) done = true;
+      cur = nxt;
+    }
+  }
+  if (PASS != 1) {
+    r.q_flags[q] = fl;
+    r.q_nseg[q] = fl ? 0 : s.nseg;
+    r.q_nbytes[q] = fl ? 0 : s.nbytes;
+  }
+}
+
+// Piece capacity of a region for the single walk: twice the ref-path slots plus branch sites of the (for sample
+// coordinates: generously widened) reference range, plus slack.  Too small a guess only costs the fallback.
+__global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, uint32_t sample_coordinates) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t margin = sample_coordinates ? (y > x ? y - x : 0) + 256 : 0;
+  const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
+  const uint32_t s0 = slot_of_find(im, lo), s1 = slot_of_find(im, hi);
+  const uint64_t slots = s1 >= s0 ? (uint64_t)(s1 - s0) + 1 : 1;
+  const uint64_t sites = s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0;
+  r.q_nseg[q] = 2 * (slots + sites) + 8;
+}
+
+// Decode the pieces into characters: one wave per region, 64 piece descriptors at a time.
+__global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= r.Q) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t s0 = r.seg_begin[q], s1 = r.relative ? s0 + r.q_nseg[q] : r.seg_begin[q + 1];
+  const uint64_t dst0 = r.relative ? r.byte_begin[q] : 0;
+  for (uint64_t base = s0; base < s1; base += 64) {
+    const uint64_t mine = base + lane;
+    uint32_t src = 0, len = 0;
+    uint64_t dst = 0;
+    if (mine < s1) { src = r.seg_src[mine]; len = r.seg_len[mine]; dst = dst0 + r.seg_dst[mine]; }
+    const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t ksrc = __builtin_amdgcn_readlane(src, k), klen = __builtin_amdgcn_readlane(len, k);
+      const uint64_t kdst = wave_bcast64(dst, k);
+      for (uint32_t i = lane; i < klen; i += 64) {
+        const uint32_t c = im.seq_codes[ksrc + i] & 7;
+        r.chars[kdst + i] = (uint8_t)(0x0505054E47544341ULL >> (8 * c));  // "ACTGN" then char 5 (map_int, util.cc:32-41)
+      }
+    }
+  }
+}
+
+// Totals of a result without copying it: {variants reported, their carriers, their REF + ALT bases}, one wave per region
+__global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned long long* out) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const bool live = q < r.Q;
+  const uint64_t n = live ? r.q_nvar[q] : 0, a0 = live ? r.var_begin[q] : 0;
+  unsigned long long nv = 0, nc = 0, nb = 0;
+  for (uint64_t j = threadIdx.x & 63; j < n; j += 64) {
+    const VariantRow v = row_load(r.rows, a0 + j);
+    if (row_dropped(v)) continue;
+    nv += 1; nc += row_count(v); nb += (uint64_t)v.ref_len + v.alt_len;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); nc += __shfl_down(nc, d, 64); nb += __shfl_down(nb, d, 64); }
+  __shared__ unsigned long long part[3][4];   // one atomic triple per block, not per wave: the three words are one hot line
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = nv; part[1][threadIdx.x >> 6] = nc; part[2][threadIdx.x >> 6] = nb; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (t) atomicAdd(out + threadIdx.x, t);
+  }
+}
+
+// Index::find batched (index.h:119-133)
+__global__ void __launch_bounds__(256) k_find(DevImage im, const uint64_t* pos, uint64_t n, uint32_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t p = pos[i];
+  if (p < 1) { out[i] = kNone; return; }
+  uint64_t rf = (p >= im.ref_length) ? im.R - 1 : (uint64_t)rank1(im, p);
+  if (p < im.ref_length) rf = rf == 0 ? 0 : rf - 1;
+  out[i] = im.rp_vid[im.rank_to_slot[rf]];
+}
+
+}  // namespace vsamd
