@@ -726,7 +726,10 @@ def main():
                                                     "the arena holds 2 -- a time-per-algorithmic-unit figure, not pin traffic"},
                          "emit_kernel_ms": emit_ms / args.steps,
                          "pipeline_ms": tot_ms / args.steps,
-                         "other_kernels": ({k: v for k, v in tj["kernels"].items() if k != fill_kernel} if tj else None),
+                         # (the committed counters of the other kernels, abridged: profiles/traffic_<workload>.json has every counter)
+                         "other_kernels": ({k: {f: v[f] for f in ("grid", "avg_us_under_pmc", "traffic_bytes_per_launch", "tcc_hit_rate", "SQ_WAVES",
+                                                                    "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if f in v}
+                                            for k, v in tj["kernels"].items() if k != fill_kernel} if tj else None),
                          "kernels_blob": kernels_hash()},
             "p50_latency_us": p50,
             "p50_latency_paced_1ms_us": p50_paced,

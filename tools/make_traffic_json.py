@@ -23,11 +23,12 @@ blob = None
 if dirs and dirs[0].startswith("--blob="):
     blob, dirs = dirs[0].split("=", 1)[1].strip(), dirs[1:]
 raw = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs))
-SHORT = {"k_fill_carriers": "k_fill_carriers", "k_fill_sites": "k_fill_sites", "k_share_rows": "k_share_rows", "k_sample_walk_coop": "k_sample_walk_coop", "k_emit_headers": "k_emit_headers", "k_sample_walk": "k_sample_walk",
-         "k_emit_from_walk": "k_emit_from_walk", "k_region_bounds": "k_region_bounds"}
+NAMES = ["k_fill_carriers", "k_fill_sites", "k_share_rows", "k_share_apply", "k_emit_headers", "k_region_bounds", "k_sample_walk_coop", "k_sample_walk_sc",
+         "k_sample_walk", "k_emit_from_walk", "k_t4_claim", "k_point_bounds", "k_has_var_filter", "k_sample_seq", "k_copy_segments"]
+NAMES.sort(key=len, reverse=True)   # (longest first: k_sample_walk is a prefix of two others)
 kernels = {}
 for name, ctr in raw.items():
-    short = next((v for k, v in SHORT.items() if k in name), None)
+    short = next((k for k in NAMES if k in name), None)
     if short is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
         continue
     grid = int(name.rsplit("[grid ", 1)[1].rstrip("]"))
@@ -44,7 +45,7 @@ for name, ctr in raw.items():
             e[k] = v
     kernels[short] = e
 out = {"workload": workload, "tag": tag, "kernels_blob": blob or bench.kernels_hash(),
-       "note": "separate rocprofv3 --pmc passes of `python3 bench.py --steps 6 --warmup 2 --extras t4` (tools/profile_round.sh); "
+       "note": "separate rocprofv3 --pmc passes of `python3 bench.py --steps 6 --warmup 2 --extras t4,points,sc` (tools/profile_round.sh); "
                "means over all launches of a kernel; traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; an "
                "upper bound where reads are narrow)",
        "kernels": kernels}

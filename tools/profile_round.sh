@@ -1,7 +1,7 @@
 #!/bin/bash
 # One profiling round of the bench command on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag> [workload]
-#  1. rocprofv3 --kernel-trace --stats (headline batch alone; then with the type-4 leg)
+#  1. rocprofv3 --kernel-trace --stats (headline batch alone; then with the type-4, point-query and sample-coordinate legs)
 #                                                 -> <tag>_kernel_stats.txt, <tag>_kernel_stats_t4.txt
 #  2. rocprofv3 --pmc, one pass per counter group -> <tag>_pmc.json, traffic_<workload>.json
 #  3. the bench line of the same tree             -> <tag>_bench.json
@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
 cd /tmp
 ARGS0="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras none --workload $wl"
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras t4 --workload $wl"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --latency-samples 0 --extras t4,points,sc --workload $wl"
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernels_hash())" > $O/kernels_blob.txt
