@@ -826,12 +826,22 @@ def test_shared_carrier_lists_of_a_sorted_batch(seed, kw, tmp_path):
     va, vb = shared.view(True), private.view(True)
     for k in va:
         assert np.array_equal(va[k], vb[k]), k
-    # not sorted: private lists, same answers
+    # not sorted: the engine sorts the regions by first site on the device (k_sort_*), shares rows and lists all the
+    # same and hands every region's outcome back in the caller's order -- twice (the second batch is sorted first, on the
+    # handle's hint), then a sorted batch again
     perm = rng.permutation(len(regions))
-    mixed = vs.get_var_in_ref([regions[i] for i in perm])
-    assert not mixed.layout()[4]
-    for j in (0, 1, 17, 250, 499):
-        assert mixed.region_text(j) == shared.region_text(int(perm[j]))
+    vs.set_option("share_lists", 2)   # (share whether or not it pays: the crowded cohort's table is nearly as long as its rows)
+    for _round in range(2):
+        mixed = vs.get_var_in_ref([regions[i] for i in perm])
+        assert mixed.layout()[4] and mixed.layout()[:4] == shared.layout()[:4]
+        assert mixed.digest() != 0 and mixed.totals() == shared.totals()
+        for j in range(len(regions)):
+            assert mixed.region_text(j) == shared.region_text(int(perm[j])), j
+        vm = mixed.view(True)
+        assert np.array_equal(vm["var_count"], va["var_count"][perm]) and np.array_equal(vm["region_flags"], va["region_flags"][perm])
+        mixed.close()
+    again = vs.get_var_in_ref(regions)
+    assert again.layout() == shared.layout() and again.digest() == shared.digest()
     # duplicates of one region, regions without sites in between, one region swallowing many others
     odd = sorted([(1, ref_len)] * 3 + regions[::7] + [(ref_len + 5, ref_len + 9), (0, 5)] + [(40, 41)] * 70)
     a = vs.get_var_in_ref(odd)

@@ -86,6 +86,8 @@ struct vs_index {
   uint64_t t4_gen = 0;
   hipStream_t fill_stream = nullptr;        // second stream of the split expansion (fill_split)
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
+  bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
+  uint32_t sort_probe_in = 0;
   int share_hint = -1;                      // did sharing pay on the last shared batch (-1: not known yet)
   uint32_t share_probe_in = 0;              // private batches until sharing is tried again
   uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
@@ -784,6 +786,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   uint32_t* sh_new_start = nullptr;
   uint64_t *sh_u_begin = nullptr, *sh_arena_new = nullptr;
+  DevResult d_user{};        // the caller's per-region arrays while an unsorted batch works on sorted copies
+  uint32_t* perm = nullptr;  // sorted position -> region of the caller's batch (NULL: the batch is worked in the order given)
   uint64_t n_unique = 0;
   if (share) {
     const uint64_t ntiles = (n + kShareTile - 1) / kShareTile;
@@ -798,16 +802,18 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_u_begin, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_arena_new, &scratch.bufs));
     VS_TRY(ralloc(r, n, &d.q_car_len));
-    HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
-    hipLaunchKernelGGL(k_share_tile_max, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, d, tile_max);
-    hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
-    hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
-    const uint64_t share_seq = ++idx->share_seq;
-    hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status,
-                       share_seq);
-    HIP_TRY(hipGetLastError());
-    {  // the sizes arrive in mapped host memory: spin on the sequence word (the runtime's completion wait costs tens of
-       // microseconds more); a kernel that never posts -- a fault -- is caught by the synchronisation after the deadline
+    // the two scans over the regions as they stand in `d`; the sizes arrive in mapped host memory
+    auto share_scans = [&]() -> int {
+      HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
+      hipLaunchKernelGGL(k_share_tile_max, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, d, tile_max);
+      hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
+      hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
+      const uint64_t share_seq = ++idx->share_seq;
+      hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status,
+                         share_seq);
+      HIP_TRY(hipGetLastError());
+      // spin on the sequence word (the runtime's completion wait costs tens of microseconds more); a kernel that never
+      // posts -- a fault -- is caught by the synchronisation after the deadline
       volatile uint64_t* seqw = pin_totals + 5;
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
       bool posted = false;
@@ -817,12 +823,55 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       }
       if (!posted) HIP_TRY(hipStreamSynchronize(idx->stream));
       std::atomic_thread_fence(std::memory_order_acquire);
-    }
+      return VS_OK;
+    };
+    // A batch that is not sorted by first site: counting sort of the regions over the site index (k_sort_*), the batch
+    // then works on sorted copies of its per-region arrays (`d` points at them from here on, `d_user` keeps the
+    // caller's) and k_permute_out hands the outcome back at the end.
+    auto sort_batch = [&]() -> int {
+      const uint64_t G = idx->d.G;
+      uint32_t* count = nullptr;
+      unsigned long long* cursor = nullptr;
+      VS_TRY(dev_alloc(idx, (G + 2) * 4, (void**)&count, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, (G + 2) * 8, (void**)&cursor, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 4, (void**)&perm, &scratch.bufs));
+      HIP_TRY(hipMemsetAsync(count, 0, (G + 1) * 4, idx->stream));
+      hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, count);
+      VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)count, G + 1, (uint64_t*)cursor, &scratch.bufs));
+      hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, cursor, perm);
+      d_user = d;
+      uint64_t* sregions = nullptr;
+      VS_TRY(dev_alloc(idx, 2 * n * 8, (void**)&sregions, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n, (void**)&d.q_flags, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 4, (void**)&d.q_g0, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_nvar, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_ncar, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.var_begin, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.car_base, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_car_len, &scratch.bufs));
+      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.var_count, &scratch.bufs));
+      hipLaunchKernelGGL(k_permute_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d_user, d, (const uint32_t*)perm, sregions);
+      d.regions = sregions;
+      HIP_TRY(hipGetLastError());
+      return VS_OK;
+    };
+    // (a handle whose last shared batch needed sorting sorts first; it looks at the order as given again every 32nd batch)
+    if (idx->sort_hint && idx->sort_probe_in > 0) { --idx->sort_probe_in; VS_TRY(sort_batch()); }
+    VS_TRY(share_scans());
+    if (((volatile uint64_t*)pin_totals)[3] && !perm) {   // not sorted by first site
+      VS_TRY(sort_batch());
+      VS_TRY(share_scans());
+      idx->sort_hint = true; idx->sort_probe_in = 32;
+    } else if (!perm) idx->sort_hint = false;
     totals[0] = ((volatile uint64_t*)pin_totals)[0];
     totals[1] = ((volatile uint64_t*)pin_totals)[1];
     n_unique = ((volatile uint64_t*)pin_totals)[2];
     r->n_rows_reported = ((volatile uint64_t*)pin_totals)[4];
-    if (((volatile uint64_t*)pin_totals)[3]) { share = false; d.q_car_len = nullptr; }   // not sorted by first site: private rows and lists
+    if (((volatile uint64_t*)pin_totals)[3]) {   // (cannot happen after the sort; kept as the safe way out)
+      share = false;
+      if (perm) { d = d_user; perm = nullptr; }
+      d.q_car_len = nullptr;
+    }
     else {   // (only now: it overwrites the per-region counts the private path scans)
       idx->share_hint = totals[0] * 5 <= r->n_rows_reported * 4 ? 1 : 0;
       if (!idx->share_hint) idx->share_probe_in = 32;
@@ -937,6 +986,13 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   const uint64_t n_fill = resident ? 0 : (share ? n_unique : d.A);   // lists to expand: shared rows resp. all rows; none with resident lists
   VS_TRY(fill_lists(idx, d, share, u_site, n_fill));
+  if (perm) {   // every region's outcome back to its place in the caller's order (rows and lists are shared: nothing else moves)
+    const DevResult ds = d;
+    d.regions = d_user.regions; d.q_flags = d_user.q_flags; d.q_g0 = d_user.q_g0; d.q_nvar = d_user.q_nvar; d.q_ncar = d_user.q_ncar;
+    d.var_begin = d_user.var_begin; d.car_base = d_user.car_base; d.q_car_len = d_user.q_car_len; d.var_count = d_user.var_count;
+    hipLaunchKernelGGL(k_permute_out, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, ds, d, (const uint32_t*)perm);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   scratch.release();

@@ -221,6 +221,38 @@ __global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResu
     ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new; ex.p += slow[i] ? nvs[i] : 0;
   }
 }
+// A batch that is NOT sorted by first site is sorted here -- a counting sort over the site index: histogram of the first
+// sites (regions without sites count as site 0), exclusive scan over the G + 1 buckets (the engine's scan kernels),
+// scatter through per-bucket cursors -- and then runs through the same kernels on sorted copies of its per-region
+// arrays; k_permute_out hands every region's outcome back to its place in the caller's order.  Rows and lists are
+// shared either way: the table is in site order whatever the order of the regions.
+__device__ __forceinline__ uint32_t sort_key(const DevResult& r, uint64_t q) { return r.q_nvar[q] ? r.q_g0[q] : 0u; }
+__global__ void __launch_bounds__(256) k_sort_hist(DevResult r, uint32_t* count) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < r.Q) atomicAdd(&count[sort_key(r, q)], 1u);
+}
+__global__ void __launch_bounds__(256) k_sort_scatter(DevResult r, unsigned long long* cursor, uint32_t* perm) {   // cursor: the scanned histogram, consumed
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < r.Q) perm[atomicAdd(&cursor[sort_key(r, q)], 1ull)] = (uint32_t)q;
+}
+// s.X[i] = r.X[perm[i]] for what the bounds kernel left per region
+__global__ void __launch_bounds__(256) k_permute_in(DevResult r, DevResult s, const uint32_t* perm, uint64_t* s_regions) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r.Q) return;
+  const uint32_t q = perm[i];
+  s_regions[2 * i] = r.regions[2 * q]; s_regions[2 * i + 1] = r.regions[2 * q + 1];
+  s.q_flags[i] = r.q_flags[q]; s.q_g0[i] = r.q_g0[q]; s.q_nvar[i] = r.q_nvar[q]; s.q_ncar[i] = r.q_ncar[q];
+}
+// r.X[perm[i]] = s.X[i] for what the batch computed per region (s: the sorted working copy, r: the caller's order)
+__global__ void __launch_bounds__(256) k_permute_out(DevResult s, DevResult r, const uint32_t* perm) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == r.Q) { r.var_begin[i] = s.var_begin[i]; r.car_base[i] = s.car_base[i]; }
+  if (i >= r.Q) return;
+  const uint32_t q = perm[i];
+  r.q_flags[q] = s.q_flags[i]; r.q_ncar[q] = s.q_ncar[i]; r.var_begin[q] = s.var_begin[i]; r.car_base[q] = s.car_base[i];
+  r.q_car_len[q] = s.q_car_len[i]; r.var_count[q] = s.var_count[i];
+}
+
 // Resident carrier lists: a region's lists ARE the arena range of its sites -- car_base = s_carpre[g0] whatever the
 // scans made of it (and the start of the region's new part likewise, for k_share_rows).
 __global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r, const uint32_t* new_start, uint64_t* arena_new, uint64_t arena_entries) {
