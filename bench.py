@@ -465,6 +465,26 @@ def main():
         finally:
             vs.set_option("share_lists", 1)
 
+    # ---- the same regions in RANDOM order (a caller that does not sort as the reference's driver does): the engine sorts
+    #      them by first site on the device and shares rows and lists all the same ----
+    unsorted = None
+    if lists_shared:
+        shuffled = torch.from_numpy(np.ascontiguousarray(regions[np.random.default_rng(5).permutation(nreg)]).astype(np.int64)).to(regions_dev.device)
+        for _i in range(2):
+            vs.get_var_in_ref_device(shuffled.data_ptr(), nreg).close()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _i in range(5):
+            ru = vs.get_var_in_ref_device(shuffled.data_ptr(), nreg)
+            ru.close()
+        torch.cuda.synchronize()
+        dtu = (time.perf_counter() - a) / 5
+        ru = vs.get_var_in_ref_device(shuffled.data_ptr(), nreg)
+        unsorted = {"queries_per_s": nreg / dtu, "ms_per_step": dtu * 1e3, "shares_rows_and_lists": bool(ru.layout()[4]), "same_totals": tuple(ru.totals()) == (nq, nvar, ncar, nbases)}
+        ru.close()
+        for _i in range(2):   # (back to the sorted batch: the handle stops sorting first)
+            vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg).close()
+
     # ---- p50 single-region latency (submit -> result resident), outside the timed region: a client that asks again
     #      the moment it has its answer (the resident server's case), and one paced at 1 query per millisecond ----
     lat = []
@@ -736,7 +756,7 @@ def main():
             "type4": t4,
             "point_queries": t17,
             "sample_coordinate_queries": tsc,
-            "delivery": delivery, "resident_lists": resident,
+            "delivery": delivery, "resident_lists": resident, "unsorted_batch": unsorted,
             "result_digest": f"{digest:016x}",
         }
         if world == 1 and not args.no_cpu_baseline:
