@@ -195,3 +195,44 @@ def test_shared_and_private_carrier_lists_agree_at_full_size(big):
     for q, text in texts.items():
         assert private.region_text(q) == text
     private.close()
+
+
+def test_unsorted_and_resident_forms_agree_at_full_size(big):
+    """The bench batch four ways: sorted (shared rows and lists), in random order (sorted on the device, outcomes handed
+    back in the caller's order), and both again over resident carrier lists (nothing expanded): same totals, the same
+    per-region counts and texts, digests equal where the region order is."""
+    vs, regions = big
+    vs.set_option("share_lists", 2)
+    try:
+        base = vs.get_var_in_ref(regions)
+        tb, db = base.totals(), base.digest()
+        vb = base.view(False)
+        perm = np.random.default_rng(77).permutation(len(regions))
+        shuffled = np.ascontiguousarray(regions[perm])
+        mixed = vs.get_var_in_ref(shuffled)
+        assert mixed.layout()[4] and mixed.layout()[:4] == base.layout()[:4] and mixed.totals() == tb
+        vm = mixed.view(False)
+        assert np.array_equal(vm["var_count"], vb["var_count"][perm]) and np.array_equal(vm["region_flags"], vb["region_flags"][perm])
+        probes = (0, 3, 12_345, 77_777, 99_999)
+        for j in probes:
+            assert mixed.region_text(j) == base.region_text(int(perm[j]))
+        dm = mixed.digest()
+        vs.set_option("resident_lists", 1)
+        res_sorted, res_mixed = vs.get_var_in_ref(regions), vs.get_var_in_ref(shuffled)
+        assert res_sorted.layout()[2] == 0 and res_mixed.layout()[2] == 0
+        assert (res_sorted.totals(), res_sorted.digest()) == (tb, db) and (res_mixed.totals(), res_mixed.digest()) == (tb, dm)
+        for j in probes:
+            assert res_sorted.region_text(j) == base.region_text(j) and res_mixed.region_text(j) == base.region_text(int(perm[j]))
+        # type 4 over resident lists: 16 samples round-robin, against the per-batch expansion
+        per = np.array([1 + (i * 157) % 2503 for i in range(16)], dtype=np.uint32)[np.arange(len(regions)) % 16]
+        r4 = vs.get_sample_var_in_ref(regions, per)
+        vs.set_option("resident_lists", 0)
+        e4 = vs.get_sample_var_in_ref(regions, per)
+        assert r4.layout()[2] == 0 and e4.layout()[2] > 0 and (r4.totals(), r4.digest()) == (e4.totals(), e4.digest())
+        for j in probes:
+            assert r4.region_text(j) == e4.region_text(j)
+        for x in (base, mixed, res_sorted, res_mixed, r4, e4):
+            x.close()
+    finally:
+        vs.set_option("resident_lists", 0)
+        vs.set_option("share_lists", 1)
