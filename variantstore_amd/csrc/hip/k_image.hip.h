@@ -64,7 +64,7 @@ struct DevImage {
   const uint64_t* t4_hold;
   uint64_t t4_hold_stride;  // 64-bit words per sample row: ceil(V / 64) + 1
   // The walk blob (device_image.hpp): 32-byte records in the order a walk along the reference needs them -- per ref-path
-  // slot one header record {first edge record, degree, ref index, 0, length, class, #carriers, vertex id}, the edge
+  // slot one header record {first edge record, degree, ref index, sequence offset, length, class, #carriers, vertex id}, the edge
   // records of the slot's node {neighbour, its ref index, its class, ITS first edge record, its degree, its ref-path
   // slot + 1, its length, its #carriers}, then the edge records of its off-path neighbours (and theirs): one or two
   // cache lines hold everything an episode of the type-4 walk reads.
@@ -72,6 +72,7 @@ struct DevImage {
   const uint32_t* blob_of_slot;   // [P + 1] header record of each ref-path slot
   const uint32_t* blob_row;       // [V] first edge record of each vertex
   const uint2* rk_back;     // [R] per rank r: {first ref-path slot of r (= Index::previous(r + 1)), out-degree of that node}
+  const uint64_t* seq_breaks;   // bit per ref-path slot: the sequence queries must step through it literally (device_image.hpp)
   // RESIDENT carrier lists (option "resident_lists"; engine.hip: build_resident_lists): every list a query can report,
   // expanded once into an arena that stays with the index -- the lists of the sites in site-table order at s_carpre[g]
   // (so a region's lists are ONE arena range, [s_carpre[g0], s_carpre[g1])), then the lists of the vertices only the

@@ -92,6 +92,56 @@ __device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_
   return true;
 }
 
+// ---- the same searches with the per-sample event and hold rows of query type 4 (DevImage::t4_events / t4_hold) ----
+// get_prev_vertex_with_sample as in walk_start_search<true>: ranks whose node has no out-neighbour holding the sample
+// (clear event bit) are counted down without being read; the candidate's edge records come from the walk blob, "holds
+// the sample" from the hold row, and only the vertex that is found pays the look-up of its sample-coordinate index.
+__device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& im, uint64_t pos, uint32_t sid, BitRow& ev, BitRow& hold,
+                                                               uint64_t& ref_pos, uint64_t& sample_pos) {
+  uint64_t rank;
+  if (pos >= im.ref_length) rank = im.R - 1;
+  else { const uint32_t k = rank1(im, pos); rank = k == 0 ? 0 : k - 1; }
+  const uint64_t ref_pos_in = ref_pos;
+  bool jumped = false;
+  while (true) {
+    const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
+    if (rank <= 1) { const uint32_t v = im.rp_vid[back.x]; ref_pos = 1; sample_pos = im.v_ridx[v]; return v; }
+    if (!ev.bit(back.x)) { rank = rank > back.y ? rank - back.y : 0; jumped = true; continue; }
+    bool found = false, had_ref = false;
+    uint32_t fv = 0, fr = 0, fc = 0;
+    const uint32_t rb0 = im.blob_of_slot[back.x] + 1;   // the edge records follow the slot's header
+    for (uint32_t e = rb0; e < rb0 + back.y; ++e) {
+      const uint4 a = im.wblob[2 * (uint64_t)e];
+      if (a.y) { ref_pos = a.y; had_ref = true; }
+      if (hold.bit(a.x)) { fv = a.x; fr = a.y; fc = a.z; found = true; }
+    }
+    rank = rank > back.y ? rank - back.y : 0;
+    if (found) {
+      if (!had_ref && jumped) {   // ref_pos would be an earlier (skipped) node's: the literal search knows
+        ref_pos = ref_pos_in;
+        return prev_vertex_with_sample(im, pos, sid, ref_pos, sample_pos);
+      }
+      uint32_t idx = 0;
+      (void)sample_entry_rec(im, fv, fr, im.use_bv ? fc : 0u, sid, idx);
+      sample_pos = idx;
+      return fv;
+    }
+  }
+}
+__device__ __forceinline__ bool rewind_to_sample_pos_ev(const DevImage& im, uint64_t x, uint32_t sid, BitRow& ev, BitRow& hold, uint32_t& closest_v,
+                                                        uint64_t& ref_pos, uint64_t& sample_pos) {
+  closest_v = prev_vertex_with_sample_ev(im, x, sid, ev, hold, ref_pos, sample_pos);
+  uint64_t guard = 0;
+  while (sample_pos >= x && closest_v > 0) {
+    const uint64_t pos = ref_pos, before_ref = ref_pos, before_sample = sample_pos;
+    const uint32_t before_v = closest_v;
+    closest_v = prev_vertex_with_sample_ev(im, pos, sid, ev, hold, ref_pos, sample_pos);
+    if (ref_pos == before_ref && sample_pos == before_sample && closest_v == before_v) return false;
+    if (++guard > 4 * im.V + 64) return false;
+  }
+  return true;
+}
+
 // Capacities of the single recording walk of type 5: branch sites of the reference range [x, y) widened by the
 // region's own length (the sample's coordinates are shifted against the reference's by its net indel length).
 __global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) {
@@ -116,7 +166,12 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t closest_v = 0;
-  if (!rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
+  bool rewound;
+  if (im.t4_events && sid != 0) {   // the backward searches with the per-sample event and hold rows
+    BitRow ev{im.t4_events + (uint64_t)sid * im.t4_stride, kNone, 0}, hold{im.t4_hold + (uint64_t)sid * im.t4_hold_stride, kNone, 0};
+    rewound = rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos);
+  } else rewound = rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos);
+  if (!rewound) fl = kRegionEndless;
   else {
     closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
     if (im.v_ridx[closest_v]) {
@@ -257,10 +312,79 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t cur = 0;
   bool ok = true;
-  if (MODE == 2) cur = prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
-  else ok = rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
+  // With the event and hold rows of query type 4 (and the break bits of device_image.hpp) the search jumps over ranks
+  // without a neighbour holding the sample, and the walk turns every uneventful run of ref-path slots into ONE piece.
+  // (not for y < x: the window's `y - x` then wraps and is clipped to the VERTEX it is applied to -- a merged run would clip differently)
+  const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x;
+  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
+  BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
+  BitRow brk{im.seq_breaks, kNone, 0};
+  if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  else ok = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, cur, ref_pos, sample_pos) : rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
   if (!ok) fl = kRegionEndless;
-  else {
+  else if (fast) {
+    // state: cur and its record {first edge record in the blob, degree, ref index, sequence offset, length, ref-path slot + 1}
+    const uint4 v0 = im.w_vertex[2 * (uint64_t)cur], v1 = im.w_vertex[2 * (uint64_t)cur + 1];
+    uint32_t rbeg = im.blob_row[cur], deg = v0.y, ridx = v0.z, off = v0.w, len = v1.x, slot1 = v1.w;
+    const uint32_t last_slot = (uint32_t)im.P - 1;
+    bool record = false;
+    while (true) {
+      // On a ref-path node (type 2: in step with it, ref_pos == its index): up to the next slot k with an event for this
+      // sample or a break bit, the literal loop appends node after node -- consecutive in the pool and in the
+      // coordinate, the path successor taken every time -- which seq_window sees as ONE vertex of their total length.
+      if (slot1 && (MODE != 2 || ref_pos == ridx)) {
+        const uint32_t s0 = slot1 - 1;
+        const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;   // (bounded look-ahead: a clear slot `lim` is as good a place to land)
+        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
+        if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
+        if (k > s0) {
+          const uint64_t h = im.blob_of_slot[k];
+          const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header of slot k
+          const uint64_t run = (uint64_t)ra.z - ridx;                   // bases of slots [s0, k)
+          int st;
+          if (MODE == 2) {
+            st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, run, ref_pos, (uint64_t)ra.z, x, y);
+            ref_pos = ra.z;
+          } else {
+            st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, run, sample_pos, sample_pos + run, x, y);
+            sample_pos += run;
+          }
+          if (st == 2) { fl = kRegionInvalid; break; }
+          if (st == 1) break;
+          cur = rb.w; rbeg = ra.x; deg = ra.y; ridx = ra.z; off = ra.w; len = rb.x; slot1 = k + 1;
+          continue;
+        }
+      }
+      // the literal iteration (query.h:143-180 / :228-250) over the blob's edge records
+      uint64_t next_ref_pos = ref_pos + len;
+      bool have_ref = false, by_sample = false;
+      uint32_t nxt = 0, min_idx = 0xFFFFFFFFu, n_rbeg = 0, n_deg = 0, n_ridx = 0, n_len = 0, n_slot1 = 0;
+      for (uint32_t e = rbeg; e < rbeg + deg; ++e) {
+        const uint4 a = im.wblob[2 * (uint64_t)e];
+        if (a.y && !have_ref) { next_ref_pos = a.y; have_ref = true; }   // the FIRST ref neighbour (query.h:150-153)
+        if (!by_sample) {                                                 // get_neighbor_vertex
+          const bool holds = hold.bit(a.x);
+          if (holds || (a.y && min_idx > a.y)) {
+            const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+            nxt = a.x; n_rbeg = a.w; n_deg = b.x; n_ridx = a.y; n_len = b.z; n_slot1 = b.y;
+            if (holds) by_sample = true; else min_idx = a.y;
+          }
+        }
+      }
+      int st;
+      if (MODE == 2) {
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, len, ref_pos, next_ref_pos, x, y);
+        ref_pos = next_ref_pos;
+      } else {
+        st = seq_window<PASS>(r, s, seg0, byte0, cap, record, off, len, sample_pos, sample_pos + len, x, y);
+        sample_pos += len;
+      }
+      if (st == 2) { fl = kRegionInvalid; break; }
+      if (st == 1 || nxt == 0) break;
+      cur = nxt; rbeg = n_rbeg; deg = n_deg; ridx = n_ridx; len = n_len; slot1 = n_slot1;
+      off = im.v_off[cur];
+    }
+  } else {
     bool record = false, done = false;
     while (!done) {
       const WalkVertex wc = walk_vertex(im, cur);

@@ -94,6 +94,11 @@ struct HostImage {
   std::vector<uint32_t> wblob;
   std::vector<uint32_t> blob_of_slot;   // [P + 1] header record of each slot
   std::vector<uint32_t> blob_row;       // [V] first edge record of each vertex
+  // Sequence queries (types 2 / 3) merge a run of ref-path slots into ONE piece; bit k set = slot k must be stepped
+  // through literally whatever the sample: its first ref neighbour (edge order) or its smallest-index ref neighbour is
+  // not its path successor, the successor's sequence does not follow its own in the pool or in ref coordinates, or it
+  // ends the path.
+  std::vector<uint64_t> seq_breaks;   // ceil(P / 64) + 1 words
   std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
@@ -386,9 +391,26 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     for (uint64_t k = 0; k < im.P; ++k) {
       const uint32_t R = im.rp_vid[k];
       uint32_t* w = &im.wblob[(uint64_t)im.blob_of_slot[k] * 8];
-      w[0] = im.blob_row[R]; w[1] = deg_of(R); w[2] = im.v_ridx[R]; w[3] = 0; w[4] = im.v_len[R]; w[5] = im.v_class[R];
+      w[0] = im.blob_row[R]; w[1] = deg_of(R); w[2] = im.v_ridx[R]; w[3] = im.v_off[R]; w[4] = im.v_len[R]; w[5] = im.v_class[R];
       w[6] = im.v_ncar[R]; w[7] = R;
     }
+  }
+  im.seq_breaks.assign((im.P + 63) / 64 + 1, 0);
+  for (uint64_t k = 0; k < im.P; ++k) {
+    const uint32_t R = im.rp_vid[k];
+    bool brk = k + 1 >= im.P;
+    if (!brk) {
+      const uint32_t succ = im.rp_vid[k + 1];
+      uint32_t first_ref = VS_NONE, min_ref = VS_NONE, min_idx = 0xFFFFFFFFu;
+      for (uint32_t e = im.row_ptr[R]; e < im.row_ptr[R + 1]; ++e) {
+        const uint32_t n = im.col[e], nr = im.v_ridx[n];
+        if (!nr) continue;
+        if (first_ref == VS_NONE) first_ref = n;
+        if (nr < min_idx) { min_idx = nr; min_ref = n; }
+      }
+      brk = first_ref != succ || min_ref != succ || im.v_off[succ] != im.v_off[R] + im.v_len[R] || im.v_ridx[succ] != im.v_ridx[R] + im.v_len[R];
+    }
+    if (brk) im.seq_breaks[k >> 6] |= 1ull << (k & 63);
   }
   im.rk_back.assign((im.R + 1) * 2, 0);
   for (uint64_t r = 0; r < im.R; ++r) {
