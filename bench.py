@@ -567,7 +567,7 @@ def main():
         kw["num_variants"] = max(1000, w["num_variants"] * 2 // 25)
         kw["first_pos"] = min(w["first_pos"], kw["ref_length"] // 10)
         vsc = VariantStore.synthetic(device=local_rank, sample_coordinates=True, **kw)
-        nsc = 20_000
+        nsc = 100_000
         srng = np.random.default_rng(23)
         st = srng.integers(max(1, kw["first_pos"]), kw["ref_length"] - w["region_len"], size=nsc, dtype=np.int64)
         sreg = np.stack([st, st + w["region_len"]], axis=1).astype(np.uint64)

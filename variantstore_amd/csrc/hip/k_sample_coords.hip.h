@@ -166,13 +166,98 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t closest_v = 0;
-  bool rewound;
-  if (im.t4_events && sid != 0) {   // the backward searches with the per-sample event and hold rows
-    BitRow ev{im.t4_events + (uint64_t)sid * im.t4_stride, kNone, 0}, hold{im.t4_hold + (uint64_t)sid * im.t4_hold_stride, kNone, 0};
-    rewound = rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos);
-  } else rewound = rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos);
+  // With the per-sample event and hold rows of query type 4 (+ the break bits of the sequence queries): the backward
+  // searches skip ranks without a holder, the walk jumps over uneventful runs of ref-path slots (nothing is reported
+  // there; ref_pos, sample_pos and cur_ref advance with the path), and only a vertex that holds the sample pays the
+  // look-up of its sample-coordinate index.
+  const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0;
+  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
+  BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
+  BitRow brk{im.seq_breaks, kNone, 0};
+  const bool rewound = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)
+                            : rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos);
   if (!rewound) fl = kRegionEndless;
-  else {
+  else if (fast) {
+    closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
+    if (im.v_ridx[closest_v]) {
+      const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
+      ref_pos = im.v_ridx[closest_v];
+      sample_pos -= seq_len;
+    }
+    uint32_t cur = closest_v, cur_ref_v = kNone;
+    const uint4 v0 = im.w_vertex[2 * (uint64_t)cur], v1 = im.w_vertex[2 * (uint64_t)cur + 1];
+    uint32_t rbeg = im.blob_row[cur], deg = v0.y, ridx = v0.z, len = v1.x, cls = v1.y, ncar_v = v1.z, slot1 = v1.w;
+    const uint32_t last_slot = (uint32_t)im.P - 1;
+    const uint64_t a0 = EMIT ? r.var_begin[q] : 0;
+    const uint64_t cb = EMIT ? r.car_base[q] : 0;
+    while (true) {
+      if (sample_pos >= y) break;
+      if (slot1 && ref_pos == ridx) {
+        const uint32_t s0 = slot1 - 1;
+        const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;
+        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
+        if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
+        if (k > s0) {
+          const uint64_t h = im.blob_of_slot[k];
+          const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header of slot k
+          sample_pos += (uint64_t)ra.z - ridx;
+          ref_pos = ra.z;
+          cur = rb.w; rbeg = ra.x; deg = ra.y; ridx = ra.z; len = rb.x; cls = rb.y; ncar_v = rb.z; slot1 = k + 1;
+          cur_ref_v = cur;   // (the last ref neighbour of the node before: not read before this node's step overwrites it)
+          continue;
+        }
+      }
+      uint64_t next_ref_pos = ref_pos + len;
+      uint32_t next_ref_v = kNone, nxt = 0, min_idx = 0xFFFFFFFFu;
+      uint32_t n_rbeg = 0, n_deg = 0, n_ridx = 0, n_len = 0, n_cls = 0, n_ncar = 0, n_slot1 = 0;
+      bool by_sample = false;
+      for (uint32_t e = rbeg; e < rbeg + deg; ++e) {
+        const uint4 a = im.wblob[2 * (uint64_t)e];
+        if (a.y) { next_ref_pos = a.y; next_ref_v = a.x; }   // the last ref neighbour
+        if (!by_sample) {
+          const bool holds = hold.bit(a.x);
+          if (holds || (a.y && min_idx > a.y)) {
+            const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+            nxt = a.x; n_rbeg = a.w; n_deg = b.x; n_ridx = a.y; n_len = b.z; n_cls = a.z; n_ncar = b.w; n_slot1 = b.y;
+            if (holds) by_sample = true; else min_idx = a.y;
+          }
+        }
+      }
+      uint32_t sidx = 0;
+      if (sample_pos > x && hold.bit(cur) && sample_entry_rec(im, cur, ridx, im.use_bv ? cls : 0u, sid, sidx)) {
+        uint64_t pos;
+        uint32_t ro, rl, ao, al;
+        if (ref_pos == next_ref_pos) {        // insertion
+          pos = ref_pos; ro = 0; rl = 0; ao = im.v_off[cur]; al = len;
+        } else if (ridx) {                    // deletion: ref = sequence of find(ref_pos - 1)
+          const uint32_t fv = im.rp_vid[slot_of_find(im, ref_pos - 1)];
+          pos = sidx; ro = im.v_off[fv]; rl = im.v_len[fv]; ao = 0; al = 0;
+        } else {                              // substitution: ref = sequence of the previous step's last ref neighbour
+          pos = sidx; ro = 0; rl = 0; ao = im.v_off[cur]; al = len;
+          if (cur_ref_v != kNone) { ro = im.v_off[cur_ref_v]; rl = im.v_len[cur_ref_v]; }
+        }
+        const uint32_t c = ncar_v;
+        if (EMIT) {
+          const uint64_t a = a0 + nvar;
+          row_store(r.rows, a, (uint32_t)pos, ro, rl, ao, al, c, false, cb + ncar);
+          r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
+        }
+        if (MODE == 2) {
+          const uint64_t s0 = ws.cap_begin[q];
+          if (nvar < ws.cap_begin[q + 1] - s0) {
+            const uint64_t s = s0 + nvar;
+            ws.pos[s] = pos; ws.cur[s] = cur; ws.ro[s] = ro; ws.rl[s] = rl; ws.ao[s] = ao; ws.al[s] = al;
+          } else *ws.overflow = 1;
+        }
+        nvar++; ncar += pad_car(c); ncar_kept += c;
+      }
+      cur_ref_v = next_ref_v;
+      ref_pos = next_ref_pos;
+      sample_pos += len;
+      if (nxt == 0) break;
+      cur = nxt; rbeg = n_rbeg; deg = n_deg; ridx = n_ridx; len = n_len; cls = n_cls; ncar_v = n_ncar; slot1 = n_slot1;
+    }
+  } else {
     closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
     if (im.v_ridx[closest_v]) {
       const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
