@@ -132,3 +132,28 @@ def test_type4_over_resident_lists(seed, kw, tmp_path):
     two = vs.get_sample_var_in_ref(regions, names)
     vs.set_option("t4_two_walks", 0)
     assert two.layout()[2] > 0 and two.digest() == before.digest()
+
+
+@pytest.mark.parametrize("seed,kw", COHORTS[:3])
+def test_type5_over_resident_lists(seed, kw, tmp_path):
+    """get_sample_var_in_sample (sample coordinates) with its rows pointing into the resident arena: the oracle's text."""
+    vs, orc = _open(tmp_path, seed, kw)
+    rng = np.random.default_rng(seed + 2)
+    L = vs.info().ref_length
+    ns = vs.info().num_samples
+    regions = sorted(random_regions(rng, L, 120, max_len=700))
+    names = [vs.sample_name(int(i)) for i in rng.integers(1, ns, size=len(regions))]
+    before = vs.get_sample_var_in_sample(regions, names)
+    vs.set_option("resident_lists", 1)
+    res = vs.get_sample_var_in_sample(regions, names)
+    assert res.layout()[2] == 0 and res.totals() == before.totals() and res.digest() == before.digest()
+    flags = res.view(False)["region_flags"]
+    checked = 0
+    for q, (x, y) in enumerate(regions):
+        n, text = orc.get_sample_var_in_sample(x, y, names[q])
+        if n == -1:
+            assert flags[q] & 8
+            continue
+        assert res.region_text(q) == text == before.region_text(q), (q, x, y, names[q])
+        checked += 1
+    assert checked > 20

@@ -774,7 +774,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
   uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
   // Resident carrier lists: the rows point into the index's arena; nothing is expanded, the result owns no arena.
-  bool resident = idx->opts.resident_lists && idx->res_arena && !point_mode && !(t4 && (walk_mode == 5 || !single_walk));
+  bool resident = idx->opts.resident_lists && idx->res_arena && !point_mode && !(t4 && !single_walk);
   // Shared carrier lists (kernels.hip.h: k_share_*): a sorted type-6 batch expands every site it covers once and lets
   // all regions that report the site point at that one list.  Not for batches the latency path would take anyway.
   // Sharing pays when the batch's regions overlap (its price: two more scans over the regions); whether they do is known
@@ -956,7 +956,8 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   uint32_t* u_site = nullptr;
   if (n) {
-    if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    if (t4 && single_walk && walk_mode == 5 && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
