@@ -96,6 +96,7 @@ __device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_
 // get_prev_vertex_with_sample as in walk_start_search<true>: ranks whose node has no out-neighbour holding the sample
 // (clear event bit) are counted down without being read; the candidate's edge records come from the walk blob, "holds
 // the sample" from the hold row, and only the vertex that is found pays the look-up of its sample-coordinate index.
+template <bool WANT_INDEX = true>   // (type 2 never reads sample_pos: no look-up of the found vertex's index)
 __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& im, uint64_t pos, uint32_t sid, BitRow& ev, BitRow& hold,
                                                                uint64_t& ref_pos, uint64_t& sample_pos) {
   uint64_t rank;
@@ -121,9 +122,11 @@ __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& i
         ref_pos = ref_pos_in;
         return prev_vertex_with_sample(im, pos, sid, ref_pos, sample_pos);
       }
-      uint32_t idx = 0;
-      (void)sample_entry_rec(im, fv, fr, im.use_bv ? fc : 0u, sid, idx);
-      sample_pos = idx;
+      if (WANT_INDEX) {
+        uint32_t idx = 0;
+        (void)sample_entry_rec(im, fv, fr, im.use_bv ? fc : 0u, sid, idx);
+        sample_pos = idx;
+      }
       return fv;
     }
   }
@@ -404,7 +407,7 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
   BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
   BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
   BitRow brk{im.seq_breaks, kNone, 0};
-  if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
+  if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
   else ok = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, cur, ref_pos, sample_pos) : rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
   if (!ok) fl = kRegionEndless;
   else if (fast) {
@@ -517,27 +520,63 @@ __global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, u
   r.q_nseg[q] = 2 * (slots + sites) + 8;
 }
 
-// Decode the pieces into characters: one wave per region, 64 piece descriptors at a time.
+// Decode the pieces into characters (map_int, util.cc:32-41: codes 0..4 -> "ACTGN", anything else -> char 5).  One wave
+// per region, 64 piece descriptors at a time; the pieces of a region lie back to back in the output, so the wave works
+// through the OUTPUT in aligned 16-byte groups, one group per lane: a lane finds the piece its group starts in by
+// bisection over the 64 destination offsets (LDS), and -- when the group lies inside one piece, as all but one or two
+// per piece do -- decodes it with one (unaligned) 16-byte load of codes, four v_perm_b32 with the eight characters as
+// the byte table and one aligned 16-byte store; groups across a piece boundary go byte by byte.
+__device__ __forceinline__ uint8_t decode_base(uint8_t c) { return (uint8_t)(0x0505054E47544341ULL >> (8 * (c & 7))); }
 __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult r) {
+  __shared__ uint32_t s_all[4][3][65];
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (q >= r.Q) return;
   const uint32_t lane = threadIdx.x & 63;
+  uint32_t* s_dst = s_all[threadIdx.x >> 6][0];
+  uint32_t* s_src = s_all[threadIdx.x >> 6][1];
+  uint32_t* s_len = s_all[threadIdx.x >> 6][2];
   const uint64_t s0 = r.seg_begin[q], s1 = r.relative ? s0 + r.q_nseg[q] : r.seg_begin[q + 1];
   const uint64_t dst0 = r.relative ? r.byte_begin[q] : 0;
+  const uint8_t* __restrict__ codes = im.seq_codes;
   for (uint64_t base = s0; base < s1; base += 64) {
     const uint64_t mine = base + lane;
     uint32_t src = 0, len = 0;
     uint64_t dst = 0;
     if (mine < s1) { src = r.seg_src[mine]; len = r.seg_len[mine]; dst = dst0 + r.seg_dst[mine]; }
     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
-    for (uint32_t k = 0; k < cnt; ++k) {
-      const uint32_t ksrc = __builtin_amdgcn_readlane(src, k), klen = __builtin_amdgcn_readlane(len, k);
-      const uint64_t kdst = wave_bcast64(dst, k);
-      for (uint32_t i = lane; i < klen; i += 64) {
-        const uint32_t c = im.seq_codes[ksrc + i] & 7;
-        r.chars[kdst + i] = (uint8_t)(0x0505054E47544341ULL >> (8 * c));  // "ACTGN" then char 5 (map_int, util.cc:32-41)
+    const uint64_t b0 = wave_bcast64(dst, 0);                                   // first output byte of this batch of pieces
+    const uint64_t b1 = wave_bcast64(dst, cnt - 1) + __builtin_amdgcn_readlane(len, cnt - 1);
+    s_dst[lane] = lane < cnt ? (uint32_t)(dst - b0) : 0xFFFFFFFFu;
+    s_src[lane] = src; s_len[lane] = len;
+    if (lane == 0) s_dst[64] = 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t g0 = b0 & ~15ULL;                                            // (r.chars is 256-byte aligned: offsets align like addresses)
+    for (uint64_t d = g0 + 16ULL * lane; d < b1; d += 16ULL * 64) {
+      const uint64_t lo = d > b0 ? d : b0, hi = d + 16 < b1 ? d + 16 : b1;
+      const uint32_t rel = (uint32_t)(lo - b0);
+      uint32_t p = 0;
+#pragma unroll
+      for (uint32_t step = 32; step; step >>= 1)
+        if (s_dst[p + step] <= rel) p += step;
+      uint32_t pd = s_dst[p], ps = s_src[p], pl = s_len[p];
+      if (hi - lo == 16 && rel + 16 <= pd + pl) {
+        uint4 c;
+        __builtin_memcpy(&c, codes + ps + (rel - pd), 16);
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.x & 0x07070707u);
+        o.y = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.y & 0x07070707u);
+        o.z = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.z & 0x07070707u);
+        o.w = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.w & 0x07070707u);
+        *reinterpret_cast<uint4*>(r.chars + d) = o;
+      } else {
+        for (uint64_t b = lo; b < hi; ++b) {
+          const uint32_t rb = (uint32_t)(b - b0);
+          while (rb >= pd + pl) { ++p; pd = s_dst[p]; ps = s_src[p]; pl = s_len[p]; }
+          r.chars[b] = decode_base(codes[ps + (rb - pd)]);
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
