@@ -364,6 +364,15 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
   VS_TRY(upload_image(idx, im.car_index, &d.car_index));
   d.has_car_index = im.car_index.empty() ? 0u : 1u;
+  d.class_cum = nullptr;
+  if (d.has_car_index && d.use_bv && im.wpc && im.num_samples < 65536) {   // rank of a sample's bit in its class row without a pass over the row
+    const uint64_t n_rows = im.class_rows.size() / im.wpc;
+    uint16_t* cum = nullptr;
+    VS_TRY(alloc_image(idx, n_rows * im.wpc, &cum));
+    if (n_rows) hipLaunchKernelGGL(k_class_cum, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, idx->stream, d.class_rows, n_rows, (uint32_t)im.wpc, cum);
+    HIP_TRY(hipGetLastError());
+    d.class_cum = cum;
+  }
   VS_TRY(upload_image(idx, im.seq_codes, &d.seq_codes));
   const uint64_t G = d.G;
   VS_TRY(alloc_image(idx, G, &d.s_pos));

@@ -26,7 +26,8 @@ __device__ __forceinline__ bool sample_entry_rec(const DevImage& im, uint32_t v,
     const uint64_t word = row[w];
     if (!((word >> bit) & 1)) return false;
     uint32_t rank = __popcll(word & ((1ULL << bit) - 1));
-    for (uint32_t i = 0; i < w; ++i) rank += __popcll(row[i]);
+    if (im.class_cum) rank += im.class_cum[(uint64_t)cls * im.wpc + w];
+    else for (uint32_t i = 0; i < w; ++i) rank += __popcll(row[i]);
     rank -= (uint32_t)(row[0] & 1);  // the ref entry is not part of the pool
     index = im.car_index[im.v_car_begin[v] + rank];
     return true;
@@ -38,6 +39,14 @@ __device__ __forceinline__ bool sample_entry_rec(const DevImage& im, uint32_t v,
 }
 __device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {
   return sample_entry_rec(im, v, im.v_ridx[v], im.use_bv ? im.v_class[v] : 0u, sid, index);
+}
+
+// ones before each word of every class row (DevImage::class_cum), once when an index with sample coordinates is opened
+__global__ void __launch_bounds__(256) k_class_cum(const uint64_t* class_rows, uint64_t n_rows, uint32_t wpc, uint16_t* cum) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_rows) return;
+  uint32_t acc = 0;
+  for (uint32_t w = 0; w < wpc; ++w) { cum[c * wpc + w] = (uint16_t)acc; acc += __popcll(class_rows[c * wpc + w]); }
 }
 
 // get_neighbor_vertex (variant_graph.h:1402-1451): first out-neighbour holding the sample, else the ref
@@ -567,7 +576,8 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
         o.y = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.y & 0x07070707u);
         o.z = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.z & 0x07070707u);
         o.w = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.w & 0x07070707u);
-        *reinterpret_cast<uint4*>(r.chars + d) = o;
+        typedef unsigned int u32x4_chars_t __attribute__((ext_vector_type(4)));   // written once, not read again here: non-temporal
+        __builtin_nontemporal_store(u32x4_chars_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_chars_t*>(r.chars + d));
       } else {
         for (uint64_t b = lo; b < hi; ++b) {
           const uint32_t rb = (uint32_t)(b - b0);
