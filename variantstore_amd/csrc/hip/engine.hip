@@ -904,7 +904,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(ralloc(r, n, &d.q_car_len));   // (before the header kernels overwrite q_ncar with the reported carriers)
     hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)nullptr, (uint64_t*)nullptr, idx->res_entries);
   }
-  if (single_walk && walk_mode != 5 && idx->opts.share_lists && n > 64 && !resident) {
+  if (single_walk && idx->opts.share_lists && n > 64 && !resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
     const uint64_t cap_rows = ws_capacity;
     if (!idx->t4_claim) {
@@ -966,6 +966,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   uint32_t* u_site = nullptr;
   if (n) {
     if (t4 && single_walk && walk_mode == 5 && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (t4 && single_walk && walk_mode == 5 && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
