@@ -9,8 +9,8 @@ namespace vsamd {
 // Point queries (types 1 and 7).  A single next_variant_in_ref(pos) call with an empty `vars`
 // walks the ref path from find(pos) and stops at the first node with a reportable branch, so its
 // answer is the branch list of ONE ref-path slot: the first slot >= slot(find(pos)) whose sites
-// carry anybody (always-dropped sites have s_ncar == 0, reportable ones >= 1).  s_carpre over
-// rp_cand_prefix is monotone in the slot, so that slot is found by bisection.
+// carry anybody (always-dropped sites have s_ncar == 0, reportable ones >= 1).  The arena prefix at the slots' first
+// sites (rp_carpre) is monotone in the slot, so that slot is found by a galloping search from the start slot.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t slot_of_find(const DevImage& im, uint64_t pos) {  // Index::find, index.h:119-133
   uint64_t rf;
@@ -19,15 +19,25 @@ __device__ __forceinline__ uint32_t slot_of_find(const DevImage& im, uint64_t po
   return im.rank_to_slot[rf];
 }
 
+// first slot m >= s0 with a reportable branch: rp_carpre[m] == rp_carpre[s0] < rp_carpre[m + 1] (rp_carpre = the arena
+// prefix at every slot's first site).  The next variant is a few slots away, so the search gallops from s0 (probes at
+// +1, +2, +4, ...: the first ones share a cache line) and bisects inside the last stride -- a bisection over the whole
+// path read two dependent tables at each of its 23 levels: 11 KB of HBM traffic per query by the counters.
 __device__ __forceinline__ uint32_t next_valid_slot(const DevImage& im, uint32_t s0) {
   const uint32_t P = (uint32_t)im.P;
   if (s0 >= P) return P;
-  const uint64_t base = im.s_carpre[im.rp_cand_prefix[s0]];
-  if (im.s_carpre[im.G] == base) return P;
-  uint32_t lo = s0, hi = P - 1;
-  while (lo < hi) {
+  const uint64_t base = im.rp_carpre[s0];
+  uint32_t lo = s0, hi = s0, step = 1;
+  while (true) {
+    hi = (P - s0 > step) ? s0 + step : P;
+    if (im.rp_carpre[hi] > base) break;
+    if (hi == P) return P;
+    lo = hi;
+    step = step < 0x80000000u ? step << 1 : 0xFFFFFFFFu;
+  }
+  while (lo + 1 < hi) {   // rp_carpre[lo] == base < rp_carpre[hi]
     const uint32_t m = lo + ((hi - lo) >> 1);
-    if (im.s_carpre[im.rp_cand_prefix[m + 1]] > base) hi = m; else lo = m + 1;
+    if (im.rp_carpre[m] > base) hi = m; else lo = m;
   }
   return lo;
 }
