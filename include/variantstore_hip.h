@@ -233,6 +233,12 @@ typedef struct {
 } vs_result_raw;
 int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw);
 
+/* Option "async_fill" (vs_index_set_option): a type-6 batch call returns as soon as rows and per-region arrays are in
+ * HBM, while the carrier expansion still runs on the handle's second stream -- the next batch's bounds, scans and rows
+ * then run beside it.  Every accessor that reads carriers waits for the expansion by itself; vs_result_fill_ms reports
+ * its duration (HIP events on the stream it ran on; -1 when the expansion was not asynchronous). */
+int vs_result_fill_ms(vs_result* r, float* ms);
+
 /* Type 6 with delivery: the (sorted) batch is answered in chunks of `chunk_regions`, and while one chunk is computed the
  * raw copy of the previous one crosses PCIe on a second stream into page-locked memory; `fn(user, first_region, raw)` is
  * called once per chunk, in order, with a raw view that is valid during the call (return non-zero to stop). */
@@ -280,7 +286,8 @@ void vs_result_free(vs_result* r);
  * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
  * chosen from the batch's shape); "share_lists" 0 = every region gets private rows and carrier lists even in a sorted
  * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whenever the batch is sorted; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
- * "resident_lists" 1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
+ * "async_fill" 1 = the carrier expansion of a type-6 batch runs on a second stream and the call returns while it is in
+ * flight (see vs_result_fill_ms; default 0); "resident_lists" 1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
  * 4 bytes per carrier record; VS_ERR_UNSUPPORTED when that does not fit): batches of query types 6 and 4 then emit rows
  * that point into it, expand nothing and own no arena, and a raw copy moves the rows only (default 0; VS_RESIDENT_LISTS=1
  * in the environment builds it when the handle is opened);

@@ -944,3 +944,43 @@ def test_type4_regions_that_outgrow_their_scratch_capacity(tmp_path):
         n, _, text = orc.get_sample_var_in_ref(x, y, per[q])
         if n >= 0:
             assert res.region_text(q) == text, (q, x, y)
+
+
+def test_async_fill_results_are_the_same(tmp_path):
+    """Option "async_fill": a type-6 batch call returns while its carrier expansion still runs on the engine's second
+    stream; every accessor that reads carriers waits by itself.  Several batches in flight, read and freed in any order,
+    small (latency-path) queries in between: the oracle's text everywhere, the synchronous digests."""
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 631, n_rows=500, ref_len=8000, n_samples=300, carrier_p=0.3, p_ins=0.1, p_del=0.1)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(631)
+    L = vs.info().ref_length
+    batches = [sorted(random_regions(rng, L, 300, max_len=1500)), random_regions(rng, L, 200, max_len=900), sorted(random_regions(rng, L, 120, max_len=4000))]
+    vs.set_option("async_fill", 0)
+    sync = [vs.get_var_in_ref(b) for b in batches]
+    want = [(r.digest(), r.totals()) for r in sync]
+    vs.set_option("async_fill", 1)
+    flight = [vs.get_var_in_ref(b) for b in batches]          # three expansions queued behind each other
+    small = vs.get_var_in_ref(batches[0][:5])                   # the latency path does not wait for them
+    for q, (x, y) in enumerate(batches[0][:5]):
+        n, _, text = orc.get_var_in_ref(x, y)
+        if n >= 0:
+            assert small.region_text(q) == text
+    assert flight[2].fill_ms() >= 0 and sync[2].fill_ms() == -1
+    for k in (2, 0, 1):
+        assert (flight[k].digest(), flight[k].totals()) == want[k]
+        for q in range(0, len(batches[k]), 9):
+            n, _, text = orc.get_var_in_ref(*batches[k][q])
+            if n >= 0:
+                assert flight[k].region_text(q) == text, (k, q)
+        va, vb = flight[k].view(True), sync[k].view(True)
+        for key in va:
+            assert np.array_equal(va[key], vb[key]), (k, key)
+    for r in flight:
+        r.close()
+    # freed while still in flight; then a raw copy straight after the call
+    vs.get_var_in_ref(batches[0]).close()
+    r = vs.get_var_in_ref(batches[0])
+    raw = r.raw(with_carriers=True)
+    assert raw["rows"].shape[0] == sync[0].layout()[1] and int(raw["arena"].astype(np.uint64).sum()) == int(sync[0].raw(True)["arena"].astype(np.uint64).sum())
+    vs.set_option("async_fill", 0)
+    assert vs.get_var_in_ref(batches[0]).fill_ms() == -1

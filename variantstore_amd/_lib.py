@@ -107,6 +107,7 @@ SYMBOLS = {
     "vs_result_digest": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "vs_result_layout": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_int)]),
+    "vs_result_fill_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "vs_result_pack_headers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vs_result_pack_regions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vs_result_free": (None, [_P]),

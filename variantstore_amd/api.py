@@ -92,6 +92,12 @@ class QueryResult:
         _check(self._lib.vs_result_layout(self._h, C.byref(n), C.byref(t), C.byref(s), C.byref(u), C.byref(sh)), "vs_result_layout")
         return int(n.value), int(t.value), int(s.value), int(u.value), bool(sh.value)
 
+    def fill_ms(self):
+        """Duration of the carrier expansion when it ran asynchronously (option "async_fill"; waits for it), else -1."""
+        ms = C.c_float()
+        _check(self._lib.vs_result_fill_ms(self._h, C.byref(ms)), "vs_result_fill_ms")
+        return float(ms.value)
+
     def digest(self):
         d = C.c_uint64()
         _check(self._lib.vs_result_digest(self._h, C.byref(d)), "vs_result_digest")

@@ -62,6 +62,9 @@ struct EngineOpts {
   int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
+  bool async_fill = false;      // type-6 batches: the carrier expansion runs on a second stream and the call returns while it is
+                                // in flight (every accessor of the result waits for it): the next batch's bounds, scans and rows
+                                // run beside it
   bool resident_lists = false;  // carrier lists expanded once into an arena that stays with the index (build_resident_lists): results hold rows only
   int share_lists = 1;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
@@ -144,6 +147,10 @@ struct vs_result {
   bool shared_lists = false;          // rows and carrier lists shared between the regions of the batch (DevResult::q_car_len valid)
   uint64_t n_unique_sites = 0;        // lists actually expanded: unique covered sites when shared, else the rows
   uint64_t n_rows_reported = 0;       // rows over all regions (shared rows counted once per region that reports them)
+  // async_fill: the expansion of this result is (or was) in flight on the handle's second stream
+  bool pending = false;
+  hipEvent_t ev_fill[2] = {nullptr, nullptr};   // around the expansion, on the stream it runs on
+  float fill_ms = -1.0f;
   bool resident = false;              // the carrier arena is the index's (vs_index::res_arena), not this result's
   bool scattered_lists = false;       // lists shared per vertex (walking query types): a region's carriers are not one arena range
   std::vector<uint64_t> h_car_len;
@@ -486,6 +493,7 @@ static void read_env_opts(vs_index* idx) {
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
   if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = 0;
+  o.async_fill = getenv("VS_ASYNC_FILL") != nullptr;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
@@ -547,8 +555,25 @@ static void launch_fill(vs_index* idx, const DevResult& d, bool share, const uin
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, ablate, gt_words);
 }
 
+static int ensure_fill_stream(vs_index* idx) {
+  if (idx->fill_stream) return VS_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
+  return VS_OK;
+}
+// An asynchronous expansion (option "async_fill") must have finished before anything reads the result or returns its
+// buffers to the pool.
+static int result_ready(vs_result* r) {
+  if (!r->pending) return VS_OK;
+  r->pending = false;
+  HIP_TRY(hipEventSynchronize(r->ev_fill[1]));
+  HIP_TRY(hipEventElapsedTime(&r->fill_ms, r->ev_fill[0], r->ev_fill[1]));
+  return VS_OK;
+}
+
 // The carrier expansion of one result (or of the resident arena): one launch over n_fill rows.
-static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill) {
+static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill, hipStream_t on = nullptr) {
   if (n_fill) {
     {
       // one task per wave, no grid-stride loop: task costs vary tenfold with the number of dense variants, and the
@@ -572,14 +597,10 @@ static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint3
       constexpr bool kTune = false;
 #endif
       const bool wide = idx->d.wpc > 63;
-      if (idx->opts.fill_split && share && !wide && idx->d.use_bv) {
+      if (idx->opts.fill_split && share && !wide && idx->d.use_bv && !on) {
         // the listed variants (64 rows per task: lane per group of 8 carriers) and the denser ones (16 rows per task: wave per
         // variant) as two launches side by side on two streams
-        if (!idx->fill_stream) {
-          HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
-          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
-          HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
-        }
+        VS_TRY(ensure_fill_stream(idx));
         HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
         HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
         const unsigned blocks64 = (unsigned)(((n_fill + 63) / 64 + 3) / 4), blocks16 = (unsigned)(((n_fill + 15) / 16 + 3) / 4);
@@ -589,14 +610,14 @@ static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint3
         HIP_TRY(hipStreamWaitEvent(idx->stream, idx->fill_ev[1], 0));
       } else
       switch (chunk) {
-        case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        case 16: wide ? launch_fill<true, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        case 32: wide ? launch_fill<true, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
-        default: wide ? launch_fill<true, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words)
-                      : launch_fill<false, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words); break;
+        case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on)
+                      : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on); break;
+        case 16: wide ? launch_fill<true, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on)
+                      : launch_fill<false, 16, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on); break;
+        case 32: wide ? launch_fill<true, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on)
+                      : launch_fill<false, 32, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on); break;
+        default: wide ? launch_fill<true, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on)
+                      : launch_fill<false, 64, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on); break;
       }
     }
     HIP_TRY(hipGetLastError());
@@ -692,7 +713,7 @@ static int ensure_resident_mirror(vs_index* idx) {
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
                           const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
-                          int walk_mode = 4, bool regions_on_device = false, const uint64_t* site_records = nullptr) {
+                          int walk_mode = 4, bool regions_on_device = false, const uint64_t* site_records = nullptr, bool allow_async = false) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
   uint32_t* dsids = nullptr;
@@ -997,7 +1018,20 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   const uint64_t n_fill = resident ? 0 : (share ? n_unique : d.A);   // lists to expand: shared rows resp. all rows; none with resident lists
-  VS_TRY(fill_lists(idx, d, share, u_site, n_fill));
+  // async_fill: the expansion goes to the handle's second stream behind an event and the call returns once the FIRST
+  // stream is done (rows, per-region arrays); the next batch's bounds, scans and rows then run beside it.  The call's
+  // temporaries (the site index the expansion reads) stay with the result until it is freed.
+  const bool async_fill = allow_async && idx->opts.async_fill && !t4 && !point_mode && n_fill > 0;
+  if (async_fill) {
+    VS_TRY(ensure_fill_stream(idx));
+    for (auto& e : r->ev_fill) if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
+    HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
+    HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
+    VS_TRY(fill_lists(idx, d, share, u_site, n_fill, idx->fill_stream));
+    HIP_TRY(hipEventRecord(r->ev_fill[1], idx->fill_stream));
+    r->pending = true;
+  } else VS_TRY(fill_lists(idx, d, share, u_site, n_fill));
   if (perm) {   // every region's outcome back to its place in the caller's order (rows and lists are shared: nothing else moves)
     const DevResult ds = d;
     d.regions = d_user.regions; d.q_flags = d_user.q_flags; d.q_g0 = d_user.q_g0; d.q_nvar = d_user.q_nvar; d.q_ncar = d_user.q_ncar;
@@ -1007,6 +1041,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
+  if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
   scratch.release();
   vs_timing& t = idx->timing;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
@@ -1014,7 +1049,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
   HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
   HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
-  t.fill_launches = n_fill ? 1 : 0;
+  t.fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
   return VS_OK;
 }
 
@@ -1028,6 +1063,7 @@ static int fetch(vs_index* idx, std::vector<T>& h, const T* dptr, size_t n) {
 // carriers [first, first + n) of the arena as 32-bit words (id | gt << 29), whatever the arena's width
 static int fetch_carriers(vs_result* r, uint64_t first, uint64_t n, std::vector<uint32_t>& out) {
   vs_index* idx = r->idx;
+  VS_TRY(result_ready(r));
   out.resize(n);
   if (n == 0) return VS_OK;
   if (r->d.car_width == 4) {
@@ -1623,6 +1659,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value) VS_TRY(build_resident_lists(idx));   // (kept once built: switching back to 0 only stops results from using it)
     o.resident_lists = value != 0;
   }
+  else if (k == "async_fill") o.async_fill = value != 0;
   else if (k == "fill_split") o.fill_split = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
@@ -1652,6 +1689,8 @@ void vs_result_free(vs_result* r) {
   if (!r) return;
   if (r->idx) {
     (void)hipSetDevice(r->idx->device);
+    (void)result_ready(r);
+    for (auto& e : r->ev_fill) if (e) (void)hipEventDestroy(e);
     release_bufs(r->idx, r->bufs);
     pin_release(r->idx, r->raw_pin);
     r->idx->live_results--;
@@ -1675,7 +1714,7 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
       r->d = DevResult{};
     }
   }
-  if (rc == 1) rc = run_var_in_ref(idx, regions, n, r);
+  if (rc == 1) rc = run_var_in_ref(idx, regions, n, r, kNone, nullptr, 0, nullptr, 4, false, nullptr, /*allow_async=*/true);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1688,7 +1727,7 @@ int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, u
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  const int rc = run_var_in_ref(idx, device_regions, n, r, kNone, nullptr, 0, nullptr, 4, /*regions_on_device=*/true);
+  const int rc = run_var_in_ref(idx, device_regions, n, r, kNone, nullptr, 0, nullptr, 4, /*regions_on_device=*/true, nullptr, /*allow_async=*/true);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1870,6 +1909,7 @@ static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) 
   const DevResult& d = r->d;
   const size_t row_bytes = (size_t)d.A * sizeof(VariantRow), arena_bytes = with_carriers && !r->resident ? (size_t)d.S * d.car_width : 0;
   if (r->raw_rows && (r->raw_arena || !with_carriers)) return VS_OK;
+  if (with_carriers) VS_TRY(result_ready(r));
   if (with_carriers && r->resident) VS_TRY(ensure_resident_mirror(idx));   // the rows point into the handle's mirror of the resident arena
   if (r->raw_pin.p) { pin_release(idx, r->raw_pin); r->raw_pin = DevBuf{nullptr, 0}; r->raw_rows = nullptr; r->raw_arena = nullptr; }
   VS_TRY(pin_alloc(idx, row_bytes + arena_bytes + 64, &r->raw_pin));
@@ -2143,6 +2183,16 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   return VS_OK;
 }
 
+/* Duration of the result's carrier expansion by HIP events on the stream it ran on, when it ran asynchronously (option
+ * "async_fill"; waits for it); -1 otherwise (vs_index_last_timing().ms_fill has it then). */
+int vs_result_fill_ms(vs_result* r, float* ms) {
+  if (!r || !ms) return fail(VS_ERR_ARG, "null argument");
+  if (r->idx && r->idx->device >= 0) HIP_TRY(hipSetDevice(r->idx->device));
+  VS_TRY(result_ready(r));
+  *ms = r->fill_ms;
+  return VS_OK;
+}
+
 int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
@@ -2159,6 +2209,7 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   VS_NOT_SEQ(r);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(result_ready(r));
   ScratchBufs tmp(idx);
   void* dd = nullptr;
   VS_TRY(dev_alloc(idx, 8, &dd, &tmp.bufs));
