@@ -560,30 +560,47 @@ __global__ void __launch_bounds__(256) k_copy_segments(DevImage im, DevSeqResult
     if (lane == 0) s_dst[64] = 0xFFFFFFFFu;
     __builtin_amdgcn_wave_barrier();
     const uint64_t g0 = b0 & ~15ULL;                                            // (r.chars is 256-byte aligned: offsets align like addresses)
-    for (uint64_t d = g0 + 16ULL * lane; d < b1; d += 16ULL * 64) {
-      const uint64_t lo = d > b0 ? d : b0, hi = d + 16 < b1 ? d + 16 : b1;
-      const uint32_t rel = (uint32_t)(lo - b0);
-      uint32_t p = 0;
+    for (uint64_t dbase = g0; dbase < b1; dbase += 16ULL * 64) {               // 64 groups = 1 KiB of output per pass
+      const uint64_t d = dbase + 16ULL * lane;
+      bool odd = false;                                                          // my group is not wholly inside one piece
+      if (d < b1) {
+        const uint64_t lo = d > b0 ? d : b0, hi = d + 16 < b1 ? d + 16 : b1;
+        const uint32_t rel = (uint32_t)(lo - b0);
+        uint32_t p = 0;
 #pragma unroll
-      for (uint32_t step = 32; step; step >>= 1)
-        if (s_dst[p + step] <= rel) p += step;
-      uint32_t pd = s_dst[p], ps = s_src[p], pl = s_len[p];
-      if (hi - lo == 16 && rel + 16 <= pd + pl) {
-        uint4 c;
-        __builtin_memcpy(&c, codes + ps + (rel - pd), 16);
-        uint4 o;
-        o.x = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.x & 0x07070707u);
-        o.y = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.y & 0x07070707u);
-        o.z = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.z & 0x07070707u);
-        o.w = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.w & 0x07070707u);
-        typedef unsigned int u32x4_chars_t __attribute__((ext_vector_type(4)));   // written once, not read again here: non-temporal
-        __builtin_nontemporal_store(u32x4_chars_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_chars_t*>(r.chars + d));
-      } else {
-        for (uint64_t b = lo; b < hi; ++b) {
-          const uint32_t rb = (uint32_t)(b - b0);
-          while (rb >= pd + pl) { ++p; pd = s_dst[p]; ps = s_src[p]; pl = s_len[p]; }
-          r.chars[b] = decode_base(codes[ps + (rb - pd)]);
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_dst[p + step] <= rel) p += step;
+        const uint32_t pd = s_dst[p], ps = s_src[p], pl = s_len[p];
+        if (hi - lo == 16 && rel + 16 <= pd + pl) {
+          uint4 c;
+          __builtin_memcpy(&c, codes + ps + (rel - pd), 16);
+          uint4 o;
+          o.x = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.x & 0x07070707u);
+          o.y = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.y & 0x07070707u);
+          o.z = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.z & 0x07070707u);
+          o.w = __builtin_amdgcn_perm(0x0505054Eu, 0x47544341u, c.w & 0x07070707u);
+          typedef unsigned int u32x4_chars_t __attribute__((ext_vector_type(4)));   // written once, not read again here: non-temporal
+          __builtin_nontemporal_store(u32x4_chars_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_chars_t*>(r.chars + d));
+        } else odd = true;
+      }
+      // groups across a piece boundary (and the ragged first / last one): four of them per pass, one BYTE per lane --
+      // sixteen lanes per group, each finds its byte's piece by itself
+      uint64_t m = __ballot(odd);
+      while (m) {
+        uint64_t mm = m;
+        for (uint32_t t = 0; t < (lane >> 4); ++t) mm &= mm - 1;               // the (lane / 16)-th odd group of this pass
+        if (mm) {
+          const uint64_t b = dbase + 16ULL * (uint32_t)__builtin_ctzll(mm) + (lane & 15u);
+          if (b >= b0 && b < b1) {
+            const uint32_t rel = (uint32_t)(b - b0);
+            uint32_t p = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1)
+              if (s_dst[p + step] <= rel) p += step;
+            r.chars[b] = decode_base(codes[s_src[p] + (rel - s_dst[p])]);
+          }
         }
+        for (int t = 0; t < 4 && m; ++t) m &= m - 1;
       }
     }
     __builtin_amdgcn_wave_barrier();
