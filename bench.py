@@ -281,12 +281,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-samples", type=int, default=200)
     ap.add_argument("--extras", default=os.environ.get("VS_BENCH_EXTRAS", "all"),
-                    help="comma list of the untimed legs to run: t4,points,sc,delivery,cli | all | none")
+                    help="comma list of the untimed legs to run: t4,points,sc,delivery,resident,cli,pipelined | all (= all but cli and pipelined, "
+                         "which run by name only) | none")
     ap.add_argument("--skip-extras", action="store_true", help="same as --extras none")
     ap.add_argument("--async-fill", action="store_true",
                     help="headline loop with the engine's pipelined expansion (option async_fill): step k's carrier expansion runs beside step "
                          "k + 1's bounds, scans and rows.  Off by default: the expansion kernel then shares the machine and its own duration -- "
-                         "the roofline figure -- no longer describes the kernel; the `pipelined` block of the line has the throughput")
+                         "the roofline figure -- no longer describes the kernel; `--extras pipelined` measures the throughput beside the default loop")
     args = ap.parse_args()
     if args.skip_extras or os.environ.get("VS_BENCH_SKIP_T4") == "1":
         args.extras = "none"
@@ -495,8 +496,8 @@ def main():
     # ---- the same batches PIPELINED (engine option async_fill): a batch call returns when rows and per-region arrays are in
     #      HBM, its carrier expansion runs on the engine's second stream beside the next batch's bounds, scans and rows ----
     pipe = None
-    if not pipelined and not use_dist:
-        vs.set_option("async_fill", 1)
+    if "pipelined" in extras and not pipelined and not use_dist:   # (by name only: its launches of the expansion kernel last longer
+        vs.set_option("async_fill", 1)                              #  and would blur the kernel's mean duration in a trace of this command)
         try:
             prev_r = None
             for _i in range(3):

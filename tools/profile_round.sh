@@ -37,4 +37,6 @@ python3 tools/make_traffic_json.py $wl $tag --blob=$(cat $O/kernels_blob.txt) gp
 cp profiles/traffic_$wl.json $O/
 python3 bench.py --workload $wl > $O/${tag}_bench.json 2> gpurun_out/${tag}_bench_err.log
 echo "bench rc=$?"
+python3 bench.py --workload $wl --extras pipelined --no-cpu-baseline --latency-samples 0 > $O/${tag}_bench_pipelined.json 2>> gpurun_out/${tag}_bench_err.log
+echo "bench (pipelined leg) rc=$?"
 tail -c 600 $O/${tag}_bench.json
