@@ -356,6 +356,9 @@ static int build_device_image(vs_index* idx) {
     VS_TRY(upload_image(idx, im.blob_row, &d.blob_row));
     VS_TRY(upload_image(idx, im.rk_back, &rb));
     VS_TRY(upload_image(idx, im.seq_breaks, &d.seq_breaks));
+    const uint32_t* ra = nullptr;
+    VS_TRY(upload_image(idx, im.rk_anc, &ra));
+    d.rk_anc = reinterpret_cast<const uint2*>(ra);
     d.wblob = reinterpret_cast<const uint4*>(wb);
     d.rk_back = reinterpret_cast<const uint2*>(rb);
   }

@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
 // or kEpSteps steps -- not seen) sends its region through the serial loop, again redundantly in the 16 lanes.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEpEmits = 4, kEpSteps = 12;
+constexpr uint32_t kSearchWindow = 32;   // ranks of the backward search's chain read per round trip (a multiple of SUB, at most 32)
 
 template <uint32_t SUB>
 __device__ __forceinline__ uint32_t group_inclusive_scan(uint32_t l, uint32_t v) {   // prefix sum inside each group of SUB lanes (l = lane within the group)
@@ -573,14 +574,15 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       if (!cx.use_ev) serial = true;
     }
   }
-  // ---- get_prev_vertex_with_sample, 16 ranks of the chain at a time ----
-  // The search visits rank, rank - deg(previous(rank)), ... (one count per neighbour of each visited node).  The group
-  // reads the records of the 16 ranks below the current one together, follows the chain through them in registers
-  // (which of the 16 are visited), tests the visited nodes' event bits, and checks the candidates literally in
+  // ---- get_prev_vertex_with_sample, kSearchWindow (32) ranks at a time ----
+  // The search visits rank, rank - deg(previous(rank)), ... (one count per neighbour of each visited node): a static
+  // chain.  The group reads the records of the 32 ranks below the current one together, decides which of them the
+  // chain visits (ancestor labels, rk_anc), tests the visited nodes' event bits, and checks the candidates literally in
   // parallel; the first visited node with a neighbour holding the sample is the answer.  Its ref_pos is the node's own
   // last ref neighbour; a node without one (the end of the path) would need the history: serial loop.
   bool searching = live && !fl && cx.use_ev;
   uint64_t rank = rank0;
+  const uint32_t tin0 = (searching && rank0 >= 2) ? im.rk_anc[rank0 - 1].x : 0u;   // label of the chain's first rank
   while (__any(searching)) {
     if (searching && rank <= 1) {   // the head of the path (redundant in the group)
       const uint32_t v = im.rp_vid[im.rk_back[rank == 0 ? 0 : rank - 1].x];
@@ -589,31 +591,50 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       searching = false;
     }
     ++n_search;
-    const bool valid = searching && rank >= (uint64_t)l + 2;
-    uint2 back{0, 1};
-    if (valid) back = im.rk_back[rank - l - 1];
-    uint32_t vis = 0, pos = 0;   // group-uniform: chain positions visited among the 16, next position
-#pragma unroll 1
-    for (int t = 0; t < (int)SUB; ++t) {
-      const int src = (int)gbase + (int)(pos < SUB ? pos : SUB - 1);
-      const uint32_t deg_c = (uint32_t)__shfl((int)back.y, src, 64);
-      const bool val_c = __shfl((int)valid, src, 64) != 0;
-      if (pos < SUB && val_c) { vis |= 1u << pos; pos += deg_c ? deg_c : 1u; }
+    // kSearchWindow ranks per round trip, E consecutive rank records per lane (lane l: offsets [l * E, l * E + E) below
+    // the window's top rank).  Which of them the chain from rank0 visits is an ancestor test on the static forest of
+    // chains (DevImage::rk_anc) -- no walking along the chain, every lane decides for its own ranks.
+    constexpr uint32_t E = kSearchWindow / SUB;
+    uint2 back[E], anc[E];
+    bool valid[E];
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      const uint64_t off = (uint64_t)l * E + e;
+      valid[e] = searching && rank >= off + 2;
+      back[e] = valid[e] ? im.rk_back[rank - off - 1] : uint2{0, 1};
+      anc[e] = valid[e] ? im.rk_anc[rank - off - 1] : uint2{1, 0};
     }
-    const bool cand = valid && ((vis >> l) & 1) && ev.bit(back.x);
+    uint32_t vis = 0;   // (per lane: bit l * E + e)
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e)
+      if (valid[e] && anc[e].x <= tin0 && tin0 - anc[e].x < anc[e].y) vis |= 1u << (l * E + e);
+    const uint32_t pos = kSearchWindow;   // the next window starts right below this one
     bool found = false, had_ref = false;
     uint32_t f_ref_pos = 0, f_v = 0, f_slot1 = 0;
     WalkVertex f_wc{};
-    if (cand) {
-      const uint32_t rb0 = im.blob_of_slot[back.x] + 1;   // the edge records follow the slot's header
-      for (uint32_t e = rb0; e < rb0 + back.y; ++e) {
-        const uint4 a = im.wblob[2 * (uint64_t)e];
-        if (a.y) { f_ref_pos = a.y; had_ref = true; }
-        if (hold.bit(a.x)) {
-          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
-          f_v = a.x; found = true; f_slot1 = b.y;
-          f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
+    uint64_t ev_word[E];   // the visited nodes' event words, requested together (one memory latency, not one per node)
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      const bool visited = valid[e] && ((vis >> (l * E + e)) & 1);
+      ev_word[e] = visited ? ev.row[back[e].x >> 6] : 0ULL;
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {   // in chain order within the lane: the first visited node with a holder wins
+      const bool cand = !found && ((ev_word[e] >> (back[e].x & 63)) & 1);
+      if (cand) {
+        bool hr = false;
+        uint32_t rp = 0;
+        const uint32_t rb0 = im.blob_of_slot[back[e].x] + 1;   // the edge records follow the slot's header
+        for (uint32_t ed = rb0; ed < rb0 + back[e].y; ++ed) {
+          const uint4 a = im.wblob[2 * (uint64_t)ed];
+          if (a.y) { rp = a.y; hr = true; }
+          if (hold.bit(a.x)) {
+            const uint4 b = im.wblob[2 * (uint64_t)ed + 1];
+            f_v = a.x; found = true; f_slot1 = b.y;
+            f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
+          }
         }
+        if (found) { f_ref_pos = rp; had_ref = hr; }
       }
     }
     const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & kGroupMask);

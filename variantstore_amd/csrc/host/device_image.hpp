@@ -99,6 +99,10 @@ struct HostImage {
   // not its path successor, the successor's sequence does not follow its own in the pool or in ref coordinates, or it
   // ends the path.
   std::vector<uint64_t> seq_breaks;   // ceil(P / 64) + 1 words
+  // The backward search of get_prev_vertex_with_sample visits rank, rank - deg(previous(rank)), ...: a STATIC chain, so
+  // the ranks form a forest (parent = the next rank of the chain) and "does the chain from r0 visit rank p" is "p is an
+  // ancestor of r0": DFS interval labels {tin, subtree size} per chain rank, 2 words at index rank - 1 like rk_back.
+  std::vector<uint32_t> rk_anc;
   std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
@@ -417,6 +421,20 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     const uint32_t slot = im.rank_to_slot[r];
     im.rk_back[2 * r] = slot;
     if (slot < im.P) { const uint32_t v = im.rp_vid[slot]; im.rk_back[2 * r + 1] = im.row_ptr[v + 1] - im.row_ptr[v]; }
+  }
+  {  // chain ranks 0 .. R; rank p >= 2 steps to p - max(deg, 1) with deg = out-degree of previous(p) = rk_back[p - 1]
+    const uint64_t n = im.R + 1;
+    auto parent = [&](uint64_t p) -> uint64_t {
+      const uint32_t deg = im.rk_back[2 * (p - 1) + 1];
+      const uint64_t step = deg ? deg : 1;
+      return p > step ? p - step : 0;
+    };
+    std::vector<uint32_t> size(n, 1), off(n, 1), tin(n, 0);
+    for (uint64_t p = n; p-- > 2;) size[parent(p)] += size[p];
+    if (n > 1) tin[1] = size[0];
+    for (uint64_t p = 2; p < n; ++p) { const uint64_t q = parent(p); tin[p] = tin[q] + off[q]; off[q] += size[p]; }
+    im.rk_anc.assign(n * 2, 0);
+    for (uint64_t p = 1; p < n; ++p) { im.rk_anc[2 * (p - 1)] = tin[p]; im.rk_anc[2 * (p - 1) + 1] = size[p]; }
   }
 }
 
