@@ -984,3 +984,37 @@ def test_async_fill_results_are_the_same(tmp_path):
     assert raw["rows"].shape[0] == sync[0].layout()[1] and int(raw["arena"].astype(np.uint64).sum()) == int(sync[0].raw(True)["arena"].astype(np.uint64).sum())
     vs.set_option("async_fill", 0)
     assert vs.get_var_in_ref(batches[0]).fill_ms() == -1
+
+
+@pytest.mark.parametrize("seed,n_samples,carrier_p", [(641, 40, 0.002), (642, 150, 0.004), (643, 9, 0.01)])
+def test_type4_long_backward_searches(seed, n_samples, carrier_p, tmp_path):
+    """Samples with a handful of variants on a reference with thousands of nodes: get_prev_vertex_with_sample runs for
+    hundreds of ranks, so the cooperative walk's search leaves its rank windows for the set bits of the sample's event
+    row (k_sample_walk_coop: hop) -- every walk form against the oracle, and the same for types 2, 3 and 5."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), seed, n_rows=1500, ref_len=24000, n_samples=n_samples, carrier_p=carrier_p,
+                                            p_ins=0.1, p_del=0.1, p_multi=0.1)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(seed)
+    L = vs.info().ref_length
+    regions = sorted(random_regions(rng, L, 260, max_len=1200))
+    per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
+    want = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(regions, per)]
+    assert sum(1 for n, _, _ in want if n >= 0) > 200
+    for coop, skip in ((8, 1), (16, 1), (0, 1), (0, 0)):
+        vs.set_option("t4_coop", coop)
+        vs.set_option("t4_skip", skip)
+        res = vs.get_sample_var_in_ref(regions, per)
+        for q, (n, _, text) in enumerate(want):
+            if n >= 0:
+                assert res.region_text(q) == text, (coop, skip, q, regions[q], per[q])
+        res.close()
+    vs.set_option("t4_coop", 8)
+    vs.set_option("t4_skip", 1)
+    r5 = vs.get_sample_var_in_sample(regions, per)
+    f5 = r5.view(False)["region_flags"]
+    for q, ((x, y), sm) in enumerate(zip(regions, per)):
+        n, text = orc.get_sample_var_in_sample(x, y, sm)
+        if n == -1:
+            assert f5[q] & 8
+        else:
+            assert r5.region_text(q) == text, (q, x, y, sm)

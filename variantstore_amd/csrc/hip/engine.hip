@@ -359,6 +359,7 @@ static int build_device_image(vs_index* idx) {
     const uint32_t* ra = nullptr;
     VS_TRY(upload_image(idx, im.rk_anc, &ra));
     d.rk_anc = reinterpret_cast<const uint2*>(ra);
+    VS_TRY(upload_image(idx, im.slot_rank, &d.slot_rank));
     d.wblob = reinterpret_cast<const uint4*>(wb);
     d.rk_back = reinterpret_cast<const uint2*>(rb);
   }

@@ -76,6 +76,7 @@ struct DevImage {
                                 //   NULL otherwise): the rank of a sample's bit -- its entry in the carrier pool -- in two loads
   const uint2* rk_anc;      // [R] per chain rank r + 1: {tin, subtree size} in the forest of the backward search's chains (device_image.hpp):
                             //   the chain from r0 visits rank p  <=>  tin[p] <= tin[r0] < tin[p] + size[p]
+  const uint32_t* slot_rank;  // [P] rank of every ref-path slot (its node's start index is the rank-th set bit of the rank structure)
   const uint64_t* seq_breaks;   // bit per ref-path slot: the sequence queries must step through it literally (device_image.hpp)
   // RESIDENT carrier lists (option "resident_lists"; engine.hip: build_resident_lists): every list a query can report,
   // expanded once into an arena that stays with the index -- the lists of the sites in site-table order at s_carpre[g]

@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
 // or kEpSteps steps -- not seen) sends its region through the serial loop, again redundantly in the 16 lanes.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEpEmits = 4, kEpSteps = 12;
+constexpr uint32_t kHopAfter = 4;        // windows of the backward search before it goes over to the event row's set bits
 constexpr uint32_t kSearchWindow = 32;   // ranks of the backward search's chain read per round trip (a multiple of SUB, at most 32)
 
 template <uint32_t SUB>
@@ -583,6 +584,8 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   bool searching = live && !fl && cx.use_ev;
   uint64_t rank = rank0;
   const uint32_t tin0 = (searching && rank0 >= 2) ? im.rk_anc[rank0 - 1].x : 0u;   // label of the chain's first rank
+  bool hop = false;            // group-uniform: the search has gone over to the event row's set bits
+  uint32_t windows = 0, s_top = 0;
   while (__any(searching)) {
     if (searching && rank <= 1) {   // the head of the path (redundant in the group)
       const uint32_t v = im.rp_vid[im.rk_back[rank == 0 ? 0 : rank - 1].x];
@@ -591,50 +594,67 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       searching = false;
     }
     ++n_search;
-    // kSearchWindow ranks per round trip, E consecutive rank records per lane (lane l: offsets [l * E, l * E + E) below
-    // the window's top rank).  Which of them the chain from rank0 visits is an ancestor test on the static forest of
-    // chains (DevImage::rk_anc) -- no walking along the chain, every lane decides for its own ranks.
-    constexpr uint32_t E = kSearchWindow / SUB;
-    uint2 back[E], anc[E];
-    bool valid[E];
-#pragma unroll
-    for (uint32_t e = 0; e < E; ++e) {
-      const uint64_t off = (uint64_t)l * E + e;
-      valid[e] = searching && rank >= off + 2;
-      back[e] = valid[e] ? im.rk_back[rank - off - 1] : uint2{0, 1};
-      anc[e] = valid[e] ? im.rk_anc[rank - off - 1] : uint2{1, 0};
-    }
-    uint32_t vis = 0;   // (per lane: bit l * E + e)
-#pragma unroll
-    for (uint32_t e = 0; e < E; ++e)
-      if (valid[e] && anc[e].x <= tin0 && tin0 - anc[e].x < anc[e].y) vis |= 1u << (l * E + e);
-    const uint32_t pos = kSearchWindow;   // the next window starts right below this one
     bool found = false, had_ref = false;
     uint32_t f_ref_pos = 0, f_v = 0, f_slot1 = 0;
     WalkVertex f_wc{};
-    uint64_t ev_word[E];   // the visited nodes' event words, requested together (one memory latency, not one per node)
-#pragma unroll
-    for (uint32_t e = 0; e < E; ++e) {
-      const bool visited = valid[e] && ((vis >> (l * E + e)) & 1);
-      ev_word[e] = visited ? ev.row[back[e].x >> 6] : 0ULL;
-    }
-#pragma unroll
-    for (uint32_t e = 0; e < E; ++e) {   // in chain order within the lane: the first visited node with a holder wins
-      const bool cand = !found && ((ev_word[e] >> (back[e].x & 63)) & 1);
-      if (cand) {
-        bool hr = false;
-        uint32_t rp = 0;
-        const uint32_t rb0 = im.blob_of_slot[back[e].x] + 1;   // the edge records follow the slot's header
-        for (uint32_t ed = rb0; ed < rb0 + back[e].y; ++ed) {
-          const uint4 a = im.wblob[2 * (uint64_t)ed];
-          if (a.y) { rp = a.y; hr = true; }
-          if (hold.bit(a.x)) {
-            const uint4 b = im.wblob[2 * (uint64_t)ed + 1];
-            f_v = a.x; found = true; f_slot1 = b.y;
-            f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
-          }
+    // the literal test of one visited node (query.h:75-100): its last ref neighbour, its last neighbour holding the sample
+    auto check_node = [&](uint32_t slot, uint32_t deg) {
+      bool hr = false;
+      uint32_t rp = 0;
+      const uint32_t rb0 = im.blob_of_slot[slot] + 1;   // the edge records follow the slot's header
+      for (uint32_t ed = rb0; ed < rb0 + deg; ++ed) {
+        const uint4 a = im.wblob[2 * (uint64_t)ed];
+        if (a.y) { rp = a.y; hr = true; }
+        if (hold.bit(a.x)) {
+          const uint4 b = im.wblob[2 * (uint64_t)ed + 1];
+          f_v = a.x; found = true; f_slot1 = b.y;
+          f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
         }
-        if (found) { f_ref_pos = rp; had_ref = hr; }
+      }
+      if (found) { f_ref_pos = rp; had_ref = hr; }
+    };
+    if (searching && !hop) {
+      // kSearchWindow ranks per round trip, E consecutive rank records per lane (lane l: offsets [l * E, l * E + E) below
+      // the window's top rank).  Which of them the chain from rank0 visits is an ancestor test on the static forest of
+      // chains (DevImage::rk_anc) -- no walking along the chain, every lane decides for its own ranks.
+      constexpr uint32_t E = kSearchWindow / SUB;
+      uint2 back[E], anc[E];
+      bool valid[E];
+#pragma unroll
+      for (uint32_t e = 0; e < E; ++e) {
+        const uint64_t off = (uint64_t)l * E + e;
+        valid[e] = rank >= off + 2;
+        back[e] = valid[e] ? im.rk_back[rank - off - 1] : uint2{0, 1};
+        anc[e] = valid[e] ? im.rk_anc[rank - off - 1] : uint2{1, 0};
+      }
+      uint64_t ev_word[E];   // the visited nodes' event words, requested together (one memory latency, not one per node)
+#pragma unroll
+      for (uint32_t e = 0; e < E; ++e) {
+        const bool visited = valid[e] && anc[e].x <= tin0 && tin0 - anc[e].x < anc[e].y;
+        ev_word[e] = visited ? ev.row[back[e].x >> 6] : 0ULL;
+      }
+#pragma unroll
+      for (uint32_t e = 0; e < E; ++e)   // in chain order within the lane: the first visited node with a holder wins
+        if (!found && ((ev_word[e] >> (back[e].x & 63)) & 1)) check_node(back[e].x, back[e].y);
+    }
+    if (searching && hop) {
+      // A long search (a sample with few variants): from here on it goes by the SET BITS of the sample's event row, one
+      // 64-slot word per lane and round, highest slot first.  A set bit is a candidate when its slot is the first of its
+      // rank (the only node of a rank the chain looks at) and that rank is on the chain from rank0 (ancestor labels).
+      const int64_t wi = (int64_t)(s_top >> 6) - (int64_t)l;
+      uint64_t word = wi >= 0 ? ev.row[wi] : 0ULL;
+      if (l == 0 && (s_top & 63) != 63) word &= (1ULL << ((s_top & 63) + 1)) - 1;   // nothing above s_top
+      while (word && !found) {
+        const uint32_t b = 63u - (uint32_t)__builtin_clzll(word);
+        word &= ~(1ULL << b);
+        const uint32_t k = (uint32_t)wi * 64u + b;
+        const uint32_t r = im.slot_rank[k];               // chain rank r + 1 looks at the first slot of rank r
+        if (r < 1) continue;                              // (the chain stops at rank <= 1 before it would look there)
+        const uint2 bk = im.rk_back[r];
+        if (bk.x != k) continue;
+        const uint2 an = im.rk_anc[r];
+        if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
+        check_node(k, bk.y);
       }
     }
     const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & kGroupMask);
@@ -652,7 +672,11 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
         if (!g_had_ref) serial = true;   // (ref_pos would be an earlier iteration's: the serial loop knows)
         st.cur = g_v; st.wc = g_wc; st.ref_pos = g_ref_pos; st.cur_ref_v = kNone; st.cur_slot1 = g_slot1;
         searching = false;
-      } else rank = rank > pos ? rank - pos : 0;
+      } else if (!hop) {
+        rank = rank > kSearchWindow ? rank - kSearchWindow : 0;   // the next window starts right below this one
+        if (++windows >= kHopAfter && rank > 1 && im.slot_rank) { hop = true; s_top = im.rk_back[rank - 1].x; }
+      } else if ((s_top >> 6) >= SUB) s_top = (((s_top >> 6) - SUB) << 6) | 63u;
+      else rank = 0;   // nothing left below: the head of the path
     }
   }
   t_c1 = VS_WALK_CLOCK();

@@ -103,6 +103,7 @@ struct HostImage {
   // the ranks form a forest (parent = the next rank of the chain) and "does the chain from r0 visit rank p" is "p is an
   // ancestor of r0": DFS interval labels {tin, subtree size} per chain rank, 2 words at index rank - 1 like rk_back.
   std::vector<uint32_t> rk_anc;
+  std::vector<uint32_t> slot_rank;   // [P] rank of every ref-path slot (slots of rank r: [rank_to_slot[r], rank_to_slot[r + 1]))
   std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
   std::vector<uint8_t> gt_nibbles;   // 2 carriers per byte, low nibble first
   std::vector<uint32_t> car_sid;     // explicit mode only
@@ -422,6 +423,9 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     im.rk_back[2 * r] = slot;
     if (slot < im.P) { const uint32_t v = im.rp_vid[slot]; im.rk_back[2 * r + 1] = im.row_ptr[v + 1] - im.row_ptr[v]; }
   }
+  im.slot_rank.assign(im.P, 0);
+  for (uint64_t r = 0; r < im.R; ++r)
+    for (uint64_t k = im.rank_to_slot[r]; k < im.rank_to_slot[r + 1] && k < im.P; ++k) im.slot_rank[k] = (uint32_t)r;
   {  // chain ranks 0 .. R; rank p >= 2 steps to p - max(deg, 1) with deg = out-degree of previous(p) = rk_back[p - 1]
     const uint64_t n = im.R + 1;
     auto parent = [&](uint64_t p) -> uint64_t {
