@@ -137,3 +137,21 @@ def test_handle_options_are_checked():
         vs.set_option("fill_ablate", 1)
     assert e.value.code == -7
     vs.close()
+
+
+def test_image_labels_against_brute_force(golden_dir, tmp_path):
+    """device_image.hpp's static structures for the walking query types -- ancestor labels of the backward search's
+    chains (rk_anc), slot -> rank table, break bits of the sequence queries -- against brute force, on a synthetic cohort
+    and on VCF-built graphs (edges in the reference's hash-set order), under ASan + UBSan."""
+    import subprocess
+    from helpers import write_random_cohort
+    exe = os.path.join(tmp_path, "image_labels_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "image_labels_check.cpp"), "-lz"])
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 177, n_rows=600, ref_len=9000, n_samples=30, p_ins=0.2, p_del=0.25, p_multi=0.2, p_near=0.5)
+    for args in ([], [os.path.join(golden_dir, "x.fa"), os.path.join(golden_dir, "x.vcf")], [fasta, vcf]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+        ranks, slots, tested, breaks = (int(x) for x in out.stdout.split()[1:5])
+        assert ranks > 100 and slots >= ranks and tested > 200 and breaks >= 1
+        assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
