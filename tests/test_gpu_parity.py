@@ -1018,3 +1018,13 @@ def test_type4_long_backward_searches(seed, n_samples, carrier_p, tmp_path):
             assert f5[q] & 8
         else:
             assert r5.region_text(q) == text, (q, x, y, sm)
+    for coords in (False, True):
+        flags, seqs = vs.query_sample_seq(regions, per, sample_coordinates=coords).sequences()
+        for q, ((x, y), sm) in enumerate(zip(regions, per)):
+            n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, sm)
+            if n == -1:
+                assert flags[q] & 8, (coords, q)
+            elif n == -3:
+                assert flags[q] & 2, (coords, q)
+            else:
+                assert not flags[q] and seqs[q] == seq, (coords, q, x, y, sm)

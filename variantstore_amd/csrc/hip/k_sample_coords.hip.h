@@ -105,6 +105,7 @@ __device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_
 // get_prev_vertex_with_sample as in walk_start_search<true>: ranks whose node has no out-neighbour holding the sample
 // (clear event bit) are counted down without being read; the candidate's edge records come from the walk blob, "holds
 // the sample" from the hold row, and only the vertex that is found pays the look-up of its sample-coordinate index.
+constexpr uint32_t kSerialHopAfter = 48;   // skipped ranks before a one-lane backward search goes over to the event row's set bits
 template <bool WANT_INDEX = true>   // (type 2 never reads sample_pos: no look-up of the found vertex's index)
 __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& im, uint64_t pos, uint32_t sid, BitRow& ev, BitRow& hold,
                                                                uint64_t& ref_pos, uint64_t& sample_pos) {
@@ -112,11 +113,46 @@ __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& i
   if (pos >= im.ref_length) rank = im.R - 1;
   else { const uint32_t k = rank1(im, pos); rank = k == 0 ? 0 : k - 1; }
   const uint64_t ref_pos_in = ref_pos;
+  const uint64_t rank_in = rank;
   bool jumped = false;
+  uint32_t skipped = 0;
   while (true) {
-    const uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
+    uint2 back = im.rk_back[rank == 0 ? 0 : rank - 1];
     if (rank <= 1) { const uint32_t v = im.rp_vid[back.x]; ref_pos = 1; sample_pos = im.v_ridx[v]; return v; }
-    if (!ev.bit(back.x)) { rank = rank > back.y ? rank - back.y : 0; jumped = true; continue; }
+    if (!ev.bit(back.x)) {
+      rank = rank > back.y ? rank - back.y : 0;
+      jumped = true;
+      if (++skipped < kSerialHopAfter || rank <= 1 || !im.slot_rank) continue;
+      // A long search (a sample with few variants): from here on by the SET BITS of the sample's event row, highest slot
+      // first.  A set bit is a candidate when its slot is the first of its rank (the only node of a rank the chain looks
+      // at) and that rank is on the chain from the start rank (ancestor labels, DevImage::rk_anc).
+      const uint32_t tin0 = im.rk_anc[rank_in - 1].x;
+      const uint32_t s_top = im.rk_back[rank - 1].x;
+      uint32_t hit = kNone;
+      for (int64_t wi = s_top >> 6; wi >= 0 && hit == kNone; --wi) {
+        uint64_t word = ev.row[wi];
+        if ((uint32_t)wi == (s_top >> 6) && (s_top & 63) != 63) word &= (1ULL << ((s_top & 63) + 1)) - 1;
+        while (word) {
+          const uint32_t bpos = 63u - (uint32_t)__builtin_clzll(word);
+          word &= ~(1ULL << bpos);
+          const uint32_t k = (uint32_t)wi * 64u + bpos;
+          const uint32_t r = im.slot_rank[k];
+          if (r < 1) continue;                    // (the chain stops at rank <= 1 before it would look there)
+          if (im.rk_back[r].x != k) continue;     // not the first slot of its rank
+          const uint2 an = im.rk_anc[r];
+          if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
+          // the literal test of this node; if no neighbour holds the sample the search goes on below it
+          bool f2 = false;
+          const uint32_t deg = im.rk_back[r].y, rbk = im.blob_of_slot[k] + 1;
+          for (uint32_t e = rbk; e < rbk + deg; ++e)
+            if (hold.bit(im.wblob[2 * (uint64_t)e].x)) { f2 = true; break; }
+          if (f2) { hit = r; break; }
+        }
+      }
+      if (hit == kNone) { rank = 0; continue; }   // nothing below: the head of the path
+      rank = (uint64_t)hit + 1;                    // the chain rank that looks at this node: the loop's literal test takes it from here
+      back = im.rk_back[hit];
+    }
     bool found = false, had_ref = false;
     uint32_t fv = 0, fr = 0, fc = 0;
     const uint32_t rb0 = im.blob_of_slot[back.x] + 1;   // the edge records follow the slot's header
