@@ -796,6 +796,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "avg_launch_ms": fill_ms / args.steps,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                         # what a plain streaming kernel with THIS kernel's traffic shape (2 bytes read : 3 written, non-temporal
+                         # 16-byte stores) reaches on the part: 4.7 - 5.04 TB/s (tools/microbench/mix_ceiling.hip,
+                         # profiles/r03x_mix_ceiling.txt; read-only streams 6.1 - 6.4, write-only 4.6 - 5.4, a 1:1 copy 5.0 - 5.3)
+                         "frac_of_measured_mix_ceiling_5000": achieved / 5000.0,
                          "layout": {"bytes_per_launch": fill_bytes_layout, "GBps": layout_gbps, "frac": layout_gbps / HBM_PEAK_GBPS,
                                     "note": "bytes the data layout obliges the kernel to move (DESIGN.md section 5)"},
                          "survey_formula": {"bytes_per_launch": fill_bytes_survey, "GBps": survey_gbps,
