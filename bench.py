@@ -795,7 +795,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": fill_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "avg_launch_ms": fill_ms / args.steps,
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                         "frac_of_measured_read_ceiling_6290": achieved / 6290.0,   # (a read-only stream; rounds 1-2 called it the copy ceiling)
                          # what a plain streaming kernel with THIS kernel's traffic shape (2 bytes read : 3 written, non-temporal
                          # 16-byte stores) reaches on the part: 4.7 - 5.04 TB/s (tools/microbench/mix_ceiling.hip,
                          # profiles/r03x_mix_ceiling.txt; read-only streams 6.1 - 6.4, write-only 4.6 - 5.4, a 1:1 copy 5.0 - 5.3)
