@@ -253,10 +253,12 @@ int vs_result_get_view(vs_result* r, int with_carriers, vs_result_view* view);
 int vs_result_totals(const vs_result* r, uint64_t* n_regions, uint64_t* n_variants, uint64_t* n_carriers,
                      uint64_t* n_bases);
 /* How the result lies in HBM: rows the regions report in total, rows of the variant table, arena entries in use (lists
- * padded to groups of 8), carrier lists actually expanded, and whether rows and lists are SHARED: a sorted type-6 batch
- * of overlapping regions holds one row and one carrier list per site it covers, and every region reporting the site
+ * padded to groups of 8), carrier lists actually expanded, and whether rows and lists are SHARED: a type-6 batch of
+ * overlapping regions holds one row and one carrier list per site it covers, and every region reporting the site
  * refers to them (its rows are a range of the shared table) -- the way REF / ALT are references into the sequence
- * pool.  Views, texts, digests and totals are per region and unaffected. */
+ * pool.  (A batch that is not sorted by start is sorted on the device for this and answered in the caller's order.)
+ * Views, texts, digests and totals are per region and unaffected.  With resident carrier lists ("resident_lists") a
+ * result owns no arena: arena_entries and lists_expanded are 0. */
 int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows, uint64_t* arena_entries, uint64_t* lists_expanded,
                      int* shared);
 /* The `-o` file of region q (print_header + print_var, query.h:38-50) as text owned by the result. */
@@ -285,7 +287,7 @@ void vs_result_free(vs_result* r);
  * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
  * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
  * chosen from the batch's shape); "share_lists" 0 = every region gets private rows and carrier lists even in a sorted
- * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whenever the batch is sorted; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
+ * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whether or not it pays; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
  * "async_fill" 1 = the carrier expansion of a type-6 batch runs on a second stream and the call returns while it is in
  * flight (see vs_result_fill_ms; default 0); "resident_lists" 1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
  * 4 bytes per carrier record; VS_ERR_UNSUPPORTED when that does not fit): batches of query types 6 and 4 then emit rows
