@@ -32,8 +32,9 @@ for name, ctr in raw.items():
     if short is None or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
         continue
     grid = int(name.rsplit("[grid ", 1)[1].rstrip("]"))
-    if short in kernels and kernels[short]["grid"] >= grid:
-        continue  # (a kernel that ran in several shapes: the bench batch is the largest)
+    if short in kernels and (kernels[short]["_launches"], kernels[short]["grid"]) >= (ctr["_launches"], grid):
+        continue  # (a kernel that ran in several shapes: the headline batch is the one launched most often -- warm-up, timed
+                  #  steps and the comparison legs -- and, among equals, the largest)
     fetch, write = ctr["FETCH_SIZE"] * 1024, ctr["WRITE_SIZE"] * 1024
     e = {"full_name": name, "grid": grid, "_launches": ctr["_launches"], "avg_us_under_pmc": ctr["_avg_us"], "FETCH_SIZE_KiB": ctr["FETCH_SIZE"], "WRITE_SIZE_KiB": ctr["WRITE_SIZE"],
          "traffic_bytes_per_launch": int(2 * fetch + write), "traffic_bytes_per_launch_uncorrected": int(fetch + write)}
