@@ -678,7 +678,7 @@ def test_sample_coordinate_queries_need_the_indexes(tmp_path):
 
 def test_tcga_shaped_cohort_mixed_types(tmp_path):
     """BASELINE config #5's shape at reduced scale: 10,000 samples, somatic-like sparse carriers (explicit sample ids,
-    not class bit vectors), 10 % indels; mixed query types 3 / 6 / 7 (the code's numbering) against the oracle."""
+    not class bit vectors), 10 % indels; mixed query types 3 / 6 / 7 / 4 / 5 (the code's numbering) against the oracle."""
     vs = VariantStore.synthetic(device=0, ref_length=3_000_000, num_variants=30_000, num_samples=10_000, seed=55,
                                 first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6,
                                 af_exponent=2.0, max_af=0.0004, sample_coordinates=True)
@@ -724,6 +724,27 @@ def test_tcga_shaped_cohort_mixed_types(tmp_path):
                 good += 1
         assert good > 60
         rs.close()
+    # types 4 and 5 with one carrier sample per region (explicit sample ids; a carrier has a variant every ~100 kb here:
+    # the backward searches run for thousands of ranks -- the hop phase of the cooperative and of the one-lane search)
+    sub = sorted(regions[:240])
+    per = [carriers[i % len(carriers)] for i in range(len(sub))]
+    want4 = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(sub, per)]
+    for coop in (8, 16, 0):
+        vs.set_option("t4_coop", coop)
+        r4 = vs.get_sample_var_in_ref(sub, per)
+        for q, (n, _, text) in enumerate(want4):
+            if n >= 0:
+                assert r4.region_text(q) == text, (coop, q, sub[q], per[q])
+        r4.close()
+    vs.set_option("t4_coop", 8)
+    r5 = vs.get_sample_var_in_sample(sub, per)
+    f5 = r5.view(False)["region_flags"]
+    for q, ((x, y), sm) in enumerate(zip(sub, per)):
+        n, text = orc.get_sample_var_in_sample(x, y, sm)
+        if n == -1:
+            assert f5[q] & 8
+        else:
+            assert r5.region_text(q) == text, (q, x, y, sm)
 
 
 def test_saved_and_reloaded_index_answers_identically(tmp_path):
