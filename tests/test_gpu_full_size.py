@@ -177,7 +177,6 @@ def test_shared_and_private_carrier_lists_agree_at_full_size(big):
     """The bench batch both ways: one list per covered site shared by the regions that report it (the default for a
     sorted batch) against a private copy per region -- same digest, totals and rows; a quarter of the lists."""
     vs, regions = big
-    vs.set_option("share_lists", 2)   # (the handle is this module's: an earlier batch of short regions may have told it that sharing does not pay)
     shared = vs.get_var_in_ref(regions)
     slots, table, arena, lists, is_shared = shared.layout()
     assert is_shared and slots > 15_000_000 and 4_000_000 < lists <= table < 5_100_000
@@ -202,7 +201,6 @@ def test_unsorted_and_resident_forms_agree_at_full_size(big):
     back in the caller's order), and both again over resident carrier lists (nothing expanded): same totals, the same
     per-region counts and texts, digests equal where the region order is."""
     vs, regions = big
-    vs.set_option("share_lists", 2)
     try:
         base = vs.get_var_in_ref(regions)
         tb, db = base.totals(), base.digest()

@@ -51,7 +51,6 @@ def test_type6_over_resident_lists(seed, kw, tmp_path):
     L = vs.info().ref_length
     regions = random_regions(rng, L, 400, max_len=900)
     batches = {"unsorted": regions, "sorted": sorted(regions)}
-    vs.set_option("share_lists", 2)   # (sorted batches share their rows whether or not it pays: the same form before and after)
     before = {k: vs.get_var_in_ref(b) for k, b in batches.items()}
     vs.set_option("resident_lists", 1)
     for k, b in batches.items():

@@ -1,0 +1,35 @@
+"""A/B of the shared type-6 batch forms on the bench workload: per-phase times by HIP events and wall per step."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from variantstore_amd import VariantStore
+w = bench.WORKLOADS[os.environ.get("WL", "chr1-2504")]
+vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
+nreg = int(os.environ.get("NREG", w["regions"]))
+regions = bench.make_regions(w, 0, nreg)
+dev = torch.from_numpy(regions.astype(np.int64)).cuda()
+def run(label, opts, steps=30):
+    for k, v in opts.items():
+        vs.set_option(k, v)
+    for _ in range(3):
+        vs.get_var_in_ref_device(dev.data_ptr(), nreg).close()
+    torch.cuda.synchronize()
+    acc = np.zeros(5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
+        t = vs.last_timing()
+        acc += (t.ms_total, t.ms_bounds, t.ms_scan, t.ms_emit, t.ms_fill)
+        r.close()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
+    dg = r.digest()
+    r.close()
+    a = acc / steps
+    print(f"{label:28s} wall {dt:.4f} ms  stream {a[0]:.4f} = plan {a[1]:.4f} + host {a[2]:.4f} + rows {a[3]:.4f} + fill {a[4]:.4f}   {nreg/dt/1e3:.1f} M/s  digest {dg:016x}", flush=True)
+for label, opts in [("fused16", dict(fill_fused=1, fill_chunk=16)), ("unfused16", dict(fill_fused=0, fill_chunk=16)),
+                    ("fused32", dict(fill_fused=1, fill_chunk=32)), ("fused64", dict(fill_fused=1, fill_chunk=64)),
+                    ("fused8", dict(fill_fused=1, fill_chunk=8)), ("unfused16 again", dict(fill_fused=0, fill_chunk=16)), ("fused16 again", dict(fill_fused=1, fill_chunk=16))]:
+    run(label, opts)

@@ -66,7 +66,8 @@ struct EngineOpts {
                                 // in flight (every accessor of the result waits for it): the next batch's bounds, scans and rows
                                 // run beside it
   bool resident_lists = false;  // carrier lists expanded once into an arena that stays with the index (build_resident_lists): results hold rows only
-  int share_lists = 1;      // sorted type-6 batches: one carrier list per covered site, shared by the regions that report it
+  bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
+  bool share_lists = true;      // type-6 batches: one row and one carrier list per covered site, shared by the regions that report it
   uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
   bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
   uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
@@ -91,9 +92,8 @@ struct vs_index {
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
   bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
   uint32_t sort_probe_in = 0;
-  int share_hint = -1;                      // did sharing pay on the last shared batch (-1: not known yet)
-  uint32_t share_probe_in = 0;              // private batches until sharing is tried again
-  uint64_t share_seq = 0;                   // sequence number of the share scans' totals mailbox
+  uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
+  uint64_t done_seq = 0;                    // sequence number of the batch completion word
   // resident carrier lists (DevImage::v_abegin): the arena, its length in entries, and -- once a caller has asked for
   // carriers on the host -- its page-locked host mirror, shared by every result of the handle
   void* res_arena = nullptr;
@@ -123,7 +123,9 @@ struct vs_index {
   static constexpr size_t kPinFlag = 6;       // latency path: completion sequence number
   static constexpr size_t kPinSrvResp = 16;   // [16..20] resident server: sequence number of the last request answered (+ debug stamps)
   static constexpr size_t kPinSrvReq = 256;   // [256 .. 256 + 136) resident server: the request (ServerRequest, 64-byte aligned)
-  static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path: slots and arena entries of the batch
+  static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path, private rows: slots and arena entries of the batch
+  static constexpr size_t kPinPlan = 1056;    // [1056..1062] throughput path, shared rows: PlanTotals of the batch (k_t6_apply), sequence word last
+  static constexpr size_t kPinDone = 1072;    // completion word of a batch (k_post_done)
 };
 
 struct vs_result {
@@ -425,6 +427,13 @@ static int build_device_image(vs_index* idx) {
       HIP_TRY(hipGetLastError());
       d.rp_carpre = rc; d.rp_kpre = rk;
     }
+    {
+      VariantRow* rows = nullptr;
+      VS_TRY(alloc_image(idx, G, &rows));
+      if (G) hipLaunchKernelGGL(k_build_site_rows, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, d, rows);
+      HIP_TRY(hipGetLastError());
+      d.s_row = rows;
+    }
     idx->h_carpre.resize(G + 1);
     HIP_TRY(hipMemcpyAsync(idx->h_carpre.data(), d.s_carpre, (G + 1) * 8, hipMemcpyDeviceToHost, idx->stream));
   }
@@ -497,7 +506,7 @@ static void read_env_opts(vs_index* idx) {
   o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
   o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
   if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
-  if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = 0;
+  if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = false;
   o.async_fill = getenv("VS_ASYNC_FILL") != nullptr;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
@@ -714,12 +723,250 @@ static int ensure_resident_mirror(vs_index* idx) {
   return VS_OK;
 }
 
+// Spin on a word in mapped host memory until the device has posted `seq` (the runtime's completion wait costs tens of
+// microseconds more); a kernel that never posts -- a fault -- is caught by the synchronisation after the deadline.
+static int wait_posted(vs_index* idx, volatile uint64_t* word, uint64_t seq, int deadline_ms) {
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(deadline_ms);
+  bool posted = false;
+  uint32_t spins = 0;
+  while (!(posted = (*word == seq))) {
+    __builtin_ia32_pause();
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > deadline) break;
+  }
+  if (!posted) {
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (*word != seq) return fail(VS_ERR_INTERNAL, "a batch kernel finished without posting its sequence word");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return VS_OK;
+}
+
+// The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).
+template <bool WIDE, bool TUNE>
+static void launch_fill2(vs_index* idx, const DevResult& d, const uint64_t* u_begin, const RowDelta* delta, uint64_t U, uint32_t chunk, size_t lds_bytes,
+                         uint32_t ablate, uint32_t gt_words) {
+  const unsigned blocks = (unsigned)(((U + chunk - 1) / chunk + 3) / 4);
+  switch (chunk) {
+    case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
+  }
+}
+
+// Query type 6 over a batch whose regions SHARE rows and carrier lists (every batch of more than 64 regions unless
+// option share_lists is 0).  Stages, each reading only what the stage before it left:
+//   plan   k_t6_bounds / _mid / _apply: bounds, E_prev, the per-region arrays, the row deltas, the slow-region list;
+//          the totals arrive in mapped host memory and the host spins on their sequence word (the one host wait of a batch)
+//   (sort  a batch that turns out not to be sorted by first site is sorted on the device and planned again)
+//   rows   k_t6_slow (private copies + the literal duplicate rule, only when the plan counted such regions)
+//   fill   k_fill_sites2: the shared rows AND their carrier lists, one launch; with resident lists k_share_rows2 alone;
+//          with async_fill k_share_rows2 here and k_fill_sites on the second stream
+//   done   k_post_done: a word in mapped host memory, the host spins on it
+static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
+                            bool allow_async) {
+  if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
+  DevResult& d = r->d;
+  d.Q = n;
+  uint64_t* dreg = nullptr;
+  VS_TRY(ralloc(r, 2 * n, &dreg));
+  d.regions = dreg;
+  VS_TRY(ralloc(r, n, &d.q_flags));
+  VS_TRY(ralloc(r, n, &d.q_g0));
+  VS_TRY(ralloc(r, n, &d.q_nvar));
+  VS_TRY(ralloc(r, n, &d.q_ncar));
+  VS_TRY(ralloc(r, n + 1, &d.var_begin));
+  VS_TRY(ralloc(r, n + 1, &d.car_base));
+  VS_TRY(ralloc(r, n, &d.var_count));
+  VS_TRY(ralloc(r, n, &d.q_car_len));
+  if (regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
+  else HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  ScratchBufs scratch(idx);
+  const bool resident = idx->opts.resident_lists && idx->res_arena;
+  // ---- plan ----
+  const uint32_t items = (uint32_t)((n + (uint64_t)kPlanBlock * kPlanMaxTiles - 1) / ((uint64_t)kPlanBlock * kPlanMaxTiles));
+  const uint32_t ntiles = (uint32_t)((n + (uint64_t)kPlanBlock * items - 1) / ((uint64_t)kPlanBlock * items));
+  ShareMax* tile_max = nullptr;
+  Scan5* tile_sums = nullptr;
+  uint32_t *e_prev = nullptr, *status = nullptr, *slow_list = nullptr;
+  uint64_t* u_begin = nullptr;
+  RowDelta* delta = nullptr;
+  VS_TRY(dev_alloc(idx, ntiles * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, ntiles * sizeof(Scan5), (void**)&tile_sums, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, n * 4, (void**)&slow_list, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&u_begin, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, n * sizeof(RowDelta), (void**)&delta, &scratch.bufs));
+  PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
+  auto launch_bounds = [&](int src) {
+    if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
+    else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, site_records, items, tile_max);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
+  };
+  // the plan over the regions as they stand in `d`; the totals arrive in mapped host memory
+  auto plan = [&](int src) -> int {
+    HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
+    launch_bounds(src);
+    hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
+    const uint64_t seq = ++idx->share_seq;
+    if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+                                     ntiles, items, u_begin, delta, slow_list, pt, (const uint32_t*)status, seq, idx->res_entries);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+                            ntiles, items, u_begin, delta, slow_list, pt, (const uint32_t*)status, seq, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    return wait_posted(idx, &pt->seq, seq, 200);
+  };
+  // A batch that is not sorted by first site: counting sort of the regions over the site index (k_sort_*), the batch
+  // then works on sorted copies of its per-region arrays (`d` points at them from here on, `d_user` keeps the
+  // caller's) and k_permute_out hands the outcome back at the end.
+  DevResult d_user{};        // the caller's per-region arrays while an unsorted batch works on sorted copies
+  uint32_t* perm = nullptr;  // sorted position -> region of the caller's batch (NULL: the batch is worked in the order given)
+  auto sort_batch = [&]() -> int {
+    const uint64_t G = idx->d.G;
+    uint32_t* count = nullptr;
+    unsigned long long* cursor = nullptr;
+    VS_TRY(dev_alloc(idx, (G + 2) * 4, (void**)&count, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (G + 2) * 8, (void**)&cursor, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 4, (void**)&perm, &scratch.bufs));
+    HIP_TRY(hipMemsetAsync(count, 0, (G + 1) * 4, idx->stream));
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, count);
+    VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)count, G + 1, (uint64_t*)cursor, &scratch.bufs));
+    hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, cursor, perm);
+    d_user = d;
+    uint64_t* sregions = nullptr;
+    VS_TRY(dev_alloc(idx, 2 * n * 8, (void**)&sregions, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n, (void**)&d.q_flags, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 4, (void**)&d.q_g0, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_nvar, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_ncar, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.var_begin, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.car_base, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_car_len, &scratch.bufs));
+    VS_TRY(dev_alloc(idx, n * 8, (void**)&d.var_count, &scratch.bufs));
+    hipLaunchKernelGGL(k_permute_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d_user, d, (const uint32_t*)perm, sregions);
+    d.regions = sregions;
+    HIP_TRY(hipGetLastError());
+    return VS_OK;
+  };
+  const int src = site_records ? 1 : 0;
+  // (a handle whose last batch needed sorting sorts first; it looks at the order as given again every 32nd batch)
+  if (idx->sort_hint && idx->sort_probe_in > 0) {
+    --idx->sort_probe_in;
+    launch_bounds(src);
+    VS_TRY(sort_batch());
+    VS_TRY(plan(2));
+  } else {
+    VS_TRY(plan(src));
+    if (pt->not_sorted) {
+      VS_TRY(sort_batch());
+      VS_TRY(plan(2));
+      idx->sort_hint = true; idx->sort_probe_in = 32;
+    } else idx->sort_hint = false;
+  }
+  if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
+  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  const uint64_t U = pt->shared_rows, n_slow = pt->n_slow;
+  d.A = pt->rows;
+  d.S = pt->arena;
+  r->n_rows_reported = pt->reported;
+  r->shared_lists = true;
+  r->resident = resident;
+  r->scattered_lists = false;
+  r->n_unique_sites = resident ? 0 : U;
+  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  VS_TRY(ralloc(r, d.A, &d.rows));
+  if (resident) d.carriers = idx->res_arena;
+  else {
+    uint8_t* arena = nullptr;
+    VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
+    d.carriers = arena;
+  }
+  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  // ---- rows of the regions under the duplicate rule ----
+  if (n_slow) {
+    const uint64_t waves = std::min<uint64_t>(n_slow, 16384);
+    hipLaunchKernelGGL(k_t6_slow, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)slow_list, n_slow);
+  }
+  // ---- shared rows + carrier lists ----
+  const uint64_t n_fill = resident ? 0 : U;
+  const bool async_fill = allow_async && idx->opts.async_fill && n_fill > 0;
+  uint32_t* u_site = nullptr;
+  const bool fused = idx->opts.fill_fused && !resident && !async_fill;
+  if (U && !fused) {
+    if (!resident) VS_TRY(dev_alloc(idx, U * 4 + 8, (void**)&u_site, &scratch.bufs));
+    hipLaunchKernelGGL(k_share_rows2, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint64_t*)u_begin, (const RowDelta*)delta, U, u_site);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  if (async_fill) {
+    // the expansion goes to the handle's second stream behind an event and the call returns once the FIRST stream is done
+    // (rows, per-region arrays); the next batch's plan and rows then run beside it.  The call's temporaries (the site
+    // index the expansion reads) stay with the result until it is freed.
+    VS_TRY(ensure_fill_stream(idx));
+    for (auto& e : r->ev_fill) if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
+    HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
+    HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
+    VS_TRY(fill_lists(idx, d, true, u_site, n_fill, idx->fill_stream));
+    HIP_TRY(hipEventRecord(r->ev_fill[1], idx->fill_stream));
+    r->pending = true;
+  } else if (n_fill && !fused) {
+    VS_TRY(fill_lists(idx, d, true, u_site, n_fill));
+  } else if (n_fill) {
+    uint32_t chunk = idx->opts.fill_chunk ? idx->opts.fill_chunk : 16;
+    const uint32_t gt_words = fill_gt_words(idx);
+#ifdef VS_TUNING
+    const size_t lds_bytes = fill_lds_bytes(idx) + std::min<size_t>(idx->opts.fill_lds_pad, 96 << 10);
+    const uint32_t ablate = idx->opts.fill_ablate;
+    constexpr bool kTune = true;
+#else
+    const size_t lds_bytes = fill_lds_bytes(idx);
+    const uint32_t ablate = 0;
+    constexpr bool kTune = false;
+#endif
+    if ((U + chunk - 1) / chunk / 4 > 0x7FFFFFF0ull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu shared rows)", (unsigned long long)U);
+    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, u_begin, delta, U, chunk, lds_bytes, ablate, gt_words);
+    else launch_fill2<false, kTune>(idx, d, u_begin, delta, U, chunk, lds_bytes, ablate, gt_words);
+    HIP_TRY(hipGetLastError());
+  }
+  if (perm) {   // every region's outcome back to its place in the caller's order (rows and lists are shared: nothing else moves)
+    const DevResult ds = d;
+    d.regions = d_user.regions; d.q_flags = d_user.q_flags; d.q_g0 = d_user.q_g0; d.q_nvar = d_user.q_nvar; d.q_ncar = d_user.q_ncar;
+    d.var_begin = d_user.var_begin; d.car_base = d_user.car_base; d.q_car_len = d_user.q_car_len; d.var_count = d_user.var_count;
+    hipLaunchKernelGGL(k_permute_out, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, ds, d, (const uint32_t*)perm);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  {
+    uint64_t* done = idx->pinned + vs_index::kPinDone;
+    const uint64_t seq = ++idx->done_seq;
+    hipLaunchKernelGGL(k_post_done, dim3(1), dim3(1), 0, idx->stream, done, seq);
+    HIP_TRY(hipGetLastError());
+    VS_TRY(wait_posted(idx, done, seq, 2000));
+  }
+  if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
+  scratch.release();
+  vs_timing& t = idx->timing;
+  HIP_TRY(hipEventSynchronize(idx->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  t.fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
+  return VS_OK;
+}
+
 // sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
 // point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
 static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
                           const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
                           int walk_mode = 4, bool regions_on_device = false, const uint64_t* site_records = nullptr, bool allow_async = false) {
   const bool t4 = sample_id != kNone || sample_ids != nullptr;
+  // query type 6 over more than 64 regions: rows and carrier lists shared between the regions of the batch
+  if (!t4 && !point_mode && idx->opts.share_lists && n > 64) return run_type6_shared(idx, regions, n, r, regions_on_device, site_records, allow_async);
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
   uint32_t* dsids = nullptr;
   DevResult& d = r->d;
@@ -810,125 +1057,14 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
   // Resident carrier lists: the rows point into the index's arena; nothing is expanded, the result owns no arena.
   bool resident = idx->opts.resident_lists && idx->res_arena && !point_mode && !(t4 && !single_walk);
-  // Shared carrier lists (kernels.hip.h: k_share_*): a sorted type-6 batch expands every site it covers once and lets
-  // all regions that report the site point at that one list.  Not for batches the latency path would take anyway.
-  // Sharing pays when the batch's regions overlap (its price: two more scans over the regions); whether they do is known
-  // only afterwards, so the handle remembers: a shared batch whose table came out nearly as long as the rows it stands
-  // for (> 80 %) sends the following batches down the private path, which looks again every 32nd batch.
-  // share_lists = 2 shares whenever the batch is sorted.
-  bool share = !t4 && !point_mode && idx->opts.share_lists && n > 64;
-  if (share && idx->opts.share_lists == 1 && idx->share_hint == 0) {
-    if (idx->share_probe_in > 0) { --idx->share_probe_in; share = false; }
-  }
-  uint32_t* sh_new_start = nullptr;
-  uint64_t *sh_u_begin = nullptr, *sh_arena_new = nullptr;
-  DevResult d_user{};        // the caller's per-region arrays while an unsorted batch works on sorted copies
-  uint32_t* perm = nullptr;  // sorted position -> region of the caller's batch (NULL: the batch is worked in the order given)
-  uint64_t n_unique = 0;
-  if (share) {
-    const uint64_t ntiles = (n + kShareTile - 1) / kShareTile;
-    ShareMax* tile_max = nullptr;
-    Scan4* tile_sums = nullptr;
-    uint32_t *e_prev = nullptr, *status = nullptr;
-    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan4), (void**)&tile_sums, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, n * 4, (void**)&sh_new_start, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_u_begin, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&sh_arena_new, &scratch.bufs));
-    VS_TRY(ralloc(r, n, &d.q_car_len));
-    // the two scans over the regions as they stand in `d`; the sizes arrive in mapped host memory
-    auto share_scans = [&]() -> int {
-      HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
-      hipLaunchKernelGGL(k_share_tile_max, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, d, tile_max);
-      hipLaunchKernelGGL(k_share_spine_max, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_max, ntiles);
-      hipLaunchKernelGGL(k_share_mid, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, e_prev, tile_sums, status);
-      const uint64_t share_seq = ++idx->share_seq;
-      hipLaunchKernelGGL(k_share_spine_sum, dim3(1), dim3(kScanBlock), 0, idx->stream, tile_sums, ntiles, d, sh_u_begin, pin_totals, (const uint32_t*)status,
-                         share_seq);
-      HIP_TRY(hipGetLastError());
-      // spin on the sequence word (the runtime's completion wait costs tens of microseconds more); a kernel that never
-      // posts -- a fault -- is caught by the synchronisation after the deadline
-      volatile uint64_t* seqw = pin_totals + 5;
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
-      bool posted = false;
-      while (!(posted = (*seqw == share_seq))) {
-        __builtin_ia32_pause();
-        if (std::chrono::steady_clock::now() > deadline) break;
-      }
-      if (!posted) HIP_TRY(hipStreamSynchronize(idx->stream));
-      std::atomic_thread_fence(std::memory_order_acquire);
-      return VS_OK;
-    };
-    // A batch that is not sorted by first site: counting sort of the regions over the site index (k_sort_*), the batch
-    // then works on sorted copies of its per-region arrays (`d` points at them from here on, `d_user` keeps the
-    // caller's) and k_permute_out hands the outcome back at the end.
-    auto sort_batch = [&]() -> int {
-      const uint64_t G = idx->d.G;
-      uint32_t* count = nullptr;
-      unsigned long long* cursor = nullptr;
-      VS_TRY(dev_alloc(idx, (G + 2) * 4, (void**)&count, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, (G + 2) * 8, (void**)&cursor, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 4, (void**)&perm, &scratch.bufs));
-      HIP_TRY(hipMemsetAsync(count, 0, (G + 1) * 4, idx->stream));
-      hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, count);
-      VS_TRY(exclusive_scan<uint32_t>(idx, (const uint32_t*)count, G + 1, (uint64_t*)cursor, &scratch.bufs));
-      hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, cursor, perm);
-      d_user = d;
-      uint64_t* sregions = nullptr;
-      VS_TRY(dev_alloc(idx, 2 * n * 8, (void**)&sregions, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n, (void**)&d.q_flags, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 4, (void**)&d.q_g0, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_nvar, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_ncar, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.var_begin, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&d.car_base, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.q_car_len, &scratch.bufs));
-      VS_TRY(dev_alloc(idx, n * 8, (void**)&d.var_count, &scratch.bufs));
-      hipLaunchKernelGGL(k_permute_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d_user, d, (const uint32_t*)perm, sregions);
-      d.regions = sregions;
-      HIP_TRY(hipGetLastError());
-      return VS_OK;
-    };
-    // (a handle whose last shared batch needed sorting sorts first; it looks at the order as given again every 32nd batch)
-    if (idx->sort_hint && idx->sort_probe_in > 0) { --idx->sort_probe_in; VS_TRY(sort_batch()); }
-    VS_TRY(share_scans());
-    if (((volatile uint64_t*)pin_totals)[3] && !perm) {   // not sorted by first site
-      VS_TRY(sort_batch());
-      VS_TRY(share_scans());
-      idx->sort_hint = true; idx->sort_probe_in = 32;
-    } else if (!perm) idx->sort_hint = false;
-    totals[0] = ((volatile uint64_t*)pin_totals)[0];
-    totals[1] = ((volatile uint64_t*)pin_totals)[1];
-    n_unique = ((volatile uint64_t*)pin_totals)[2];
-    r->n_rows_reported = ((volatile uint64_t*)pin_totals)[4];
-    if (((volatile uint64_t*)pin_totals)[3]) {   // (cannot happen after the sort; kept as the safe way out)
-      share = false;
-      if (perm) { d = d_user; perm = nullptr; }
-      d.q_car_len = nullptr;
-    }
-    else {   // (only now: it overwrites the per-region counts the private path scans)
-      idx->share_hint = totals[0] * 5 <= r->n_rows_reported * 4 ? 1 : 0;
-      if (!idx->share_hint) idx->share_probe_in = 32;
-      hipLaunchKernelGGL(k_share_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan4*)tile_sums,
-                         sh_new_start, sh_u_begin, sh_arena_new);
-      if (resident) {
-        hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start, sh_arena_new, idx->res_entries);
-        totals[1] = idx->res_entries;
-      }
-      HIP_TRY(hipGetLastError());
-    }
-  }
   ListClaims lc{};
   bool share_t4 = false;   // type 4, recording walk: one carrier list per reported VERTEX, shared by the rows that report it
   uint64_t t4_arena = 0;
-  if (!share) {
   VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
   if (resident && !t4) {
     VS_TRY(ralloc(r, n, &d.q_car_len));   // (before the header kernels overwrite q_ncar with the reported carriers)
-    hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)nullptr, (uint64_t*)nullptr, idx->res_entries);
+    hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, idx->res_entries);
   }
   if (single_walk && idx->opts.share_lists && n > 64 && !resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
@@ -955,7 +1091,6 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   totals[1] = ((volatile uint64_t*)pin_totals)[1];
   if (share_t4 && !walk_overflow) totals[1] = t4_arena;
   if (resident && !(single_walk && walk_overflow)) totals[1] = idx->res_entries;
-  }
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     share_t4 = false;
@@ -970,17 +1105,15 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   d.A = totals[0];
   d.S = totals[1];
   VS_TRY(ralloc(r, d.A, &d.rows));
-  if (!share) {   // row parameters of k_fill_carriers (shared lists are expanded from the site table)
-    if (!resident) {
-      VS_TRY(ralloc(r, d.A, &d.r_class));
-      VS_TRY(ralloc(r, d.A, &d.r_gt0));
-    }
-    r->n_rows_reported = d.A;
+  if (!resident) {   // row parameters of k_fill_carriers
+    VS_TRY(ralloc(r, d.A, &d.r_class));
+    VS_TRY(ralloc(r, d.A, &d.r_gt0));
   }
-  r->shared_lists = share || share_t4;
+  r->n_rows_reported = d.A;
+  r->shared_lists = share_t4;
   r->resident = resident;
   r->scattered_lists = share_t4 || (resident && t4);   // a region's lists are not one arena range: texts come from a raw copy
-  r->n_unique_sites = resident ? 0 : (share ? n_unique : d.A);
+  r->n_unique_sites = resident ? 0 : d.A;
   d.car_width = idx->d.wpc <= 63 ? 2 : 4;
   if (resident) d.carriers = idx->res_arena;
   else {
@@ -989,7 +1122,6 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     d.carriers = arena;
   }
   HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
-  uint32_t* u_site = nullptr;
   if (n) {
     if (t4 && single_walk && walk_mode == 5 && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (t4 && single_walk && walk_mode == 5 && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
@@ -1000,11 +1132,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
     else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
     else {
-      if (share) {   // the shared rows (each covered site once) + the site index the expansion works from
-        VS_TRY(dev_alloc(idx, n_unique * 4 + 8, (void**)&u_site, &scratch.bufs));
-        hipLaunchKernelGGL(k_share_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)sh_new_start,
-                           (const uint64_t*)sh_u_begin, (const uint64_t*)sh_arena_new, u_site);
-      } else if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+      if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
       hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
       if (strings) {
@@ -1022,7 +1150,7 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
-  const uint64_t n_fill = resident ? 0 : (share ? n_unique : d.A);   // lists to expand: shared rows resp. all rows; none with resident lists
+  const uint64_t n_fill = resident ? 0 : d.A;   // lists to expand: every row; none with resident lists
   // async_fill: the expansion goes to the handle's second stream behind an event and the call returns once the FIRST
   // stream is done (rows, per-region arrays); the next batch's bounds, scans and rows then run beside it.  The call's
   // temporaries (the site index the expansion reads) stay with the result until it is freed.
@@ -1033,17 +1161,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
     HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
     HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
-    VS_TRY(fill_lists(idx, d, share, u_site, n_fill, idx->fill_stream));
+    VS_TRY(fill_lists(idx, d, false, nullptr, n_fill, idx->fill_stream));
     HIP_TRY(hipEventRecord(r->ev_fill[1], idx->fill_stream));
     r->pending = true;
-  } else VS_TRY(fill_lists(idx, d, share, u_site, n_fill));
-  if (perm) {   // every region's outcome back to its place in the caller's order (rows and lists are shared: nothing else moves)
-    const DevResult ds = d;
-    d.regions = d_user.regions; d.q_flags = d_user.q_flags; d.q_g0 = d_user.q_g0; d.q_nvar = d_user.q_nvar; d.q_ncar = d_user.q_ncar;
-    d.var_begin = d_user.var_begin; d.car_base = d_user.car_base; d.q_car_len = d_user.q_car_len; d.var_count = d_user.var_count;
-    hipLaunchKernelGGL(k_permute_out, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, ds, d, (const uint32_t*)perm);
-    HIP_TRY(hipGetLastError());
-  }
+  } else VS_TRY(fill_lists(idx, d, false, nullptr, n_fill));
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
@@ -1656,8 +1777,8 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_skip") o.t4_skip = value != 0;
   else if (k == "t4_coop") o.t4_coop = value == 16 ? 16 : (value ? 8 : 0);
   else if (k == "share_lists") {
-    if (value < 0 || value > 2) return fail(VS_ERR_ARG, "share_lists takes 0 (never), 1 (when it pays, default) or 2 (whenever the batch is sorted)");
-    o.share_lists = (int)value; idx->share_hint = -1; idx->share_probe_in = 0;
+    if (value < 0 || value > 1) return fail(VS_ERR_ARG, "share_lists takes 0 (private rows and lists per region) or 1 (shared, default)");
+    o.share_lists = value != 0;
   }
   else if (k == "resident_lists") {
     if (value != 0 && value != 1) return fail(VS_ERR_ARG, "resident_lists takes 0 or 1");
@@ -1665,6 +1786,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     o.resident_lists = value != 0;
   }
   else if (k == "async_fill") o.async_fill = value != 0;
+  else if (k == "fill_fused") o.fill_fused = value != 0;
   else if (k == "fill_split") o.fill_split = value != 0;
   else if (k == "fill_chunk") {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
@@ -2114,7 +2236,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
   else if (r->raw_rows) rows = r->raw_rows + a0;
   else {
     VS_TRY(fetch(idx, r->sl_rows, (const VariantRow*)r->d.rows + a0, (size_t)(a1 - a0)));
-    if (a1 == a0) HIP_TRY(hipStreamSynchronize(idx->stream));   // (fetch_carriers below synchronises otherwise)
+    HIP_TRY(hipStreamSynchronize(idx->stream));   // the rows are read below whether or not any carrier is fetched
     rows = r->sl_rows.data();
   }
   const uint64_t vbase = r->have_headers ? r->h_view_begin[q] : 0;   // slot of the region's first row in the view

@@ -581,4 +581,40 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, co
   }
 }
 
+// Round 4: the same expansion WRITES the shared rows as well (k_share_rows2's work, on the 16 lanes that fetch the task's
+// parameters anyway): the wave finds the region that owns its first row (shared_row_region), a lane turns its row
+// number into a site with that region's deltas, copies the static site row with the list offset rebased, and takes
+// count / source handle / genotype offset of the same site for the expansion.  No row kernel, no site index written
+// and read back, no second read of the rows.
+template <bool WIDE, uint32_t CH, bool TUNE>
+__global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, const uint64_t* __restrict__ u_begin, const RowDelta* __restrict__ delta, uint64_t U,
+                                                     uint32_t ablate, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  const uint64_t u_first = wave * CH;
+  if (u_first < U) {
+    const uint64_t q = shared_row_region(u_begin, r.Q, u_first, lane, lane < CH ? lane : 0u);
+    const uint64_t u = u_first + lane;
+    uint32_t cnt = 0, cls = 0;
+    uint64_t gt0 = 0, cb = 0;
+    if (u < U && lane < CH) {
+      const RowDelta d = delta[q];
+      const uint32_t g = (uint32_t)(u + d.dg);
+      const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
+      const uint4 x = src[0];
+      uint4 y = src[1];
+      cls = im.s_class[g];
+      gt0 = im.s_gt0[g];
+      cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
+      y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
+      uint4* dst = reinterpret_cast<uint4*>(r.rows + u);
+      dst[0] = x; dst[1] = y;
+      cnt = y.y & ~kRowDropped;
+    }
+    expand_task<WIDE, false, TUNE, 0>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+  }
+}
+
 }  // namespace vsamd

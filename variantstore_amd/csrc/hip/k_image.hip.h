@@ -13,6 +13,7 @@ constexpr uint32_t kSiteAlwaysDrop = 2;  // branch the reference would emit with
 constexpr uint32_t kVarDropped = 1;
 constexpr uint8_t kRegionEmpty = 1, kRegionInvalid = 2, kRegionNotFound = 4, kRegionEndless = 8, kRegionSlow = 128;
 
+struct VariantRow;
 struct DevImage {
   uint64_t ref_length, nbits;
   uint32_t num_samples, wpc, use_bv, pad_;
@@ -43,6 +44,7 @@ struct DevImage {
   uint64_t* s_carpre;  // [G+1] exclusive prefix of pad_car(s_ncar): arena offsets relative to a region's first site
   uint64_t* s_kpre;    // [G+1] exclusive prefix of s_ncar itself: carriers of the variants a site range reports
   uint64_t* s_gt0;     // [G] carrier-pool index of the branch's first carrier
+  const struct VariantRow* s_row;   // [G] the site as a 32-byte row of the variant table with car_begin = s_carpre[g] (k_build_site_rows)
   const uint32_t* sus_g;     // sorted site indexes that can trigger the dedup rule
   const uint32_t* sus_prev;  // nearest earlier equal site, kNone = always dropped
   const uint32_t* rp_sus_prefix;  // [P+1] suspicious sites before each ref-path slot's first site (no bisection per query)

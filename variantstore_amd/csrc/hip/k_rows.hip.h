@@ -15,15 +15,19 @@ template <bool PARAMS>
 __device__ __forceinline__ void emit_region(const DevImage& im, const DevResult& r, uint64_t q, uint32_t lane) {
   const uint64_t n = r.q_nvar[q], a0 = r.var_begin[q], cb = r.car_base[q];
   const uint32_t g0 = r.q_g0[q];
-  const uint64_t pre0 = im.s_carpre[g0];
+  const uint64_t rebase = cb - im.s_carpre[g0];   // a static site row carries s_carpre[g] as its list offset
   uint32_t kept = 0;
   for (uint64_t j = lane; j < n; j += 64) {
     const uint64_t a = a0 + j;
     const uint32_t g = g0 + (uint32_t)j;
-    const uint32_t cnt = im.s_ncar[g];
-    kept += cnt;
-    row_store(r.rows, a, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], cnt,
-              (im.s_flags[g] & kSiteAlwaysDrop) != 0, cb + (im.s_carpre[g] - pre0));
+    const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);   // one 32-byte record per site (round 3: eight SoA reads)
+    const uint4 x = src[0];
+    uint4 y = src[1];
+    kept += y.y & ~kRowDropped;
+    const uint64_t at = (((uint64_t)y.w << 32) | y.z) + rebase;
+    y.z = (uint32_t)at; y.w = (uint32_t)(at >> 32);
+    uint4* dst = reinterpret_cast<uint4*>(r.rows + a);
+    dst[0] = x; dst[1] = y;
     if (PARAMS) {
       r.r_class[a] = im.s_class[g];
       r.r_gt0[a] = im.s_gt0[g];
@@ -51,15 +55,25 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 //   car_base[q] = arena position of site g0 = arena_new[q] - (carpre[E_prev] - carpre[g0]) when g0 lies in covered
 //                 ground (sites [g0, E_prev) are contiguous there: the region that reached E_prev starts at or before g0)
 // so a row's carrier offset keeps its form car_base[q] + carpre[g] - carpre[g0].  Needs g0 ascending over the
-// regions with any site; a batch that is not reports so (status) and takes the private-list path.
+// regions with any site; a batch that is not reports so (PlanTotals::not_sorted) and is sorted on the device first.
+//
+// THE PLAN of a batch is three launches (round 4; rounds 2-3 took bounds + five scan launches):
+//   k_t6_bounds   region bounds (or bounds from gathered records) + the {max end, max start} of every tile
+//   k_t6_mid      every tile reduces the tiles before it by itself (a few thousand words at most: no spine launch),
+//                 E_prev per region, what each region adds to the batch, the tile sums of that
+//   k_t6_apply    every tile reduces the tile sums before it AND all of them (the totals: every block knows the size
+//                 of the shared table, so regions under the duplicate rule get their private rows' place here), the
+//                 per-region arrays, the row deltas of k_share_rows2 / k_fill_sites2, the list of slow regions;
+//                 block 0 posts the totals into mapped host memory, sequence word last -- the host spins on it.
+// A thread owns `items` consecutive regions (1 up to a million regions per batch), so the number of tiles stays
+// within what a block reduces by itself whatever the batch.
 // ---------------------------------------------------------------------------
-// (the scans over the regions keep 2 items per thread: their per-item work is a chain of dependent site-table reads, and
-//  100 k regions in tiles of 2048 would be 49 blocks on a 256-CU part)
-constexpr int kShareItems = 2, kShareTile = kScanBlock * kShareItems;
+constexpr int kPlanBlock = 256;
+constexpr uint32_t kPlanMaxTiles = 4096;
 struct ShareMax { uint32_t g1, g0; };
 __device__ __forceinline__ ShareMax smax(ShareMax a, ShareMax b) { return ShareMax{a.g1 > b.g1 ? a.g1 : b.g1, a.g0 > b.g0 ? a.g0 : b.g0}; }
 __device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* total) {
-  __shared__ ShareMax wmx[kScanBlock / 64];
+  __shared__ ShareMax wmx[kPlanBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   ShareMax incl = v;
   for (int d = 1; d < 64; d <<= 1) {
@@ -69,7 +83,7 @@ __device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* to
   if (lane == 63) wmx[wid] = incl;
   __syncthreads();
   ShareMax woff{0, 0}, tot{0, 0};
-  for (int w = 0; w < kScanBlock / 64; ++w) {
+  for (int w = 0; w < kPlanBlock / 64; ++w) {
     if (w < wid) woff = smax(woff, wmx[w]);
     tot = smax(tot, wmx[w]);
   }
@@ -82,144 +96,201 @@ __device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {
   const uint32_t nv = (uint32_t)r.q_nvar[q];
   return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q]} : ShareMax{0, 0};
 }
-__global__ void __launch_bounds__(kScanBlock) k_share_tile_max(DevResult r, ShareMax* tile_max) {
-  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
-  ShareMax m{0, 0};
-  for (int i = 0; i < kShareItems; ++i)
-    if (base + i < r.Q) m = smax(m, share_elem(r, base + i));
-  ShareMax tot;
-  block_exclusive_max(m, &tot);
-  if (threadIdx.x == 0) tile_max[blockIdx.x] = tot;
+// rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule), such regions
+struct Scan5 { uint64_t a, u, c, p, s; };
+__device__ __forceinline__ Scan5 operator+(Scan5 x, Scan5 y) { return Scan5{x.a + y.a, x.u + y.u, x.c + y.c, x.p + y.p, x.s + y.s}; }
+__device__ __forceinline__ Scan5 wave_shfl_up5(Scan5 v, int d) {
+  return Scan5{__shfl_up(v.a, d, 64), __shfl_up(v.u, d, 64), __shfl_up(v.c, d, 64), __shfl_up(v.p, d, 64), __shfl_up(v.s, d, 64)};
 }
-__global__ void __launch_bounds__(kScanBlock) k_share_spine_max(ShareMax* tile_max, uint64_t ntiles) {   // exclusive prefix max, in place
-  ShareMax carry{0, 0};
-  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
-    const uint64_t i = base + threadIdx.x;
-    const ShareMax v = i < ntiles ? tile_max[i] : ShareMax{0, 0};
-    ShareMax tot;
-    const ShareMax ex = block_exclusive_max(v, &tot);
-    if (i < ntiles) tile_max[i] = smax(carry, ex);
-    carry = smax(carry, tot);
-  }
-}
-struct Scan4 { uint64_t a, u, c, p; };   // rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule)
-__device__ __forceinline__ Scan4 block_exclusive_scan4(Scan4 v, Scan4* total) {
-  __shared__ Scan4 wsum[kScanBlock / 64];
+__device__ __forceinline__ Scan5 block_exclusive_scan5(Scan5 v, Scan5* total) {
+  __shared__ Scan5 wsum[kPlanBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  Scan4 incl = v;
+  Scan5 incl = v;
   for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t ta = __shfl_up(incl.a, d, 64), tu = __shfl_up(incl.u, d, 64), tc = __shfl_up(incl.c, d, 64), tp = __shfl_up(incl.p, d, 64);
-    if (lane >= d) { incl.a += ta; incl.u += tu; incl.c += tc; incl.p += tp; }
+    const Scan5 t = wave_shfl_up5(incl, d);
+    if (lane >= d) incl = incl + t;
   }
   if (lane == 63) wsum[wid] = incl;
   __syncthreads();
-  Scan4 woff{0, 0, 0, 0}, tot{0, 0, 0, 0};
-  for (int w = 0; w < kScanBlock / 64; ++w) {
-    if (w < wid) { woff.a += wsum[w].a; woff.u += wsum[w].u; woff.c += wsum[w].c; woff.p += wsum[w].p; }
-    tot.a += wsum[w].a; tot.u += wsum[w].u; tot.c += wsum[w].c; tot.p += wsum[w].p;
+  Scan5 woff{0, 0, 0, 0, 0}, tot{0, 0, 0, 0, 0};
+  for (int w = 0; w < kPlanBlock / 64; ++w) {
+    if (w < wid) woff = woff + wsum[w];
+    tot = tot + wsum[w];
   }
   __syncthreads();
   *total = tot;
-  return Scan4{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c, woff.p + incl.p - v.p};
+  return Scan5{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c, woff.p + incl.p - v.p, woff.s + incl.s - v.s};
 }
 // what region q adds to the batch, given the largest site end before it
-struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back, rback; };
+struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back, rback, pre_ns; };
 __device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, uint32_t nv, uint32_t e_prev) {
-  ShareNew o{g0, 0, 0, 0, 0};
+  ShareNew o{g0, 0, 0, 0, 0, 0};
   if (!nv) return o;
   const uint32_t g1 = g0 + nv;
   o.ns = e_prev > g0 ? (e_prev < g1 ? e_prev : g1) : g0;
   o.n_new = g1 - o.ns;
   const uint64_t c0 = im.s_carpre[g0];
-  o.arena_new = im.s_carpre[g1] - im.s_carpre[o.ns];
+  o.pre_ns = im.s_carpre[o.ns];
+  o.arena_new = im.s_carpre[g1] - o.pre_ns;
   o.back = e_prev > g0 ? im.s_carpre[e_prev] - c0 : 0;   // arena distance from site g0 to where the covered ground ends
   o.rback = e_prev > g0 ? e_prev - g0 : 0;               // the same in rows
   return o;
 }
-// per element: E_prev (kept for the last pass) and the tile sums
-__global__ void __launch_bounds__(kScanBlock) k_share_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t* e_prev, Scan4* tile_sums,
-                                                         uint32_t* status) {
-  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
-  ShareMax loc[kShareItems], m{0, 0};
-  for (int i = 0; i < kShareItems; ++i) {
-    loc[i] = base + i < r.Q ? share_elem(r, base + i) : ShareMax{0, 0};
-    m = smax(m, loc[i]);
+
+// What the plan leaves in mapped host memory: the host sizes the table and the arena from it and launches the rest.
+struct PlanTotals {
+  uint64_t rows;        // rows of the variant table: shared + private
+  uint64_t arena;       // arena entries
+  uint64_t shared_rows; // U: sites the batch covers
+  uint64_t not_sorted;  // the regions were not sorted by first site: nothing below is meaningful
+  uint64_t reported;    // rows over all regions (a shared row once per region reporting it)
+  uint64_t n_slow;      // regions under the duplicate rule
+  uint64_t seq;         // written last, system-scope release: the host spins on it
+};
+
+// SRC 0: bounds from (x, y); 1: from gathered records (k_bounds_from_records); 2: the per-region arrays are already there
+// (a batch sorted on the device works on permuted copies of them)
+struct RecordBounds { uint32_t g0, nv; uint8_t fl; uint64_t npad; };
+__device__ __forceinline__ RecordBounds record_bounds(const DevImage& im, const uint64_t* recs, uint64_t q) {
+  const uint64_t w1 = recs[4 * q + 1], w2 = recs[4 * q + 2];
+  uint32_t g0 = (uint32_t)w1, nsites = (uint32_t)w2;
+  uint8_t fl = (uint8_t)((w1 >> 32) & (kRegionEmpty | kRegionInvalid | kRegionNotFound | kRegionEndless));
+  if ((uint64_t)g0 + nsites > im.G) { g0 = 0; nsites = 0; fl = kRegionInvalid; }
+  if ((w1 >> 40) & 1) fl |= kRegionSlow;   // the producing rank dropped rows: the literal rule runs again here
+  return RecordBounds{g0, nsites, fl, im.s_carpre[g0 + nsites] - im.s_carpre[g0]};
+}
+template <int SRC>
+__global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
+  const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
+  ShareMax m{0, 0};
+  for (uint32_t i = 0; i < items; ++i) {
+    const uint64_t q = base + i;
+    if (q >= r.Q) break;
+    uint32_t g0, nv;
+    if (SRC == 0) {
+      const RegionBounds b = region_bounds_of(im, r.regions[2 * q], r.regions[2 * q + 1]);
+      g0 = b.g0; nv = b.g1 - b.g0;
+      r.q_flags[q] = b.flags; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad;
+    } else if (SRC == 1) {
+      const RecordBounds b = record_bounds(im, recs, q);
+      g0 = b.g0; nv = b.nv;
+      r.q_flags[q] = b.fl; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad;
+    } else {
+      g0 = r.q_g0[q]; nv = (uint32_t)r.q_nvar[q];
+    }
+    if (nv) m = smax(m, ShareMax{g0 + nv, g0});
   }
   ShareMax tot;
-  ShareMax ex = smax(block_exclusive_max(m, &tot), tile_max[blockIdx.x]);
-  Scan4 s{0, 0, 0, 0};
-  for (int i = 0; i < kShareItems; ++i) {
-    if (base + i < r.Q) {
-      const uint32_t nv = (uint32_t)r.q_nvar[base + i];
-      if (nv && loc[i].g0 < ex.g0) *status = 1;          // a region that starts before an earlier one: not sorted
-      e_prev[base + i] = ex.g1;
-      const ShareNew w = share_new(im, loc[i].g0, nv, ex.g1);
-      s.a += nv; s.u += w.n_new; s.c += w.arena_new;
-      if (r.q_flags[base + i] & kRegionSlow) s.p += nv;
-    }
-    ex = smax(ex, loc[i]);
-  }
-  Scan4 t4;
-  block_exclusive_scan4(s, &t4);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = t4;
+  block_exclusive_max(m, &tot);
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = tot;
 }
-// totals: {rows of the table (shared + private), arena entries, shared rows, not-sorted flag, rows reported over all regions}
-// (totals lie in mapped host memory; totals[5] = seq is written last, with a system-scope release: the host spins on it
-//  instead of synchronising the stream)
-__global__ void __launch_bounds__(kScanBlock) k_share_spine_sum(Scan4* tile_sums, uint64_t ntiles, DevResult r, uint64_t* u_begin, uint64_t* totals,
-                                                               const uint32_t* status, uint64_t seq) {
-  Scan4 carry{0, 0, 0, 0};
-  for (uint64_t base = 0; base < ntiles; base += kScanBlock) {
-    const uint64_t i = base + threadIdx.x;
-    const Scan4 v = i < ntiles ? tile_sums[i] : Scan4{0, 0, 0, 0};
-    Scan4 tot;
-    const Scan4 ex = block_exclusive_scan4(v, &tot);
-    if (i < ntiles) tile_sums[i] = Scan4{carry.a + ex.a, carry.u + ex.u, carry.c + ex.c, carry.p + ex.p};
-    carry.a += tot.a; carry.u += tot.u; carry.c += tot.c; carry.p += tot.p;
+// per region: E_prev (kept for the last pass); per tile: the sums
+__global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
+                                                       uint32_t* status) {
+  __shared__ ShareMax red[kPlanBlock / 64];
+  ShareMax pm{0, 0};   // the tiles before this one
+  for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kPlanBlock) pm = smax(pm, tile_max[t]);
+  for (int d = 32; d >= 1; d >>= 1) pm = smax(pm, ShareMax{(uint32_t)__shfl_xor(pm.g1, d, 64), (uint32_t)__shfl_xor(pm.g0, d, 64)});
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pm;
+  __syncthreads();
+  pm = smax(smax(red[0], red[1]), smax(red[2], red[3]));
+  const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
+  ShareMax m{0, 0};
+  for (uint32_t i = 0; i < items && base + i < r.Q; ++i) m = smax(m, share_elem(r, base + i));
+  ShareMax tot;
+  ShareMax ex = smax(block_exclusive_max(m, &tot), pm);
+  Scan5 s{0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
+    const uint64_t q = base + i;
+    const ShareMax el = share_elem(r, q);
+    const uint32_t nv = el.g1 - el.g0;
+    if (nv && el.g0 < ex.g0) *status = 1;          // a region that starts before an earlier one: not sorted
+    e_prev[q] = ex.g1;
+    const ShareNew w = share_new(im, el.g0, nv, ex.g1);
+    s.a += nv; s.u += w.n_new; s.c += w.arena_new;
+    if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
+    ex = smax(ex, el);
   }
-  if (threadIdx.x == 0) {
-    r.var_begin[r.Q] = carry.u + carry.p; r.car_base[r.Q] = carry.c; u_begin[r.Q] = carry.u;
-    totals[0] = carry.u + carry.p; totals[1] = carry.c; totals[2] = carry.u; totals[3] = *status; totals[4] = carry.a;
-    __hip_atomic_store(&totals[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  Scan5 t5;
+  block_exclusive_scan5(s, &t5);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = t5;
 }
-__global__ void __launch_bounds__(kScanBlock) k_share_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan4* tile_sums, uint32_t* new_start,
-                                                           uint64_t* u_begin, uint64_t* arena_new) {
-  const uint64_t base = (uint64_t)blockIdx.x * kShareTile + (uint64_t)threadIdx.x * kShareItems;
-  const uint64_t U = u_begin[r.Q];   // (written by the spine kernel before this launch)
-  ShareNew loc[kShareItems];
-  uint32_t nvs[kShareItems];
-  bool slow[kShareItems];
-  Scan4 s{0, 0, 0, 0};
-  for (int i = 0; i < kShareItems; ++i) {
-    loc[i] = ShareNew{0, 0, 0, 0, 0}; nvs[i] = 0; slow[i] = false;
-    if (base + i < r.Q) {
-      nvs[i] = (uint32_t)r.q_nvar[base + i];
-      slow[i] = (r.q_flags[base + i] & kRegionSlow) != 0;
-      loc[i] = share_new(im, r.q_g0[base + i], nvs[i], e_prev[base + i]);
-      s.a += nvs[i]; s.u += loc[i].n_new; s.c += loc[i].arena_new; s.p += slow[i] ? nvs[i] : 0;
-    }
+// The per-region deltas that turn "row u of the shared table" into "site g and its arena offset" (k_share_rows2,
+// k_fill_sites2): g = u + dg, car_begin = s_carpre[g] + dc for every row u of the region's new part.
+struct RowDelta { uint64_t dg, dc; };
+template <bool RESIDENT>
+__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+                                                         uint64_t* u_begin, RowDelta* delta, uint32_t* slow_list,
+                                                         PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
+  __shared__ Scan5 red[2][kPlanBlock / 64];
+  Scan5 pre{0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0};
+  for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) {
+    const Scan5 v = tile_sums[t];
+    all = all + v;
+    if (t < blockIdx.x) pre = pre + v;
   }
-  Scan4 tot;
-  Scan4 ex = block_exclusive_scan4(s, &tot);
-  const Scan4 ts = tile_sums[blockIdx.x];
-  ex.a += ts.a; ex.u += ts.u; ex.c += ts.c; ex.p += ts.p;
-  for (int i = 0; i < kShareItems; ++i) {
-    if (base + i < r.Q) {
-      const uint64_t q = base + i;
-      u_begin[q] = ex.u; arena_new[q] = ex.c; new_start[q] = loc[i].ns;
-      // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
-      r.var_begin[q] = slow[i] ? U + ex.p : ex.u - loc[i].rback;
-      r.car_base[q] = ex.c - loc[i].back;
+  for (int d = 32; d >= 1; d >>= 1) {
+    pre = pre + Scan5{__shfl_xor(pre.a, d, 64), __shfl_xor(pre.u, d, 64), __shfl_xor(pre.c, d, 64), __shfl_xor(pre.p, d, 64), __shfl_xor(pre.s, d, 64)};
+    all = all + Scan5{__shfl_xor(all.a, d, 64), __shfl_xor(all.u, d, 64), __shfl_xor(all.c, d, 64), __shfl_xor(all.p, d, 64), __shfl_xor(all.s, d, 64)};
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
+  __syncthreads();
+  pre = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const uint64_t U = all.u;
+  const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
+  Scan5 s{0, 0, 0, 0, 0};
+  ShareNew w_first{0, 0, 0, 0, 0, 0};   // (items == 1, the usual case: what the region adds is worked out once)
+  for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
+    const uint64_t q = base + i;
+    const uint32_t nv = (uint32_t)r.q_nvar[q];
+    const ShareNew w = share_new(im, r.q_g0[q], nv, e_prev[q]);
+    if (i == 0) w_first = w;
+    s.a += nv; s.u += w.n_new; s.c += w.arena_new;
+    if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
+  }
+  Scan5 tot;
+  Scan5 ex = block_exclusive_scan5(s, &tot) + pre;
+  const bool sorted = *status == 0;   // a batch that is not sorted is planned again after the sort: its per-region inputs stay as the bounds left them
+  for (uint32_t i = 0; sorted && i < items && base + i < r.Q; ++i) {
+    const uint64_t q = base + i;
+    const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q];
+    const bool slow = (r.q_flags[q] & kRegionSlow) != 0;
+    const ShareNew w = i == 0 ? w_first : share_new(im, g0, nv, e_prev[q]);
+    u_begin[q] = ex.u;
+    // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
+    r.var_begin[q] = slow ? U + ex.p : ex.u - w.rback;
+    if (RESIDENT) {   // the lists ARE the index's arena: a site's list lies at s_carpre[g]
+      const uint64_t pre0 = nv ? im.s_carpre[g0] : im.s_carpre[0];
+      delta[q] = RowDelta{(uint64_t)w.ns - ex.u, 0};
+      r.car_base[q] = pre0;
+      r.q_car_len[q] = im.s_carpre[(nv ? g0 : 0u) + nv] - pre0;
+    } else {
+      delta[q] = RowDelta{(uint64_t)w.ns - ex.u, ex.c - w.pre_ns};
+      r.car_base[q] = ex.c - w.back;
       r.q_car_len[q] = r.q_ncar[q];                  // the region's own padded arena extent
-      if (!slow[i]) {                                // (dedup_region sets these for the others)
-        const uint32_t g0 = r.q_g0[q];
-        r.var_count[q] = nvs[i];
-        r.q_ncar[q] = im.s_kpre[g0 + nvs[i]] - im.s_kpre[g0];
-      }
     }
-    ex.a += nvs[i]; ex.u += loc[i].n_new; ex.c += loc[i].arena_new; ex.p += slow[i] ? nvs[i] : 0;
+    if (slow) slow_list[ex.s] = (uint32_t)q;
+    else {                                           // (dedup_region sets these for the others)
+      r.var_count[q] = nv;
+      r.q_ncar[q] = im.s_kpre[g0 + nv] - im.s_kpre[g0];
+    }
+    ex.a += nv; ex.u += w.n_new; ex.c += w.arena_new;
+    if (slow) { ex.p += nv; ex.s += 1; }
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint64_t arena = RESIDENT ? resident_entries : all.c;
+    r.var_begin[r.Q] = all.u + all.p; r.car_base[r.Q] = arena; u_begin[r.Q] = all.u;
+    const uint64_t ns = *status;
+    totals_host->rows = all.u + all.p; totals_host->arena = arena; totals_host->shared_rows = all.u; totals_host->not_sorted = ns;
+    totals_host->reported = all.a; totals_host->n_slow = all.s;
+    __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// end of a batch: one word into mapped host memory behind everything else on the stream (the host spins on it: the
+// runtime's completion wait costs tens of microseconds more)
+__global__ void k_post_done(uint64_t* flag, uint64_t seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // A batch that is NOT sorted by first site is sorted here -- a counting sort over the site index: histogram of the first
 // sites (regions without sites count as site 0), exclusive scan over the G + 1 buckets (the engine's scan kernels),
@@ -253,9 +324,9 @@ __global__ void __launch_bounds__(256) k_permute_out(DevResult s, DevResult r, c
   r.q_car_len[q] = s.q_car_len[i]; r.var_count[q] = s.var_count[i];
 }
 
-// Resident carrier lists: a region's lists ARE the arena range of its sites -- car_base = s_carpre[g0] whatever the
-// scans made of it (and the start of the region's new part likewise, for k_share_rows).
-__global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r, const uint32_t* new_start, uint64_t* arena_new, uint64_t arena_entries) {
+// Resident carrier lists, private rows: a region's lists ARE the arena range of its sites -- car_base = s_carpre[g0]
+// whatever the scans made of it.
+__global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r, uint64_t arena_entries) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q == r.Q) r.car_base[q] = arena_entries;
   if (q >= r.Q) return;
@@ -264,30 +335,72 @@ __global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r
   const uint64_t pre = im.s_carpre[g0];
   r.car_base[q] = pre;
   r.q_car_len[q] = im.s_carpre[g0 + n] - pre;
-  if (arena_new) arena_new[q] = im.s_carpre[new_start[q]];
 }
 
-// The shared rows: every region writes the rows of the sites it is the first to cover (one wave per region), and the
-// site index beside them for the expansion; regions under the duplicate rule also get their private copy.
-__global__ void __launch_bounds__(256) k_share_rows(DevImage im, DevResult r, const uint32_t* new_start, const uint64_t* u_begin, const uint64_t* arena_new,
-                                                    uint32_t* u_site) {
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (q >= r.Q) return;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t u0 = u_begin[q], n_new = u_begin[q + 1] - u0;
-  if (n_new) {
-    const uint32_t ns = new_start[q];
-    const uint64_t cb0 = arena_new[q], pre = im.s_carpre[ns];
-    for (uint64_t j = lane; j < n_new; j += 64) {
-      const uint32_t g = ns + (uint32_t)j;
-      row_store(r.rows, u0 + j, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], im.s_ncar[g],
-                (im.s_flags[g] & kSiteAlwaysDrop) != 0, cb0 + (im.s_carpre[g] - pre));
-      u_site[u0 + j] = g;   // (the expansion takes source handle and genotype offset from the site table: writing them here as well cost more than the look-up)
-    }
+// ---------------------------------------------------------------------------
+// The shared rows, ROW-CENTRIC (round 4): a lane per row of the shared table.  Row u belongs to the region q with
+// u_begin[q] <= u < u_begin[q + 1] (the region that is the first to cover its site); with that region's deltas the row
+// is ONE 32-byte load of the static site row (DevImage::s_row: the row as a resident list would have it), one add, one
+// 32-byte store.  The time follows the rows, not the regions (round 3: one wave per region, eight SoA reads per row).
+//
+// shared_row_region: the wave finds the region of its FIRST row by a 64-ary search over u_begin (three dependent loads
+// for 100 k regions), loads the 64 region boundaries behind it together, and every lane counts the boundaries at or
+// below its own row by bisection over the lanes (six ds_bpermute).  A lane whose row lies beyond those 64 boundaries
+// (a run of regions that add nothing) bisects on its own.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t shared_row_region(const uint64_t* __restrict__ u_begin, uint64_t Q, uint64_t u_first, uint32_t lane, uint32_t row_in_wave) {
+  // largest q in [0, Q) with u_begin[q] <= u_first   (u_begin[0] == 0, u_begin[Q] == U > u_first)
+  uint64_t lo = 0, hi = Q;
+  while (hi - lo > 1) {
+    const uint64_t step = (hi - lo + 63) / 64;
+    const uint64_t p = lo + (uint64_t)(lane + 1) * step;
+    const bool ok = p < hi && u_begin[p] <= u_first;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));     // the probes are monotone: a prefix of the lanes says yes
+    const uint64_t nlo = lo + (uint64_t)cnt * step, nhi = lo + (uint64_t)(cnt + 1) * step;
+    lo = nlo; hi = nhi < hi ? nhi : hi;
   }
-  if (r.q_flags[q] & kRegionSlow) emit_region<false>(im, r, q, lane);
+  const uint64_t qf = lo;
+  const uint64_t bi = qf + 1 + lane;
+  const uint64_t b = u_begin[bi < Q ? bi : Q];                 // boundary behind region qf + lane
+  const uint64_t me = u_first + row_in_wave;
+  uint32_t cnt = 0;                                            // boundaries at or below my row, among the first 63
+#pragma unroll
+  for (uint32_t step = 32; step; step >>= 1) {
+    const uint64_t v = __shfl(b, (int)(cnt + step - 1), 64);
+    if (v <= me) cnt += step;
+  }
+  uint64_t q = qf + cnt;
+  const uint64_t b63 = __shfl(b, 63, 64);
+  if (cnt == 63 && b63 <= me) {                                // beyond the window: plain bisection (rare)
+    uint64_t l2 = qf + 64 < Q ? qf + 64 : Q, h2 = Q;           // u_begin[l2] <= me < u_begin[h2]
+    if (l2 > Q - 1) l2 = Q - 1;
+    while (h2 - l2 > 1) {
+      const uint64_t m = (l2 + h2) >> 1;
+      if (u_begin[m] <= me) l2 = m; else h2 = m;
+    }
+    q = l2;
+  }
+  return q;
 }
-
+// rows only (resident carrier lists; results whose expansion runs on another stream): u_site receives the site of every row
+__global__ void __launch_bounds__(256) k_share_rows2(DevImage im, DevResult r, const uint64_t* __restrict__ u_begin, const RowDelta* __restrict__ delta,
+                                                     uint64_t U, uint32_t* u_site) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t u_first = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
+  if (u_first >= U) return;
+  const uint64_t q = shared_row_region(u_begin, r.Q, u_first, lane, lane);
+  const uint64_t u = u_first + lane;
+  if (u >= U) return;
+  const RowDelta d = delta[q];
+  const uint32_t g = (uint32_t)(u + d.dg);
+  const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
+  uint4 x = src[0], y = src[1];
+  const uint64_t cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
+  y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
+  uint4* dst = reinterpret_cast<uint4*>(r.rows + u);
+  dst[0] = x; dst[1] = y;
+  if (u_site) u_site[u] = g;
+}
 // The reference's "only add var if not seen before" rule (query.h:397-414),
 // literally, for the regions flagged by k_region_bounds.  One thread per region.
 __device__ __forceinline__ void dedup_region(const DevImage& im, const DevResult& r, uint64_t q) {
@@ -324,6 +437,19 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q || !(r.q_flags[q] & kRegionSlow)) return;
   dedup_region(im, r, q);
+}
+
+// Regions under the duplicate rule: a private copy of their rows behind the shared table (their drops are their own),
+// then the literal rule.  One wave per such region, from the list k_t6_apply left.
+__global__ void __launch_bounds__(256) k_t6_slow(DevImage im, DevResult r, const uint32_t* slow_list, uint64_t n) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t i = wave; i < n; i += nwaves) {
+    const uint64_t q = slow_list[i];
+    emit_region<false>(im, r, q, lane);
+    __threadfence();   // the rows of the other lanes, before lane 0 reads them back
+    if (lane == 0) dedup_region(im, r, q);
+  }
 }
 
 }  // namespace vsamd

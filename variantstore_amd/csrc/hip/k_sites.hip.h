@@ -54,6 +54,15 @@ __global__ void __launch_bounds__(256) k_slot_prefixes(DevImage im, uint64_t* rp
   rp_kpre[i] = im.s_kpre[g];
 }
 
+// The static site rows (DevImage::s_row): what a row of the variant table says about site g when its carrier list lies at
+// s_carpre[g] -- a batch copies the record and rebases the list offset (k_share_rows2, k_fill_sites2, emit_region).
+__global__ void __launch_bounds__(256) k_build_site_rows(DevImage im, VariantRow* rows) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= im.G) return;
+  row_store(rows, g, im.s_pos[g], im.s_ref_off[g], im.s_ref_len[g], im.s_alt_off[g], im.s_alt_len[g], im.s_ncar[g],
+            (im.s_flags[g] & kSiteAlwaysDrop) != 0, im.s_carpre[g]);
+}
+
 // nearest earlier site with the same (pos, alt); positions are sorted up to an
 // off-by-one (an insertion reports end-1, everything else end), so the backward
 // scan stops at the first site whose pos < p-1.
