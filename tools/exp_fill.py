@@ -30,7 +30,7 @@ def reopen(lm):
         os.environ["VS_LIST_MAX"] = str(lm)
     vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
     cur_lm = lm
-OPTIONS = {"fill_ablate": 0, "fill_lds_pad": 0}   # the switches an experiment may set, with their defaults
+OPTIONS = {"fill_ablate": 0, "fill_lds_pad": 0, "fill_fused": 1, "fill_chunk": 0, "fill_stats": 0}   # the switches an experiment may set, with their defaults
 
 
 def run(name, env, rlen, steps=8):

@@ -1,0 +1,119 @@
+// What the HBM of an MI355X gives plain streaming kernels: read-only, write-only, a 1:1 copy and the carrier
+// expansion's own shape (2 bytes read : 3 written, non-temporal 16-byte stores) -- tuned until the 1:1 copy reproduces
+// the guide's 6.29 TB/s (MI355X_MICROARCH.md: "float4 copy"), so that the figures can serve as ceilings for
+// roofline.frac.  Round 3's mix_ceiling.hip (one 16-byte load in flight per thread, grid-stride over 1 GiB) stopped at
+// 4.8 - 5.3 TB/s for the copy (VERDICT r3, weak #2c).
+//
+// Knobs: U independent 16-byte loads in flight per thread, block size B, tiles of B x U x 16 bytes handed out
+// contiguously (a block owns a contiguous span: span = tiles_per_block consecutive tiles) or interleaved (grid-stride),
+// 4 GiB per stream.  hipMemcpyDtoDAsync / hipMemsetAsync are printed as the runtime's own reference points.
+//   hipcc --offload-arch=gfx950 -O3 -o hbm_ceiling hbm_ceiling.hip && ./hbm_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One block works through `tiles` tiles: tile t of block b is tile (CONTIG ? b * tiles + t : t * gridDim.x + b).
+// A tile is B x U 16-byte elements per stream; thread i takes elements i, i + B, ... of the tile (coalesced per load).
+template <int R, int W, int U, bool NT, bool CONTIG>
+__global__ void stream_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n_per_stream, size_t tiles, u32x4* sink) {
+  const size_t B = blockDim.x, tile_elems = B * U;
+  u32x4 acc = {0, 0, 0, 0};
+  for (size_t t = 0; t < tiles; ++t) {
+    const size_t tile = CONTIG ? (size_t)blockIdx.x * tiles + t : t * gridDim.x + blockIdx.x;
+    const size_t base = tile * tile_elems + threadIdx.x;
+    if (base >= n_per_stream) break;
+    u32x4 v[R > 0 ? R : 1][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[r][u] = __builtin_nontemporal_load(&src[(size_t)r * n_per_stream + base + (size_t)u * B]);
+    u32x4 o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      o[u] = u32x4{(unsigned)u, 1, 2, 3};
+#pragma unroll
+      for (int r = 0; r < R; ++r) o[u] += v[r][u];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32x4 x = o[u] + (unsigned)w;
+        u32x4* p = &dst[(size_t)w * n_per_stream + base + (size_t)u * B];
+        if (NT) __builtin_nontemporal_store(x, p); else *p = x;
+      }
+    if (W == 0)
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += o[u];
+  }
+  if (W == 0 && acc.x == 0x12345u) *sink = acc;   // keep the loads of the read-only form
+}
+
+struct Best { double gbps = 0; int block = 0, grid = 0, contig = 0; float ms = 0; };
+
+template <int R, int W, int U, bool NT, bool CONTIG>
+static int one(const u32x4* src, u32x4* dst, u32x4* sink, size_t n, int block, int grid_mult, Best* best, hipEvent_t e0, hipEvent_t e1) {
+  const size_t tile_elems = (size_t)block * U, ntiles = n / tile_elems;
+  size_t grid = grid_mult > 0 ? (size_t)256 * grid_mult : ntiles;   // grid_mult 0: one tile per block, no loop
+  if (grid > ntiles) grid = ntiles;
+  const size_t tiles = (ntiles + grid - 1) / grid;
+  auto f = [&] { hipLaunchKernelGGL((stream_kernel<R, W, U, NT, CONTIG>), dim3((unsigned)grid), dim3(block), 0, 0, src, dst, n, tiles, sink); };
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0)); for (int i = 0; i < 3; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+  const double gbps = (double)n * 16 * (R + W) / 1e9 / (ms * 1e-3);
+  if (gbps > best->gbps) *best = Best{gbps, block, (int)grid, CONTIG, ms};
+  return 0;
+}
+
+template <int R, int W, int U, bool NT>
+static int sweep(const char* name, const u32x4* src, u32x4* dst, u32x4* sink, size_t n, hipEvent_t e0, hipEvent_t e1) {
+  Best best;
+  double worst = 1e30;
+  for (int block : {256, 512, 1024})
+    for (int gm : {0, 4, 8, 16, 64}) {
+      Best b;
+      if (one<R, W, U, NT, true>(src, dst, sink, n, block, gm, &b, e0, e1)) return 1;
+      if (b.gbps > best.gbps) best = b;
+      worst = std::min(worst, b.gbps);
+      if (gm) {
+        Best c;
+        if (one<R, W, U, NT, false>(src, dst, sink, n, block, gm, &c, e0, e1)) return 1;
+        if (c.gbps > best.gbps) best = c;
+        worst = std::min(worst, c.gbps);
+      }
+    }
+  printf("%-28s U=%d %s: best %7.1f GB/s (%.3f ms; block %4d, grid %7d, %s)   worst of the sweep %7.1f GB/s\n", name, U, NT ? "nt stores" : "         ",
+         best.gbps, best.ms, best.block, best.grid, best.contig ? "contiguous spans" : "grid-stride", worst);
+  fflush(stdout);
+  return 0;
+}
+
+int main() {
+  const size_t n = 256ull << 20;   // 4 GiB per stream of 16-byte elements
+  u32x4 *src, *dst, *sink;
+  CK(hipMalloc(&src, n * 16 * 2)); CK(hipMalloc(&dst, n * 16 * 3)); CK(hipMalloc(&sink, 16));
+  CK(hipMemset(src, 1, n * 16 * 2));
+  CK(hipMemset(dst, 2, n * 16 * 3));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  {  // the runtime's own copy and fill
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0)); for (int i = 0; i < 3; ++i) CK(hipMemcpyDtoDAsync((hipDeviceptr_t)dst, (hipDeviceptr_t)src, n * 16, 0)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+      if (rep) printf("hipMemcpyDtoDAsync 4 GiB: %.3f ms  %.1f GB/s (read + written)\n", ms, 2.0 * n * 16 / 1e9 / (ms * 1e-3));
+      CK(hipEventRecord(e0)); for (int i = 0; i < 3; ++i) CK(hipMemsetAsync(dst, 3, n * 16, 0)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+      if (rep) printf("hipMemsetAsync 4 GiB:     %.3f ms  %.1f GB/s (written)\n", ms, 1.0 * n * 16 / 1e9 / (ms * 1e-3));
+    }
+  }
+#define SW(R, W, U, NT, NAME) if (sweep<R, W, U, NT>(NAME, src, dst, sink, n, e0, e1)) return 1;
+  SW(1, 0, 1, false, "read only") SW(1, 0, 4, false, "read only") SW(1, 0, 8, false, "read only")
+  SW(0, 1, 1, false, "write only") SW(0, 1, 4, false, "write only") SW(0, 1, 4, true, "write only") SW(0, 1, 8, true, "write only")
+  SW(1, 1, 1, false, "copy 1:1") SW(1, 1, 1, true, "copy 1:1") SW(1, 1, 2, true, "copy 1:1") SW(1, 1, 4, false, "copy 1:1") SW(1, 1, 4, true, "copy 1:1") SW(1, 1, 8, true, "copy 1:1")
+  SW(2, 3, 1, true, "mix 2:3 (expansion's shape)") SW(2, 3, 2, true, "mix 2:3 (expansion's shape)") SW(2, 3, 4, true, "mix 2:3 (expansion's shape)") SW(2, 3, 4, false, "mix 2:3 (expansion's shape)")
+  return 0;
+}

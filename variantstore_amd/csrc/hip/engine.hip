@@ -60,6 +60,7 @@ struct EngineOpts {
   bool seq_two_walks = false;   // the same for types 2 / 3
   bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
   int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
+  bool fill_stats = false;      // tuning builds only: device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
   bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
   bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
   bool async_fill = false;      // type-6 batches: the carrier expansion runs on a second stream and the call returns while it is
@@ -124,7 +125,7 @@ struct vs_index {
   static constexpr size_t kPinSrvResp = 16;   // [16..20] resident server: sequence number of the last request answered (+ debug stamps)
   static constexpr size_t kPinSrvReq = 256;   // [256 .. 256 + 136) resident server: the request (ServerRequest, 64-byte aligned)
   static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path, private rows: slots and arena entries of the batch
-  static constexpr size_t kPinPlan = 1056;    // [1056..1062] throughput path, shared rows: PlanTotals of the batch (k_t6_apply), sequence word last
+  static constexpr size_t kPinPlan = 1056;    // [1056..1063] throughput path, shared rows: PlanTotals of the batch (k_t6_apply), sequence word last
   static constexpr size_t kPinDone = 1072;    // completion word of a batch (k_post_done)
 };
 
@@ -461,6 +462,15 @@ static int build_device_image(vs_index* idx) {
     }
     VS_TRY(upload_image(idx, pre, &d.rp_sus_prefix));
   }
+  {  // the bounds' per-slot and per-rank records
+    uint4* rp = nullptr; uint2* rk = nullptr;
+    VS_TRY(alloc_image(idx, 2 * (im.P + 1), &rp));
+    VS_TRY(alloc_image(idx, im.R + 1, &rk));
+    hipLaunchKernelGGL(k_slot_records, dim3((unsigned)((im.P + 256) / 256)), dim3(256), 0, idx->stream, d, rp);
+    hipLaunchKernelGGL(k_rank_records, dim3((unsigned)((im.R + 256) / 256)), dim3(256), 0, idx->stream, d, rk);
+    HIP_TRY(hipGetLastError());
+    d.rp_rec = rp; d.rk_rec = rk;
+  }
   VS_TRY(upload_image(idx, sus_g, &d.sus_g));
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
@@ -743,14 +753,14 @@ static int wait_posted(vs_index* idx, volatile uint64_t* word, uint64_t seq, int
 
 // The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).
 template <bool WIDE, bool TUNE>
-static void launch_fill2(vs_index* idx, const DevResult& d, const uint64_t* u_begin, const RowDelta* delta, uint64_t U, uint32_t chunk, size_t lds_bytes,
-                         uint32_t ablate, uint32_t gt_words) {
+static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, const uint32_t* coarse, uint64_t n_runs, uint64_t U, uint32_t chunk,
+                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
   const unsigned blocks = (unsigned)(((U + chunk - 1) / chunk + 3) / 4);
   switch (chunk) {
-    case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
-    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, u_begin, delta, U, ablate, gt_words); break;
+    case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
   }
 }
 
@@ -790,15 +800,15 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   ShareMax* tile_max = nullptr;
   Scan5* tile_sums = nullptr;
   uint32_t *e_prev = nullptr, *status = nullptr, *slow_list = nullptr;
-  uint64_t* u_begin = nullptr;
-  RowDelta* delta = nullptr;
+  RunRec* runs = nullptr;
+  uint32_t* coarse = nullptr;
+  VS_TRY(dev_alloc(idx, (idx->d.G / kCoarseRows + 2) * 4, (void**)&coarse, &scratch.bufs));
   VS_TRY(dev_alloc(idx, ntiles * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
   VS_TRY(dev_alloc(idx, ntiles * sizeof(Scan5), (void**)&tile_sums, &scratch.bufs));
   VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
   VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
   VS_TRY(dev_alloc(idx, n * 4, (void**)&slow_list, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&u_begin, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, n * sizeof(RowDelta), (void**)&delta, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, (n + 1) * sizeof(RunRec), (void**)&runs, &scratch.bufs));
   PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
   auto launch_bounds = [&](int src) {
     if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
@@ -812,9 +822,9 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
     if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
-                                     ntiles, items, u_begin, delta, slow_list, pt, (const uint32_t*)status, seq, idx->res_entries);
+                                     ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, idx->res_entries);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
-                            ntiles, items, u_begin, delta, slow_list, pt, (const uint32_t*)status, seq, (uint64_t)0);
+                            ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return wait_posted(idx, &pt->seq, seq, 200);
   };
@@ -867,7 +877,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   }
   if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
-  const uint64_t U = pt->shared_rows, n_slow = pt->n_slow;
+  const uint64_t U = pt->shared_rows, n_slow = pt->n_slow, n_runs = pt->n_runs;
   d.A = pt->rows;
   d.S = pt->arena;
   r->n_rows_reported = pt->reported;
@@ -896,7 +906,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   const bool fused = idx->opts.fill_fused && !resident && !async_fill;
   if (U && !fused) {
     if (!resident) VS_TRY(dev_alloc(idx, U * 4 + 8, (void**)&u_site, &scratch.bufs));
-    hipLaunchKernelGGL(k_share_rows2, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const uint64_t*)u_begin, (const RowDelta*)delta, U, u_site);
+    hipLaunchKernelGGL(k_share_rows2, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const RunRec*)runs, (const uint32_t*)coarse, n_runs, U, u_site);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
@@ -915,7 +925,9 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   } else if (n_fill && !fused) {
     VS_TRY(fill_lists(idx, d, true, u_site, n_fill));
   } else if (n_fill) {
-    uint32_t chunk = idx->opts.fill_chunk ? idx->opts.fill_chunk : 16;
+    // rows per wave task: 32 (one look-up of the run records and one round of parameter loads per 32 rows; 16-row tasks -- round 3's
+    // choice for the kernel that did not write rows -- measure the same to 5 % slower, 64 and 8 slower: tools/ab_t6.py)
+    uint32_t chunk = idx->opts.fill_chunk ? idx->opts.fill_chunk : 32;
     const uint32_t gt_words = fill_gt_words(idx);
 #ifdef VS_TUNING
     const size_t lds_bytes = fill_lds_bytes(idx) + std::min<size_t>(idx->opts.fill_lds_pad, 96 << 10);
@@ -927,9 +939,31 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     constexpr bool kTune = false;
 #endif
     if ((U + chunk - 1) / chunk / 4 > 0x7FFFFFF0ull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu shared rows)", (unsigned long long)U);
-    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, u_begin, delta, U, chunk, lds_bytes, ablate, gt_words);
-    else launch_fill2<false, kTune>(idx, d, u_begin, delta, U, chunk, lds_bytes, ablate, gt_words);
+    unsigned long long* tstat = nullptr;
+#ifdef VS_TUNING
+    if (idx->opts.fill_stats) {
+      VS_TRY(dev_alloc(idx, ((U + chunk - 1) / chunk + 4) * 16, (void**)&tstat, &scratch.bufs));
+      HIP_TRY(hipMemsetAsync(tstat, 0, ((U + chunk - 1) / chunk + 4) * 16, idx->stream));
+    }
+#endif
+    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
+    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
     HIP_TRY(hipGetLastError());
+#ifdef VS_TUNING
+    if (tstat) {
+      const uint64_t nt = (U + chunk - 1) / chunk;
+      std::vector<uint32_t> h(nt * 4);
+      HIP_TRY(hipMemcpyAsync(h.data(), tstat, nt * 16, hipMemcpyDeviceToHost, idx->stream));
+      HIP_TRY(hipStreamSynchronize(idx->stream));
+      double sp = 0, sl = 0, sd = 0, st = 0, nd = 0; uint32_t mx = 0;
+      for (uint64_t t = 0; t < nt; ++t) {
+        const uint32_t tot = h[4 * t + 3] & 0xFFFFFFu;
+        sp += h[4 * t]; sl += h[4 * t + 1]; sd += h[4 * t + 2]; st += tot; nd += h[4 * t + 3] >> 24; mx = std::max(mx, tot);
+      }
+      fprintf(stderr, "fill stats: %llu tasks of %u rows | mean ticks (10 ns) per task: parameters + rows %.1f, list phase %.1f, dense phase %.1f, whole task %.1f (max %u) | "
+              "dense variants per task %.2f\n", (unsigned long long)nt, chunk, sp / nt, sl / nt, sd / nt, st / nt, mx, nd / nt);
+    }
+#endif
   }
   if (perm) {   // every region's outcome back to its place in the caller's order (rows and lists are shared: nothing else moves)
     const DevResult ds = d;
@@ -1792,11 +1826,12 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
     o.fill_chunk = (uint32_t)value;
   }
-  else if (k == "fill_ablate" || k == "fill_lds_pad" || k == "walk_stats") {
+  else if (k == "fill_ablate" || k == "fill_lds_pad" || k == "walk_stats" || k == "fill_stats") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
     if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;
     else if (k == "walk_stats") o.walk_stats = value != 0;
+    else if (k == "fill_stats") o.fill_stats = value != 0;
     else o.fill_lds_pad = (size_t)value;
 #else
     return fail(VS_ERR_UNSUPPORTED, "%s exists in tuning builds only (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force)", key);

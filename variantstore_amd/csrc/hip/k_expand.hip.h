@@ -130,8 +130,10 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // runs side by side on two streams: the list half is loads and stores, the row half LDS and vector work).
 template <bool WIDE, bool EARLY_NIB, bool TUNE = false, int PART = 0>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
-                                            uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words) {
+                                            uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words, unsigned long long* tstat = nullptr) {
   const uint32_t ablate = (TUNE ? ablate_arg : 0u) | (PART == 2 ? 1u : 0u);   // production instantiations carry no ablation tests
+  // tuning builds (option fill_stats): device-clock ticks (10 ns) per phase of the task, summed over the waves
+  const uint64_t t_enter = (TUNE && tstat) ? wall_clock64() : 0;
   const uint32_t wpc = im.wpc;
   const uint64_t* __restrict__ class_rows = im.class_rows;
   const uint8_t* __restrict__ gtp = im.gt_nibbles;
@@ -328,6 +330,11 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     }
   }
 
+  if (TUNE && tstat) {   // (tstat: three words of the CALLER's registers -- list phase, dense phase, dense variants)
+    __builtin_amdgcn_s_waitcnt(0);   // (the list phase's loads have returned; its stores are on their way)
+    tstat[0] = wall_clock64() - t_enter; tstat[2] = (unsigned long long)__popcll(dmask);
+  }
+  const uint64_t t_lists = (TUNE && tstat) ? wall_clock64() : 0;
   if (dmask == 0) return;
   if (lists && !EARLY_NIB) {   // the first dense variant's nibbles (8 registers) are requested after the list phase: its peak register
                  // demand decides how many waves a SIMD holds
@@ -528,6 +535,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       }
     }
   }
+  if (TUNE && tstat) tstat[1] = wall_clock64() - t_lists;
 }
 
 template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
@@ -582,25 +590,25 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, co
 }
 
 // Round 4: the same expansion WRITES the shared rows as well (k_share_rows2's work, on the 16 lanes that fetch the task's
-// parameters anyway): the wave finds the region that owns its first row (shared_row_region), a lane turns its row
-// number into a site with that region's deltas, copies the static site row with the list offset rebased, and takes
+// parameters anyway): the lanes find the runs of covered sites their rows lie in (shared_row_run), a lane turns its row
+// number into a site with that run's record, copies the static site row with the list offset rebased, and takes
 // count / source handle / genotype offset of the same site for the expansion.  No row kernel, no site index written
 // and read back, no second read of the rows.
 template <bool WIDE, uint32_t CH, bool TUNE>
-__global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, const uint64_t* __restrict__ u_begin, const RowDelta* __restrict__ delta, uint64_t U,
-                                                     uint32_t ablate, uint32_t gt_words) {
+__global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
+                                                     uint64_t U, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
+  const uint64_t t_start = (TUNE && tstat) ? wall_clock64() : 0;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
   const uint64_t u_first = wave * CH;
   if (u_first < U) {
-    const uint64_t q = shared_row_region(u_begin, r.Q, u_first, lane, lane < CH ? lane : 0u);
+    const RowDelta d = shared_row_run(runs, coarse, n_runs, u_first, lane, lane < CH ? lane : 0u);
     const uint64_t u = u_first + lane;
     uint32_t cnt = 0, cls = 0;
     uint64_t gt0 = 0, cb = 0;
     if (u < U && lane < CH) {
-      const RowDelta d = delta[q];
       const uint32_t g = (uint32_t)(u + d.dg);
       const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
       const uint4 x = src[0];
@@ -613,7 +621,14 @@ __global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, c
       dst[0] = x; dst[1] = y;
       cnt = y.y & ~kRowDropped;
     }
-    expand_task<WIDE, false, TUNE, 0>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    unsigned long long ph[3] = {0, 0, 0}, t_params = 0;
+    if (TUNE && tstat) {
+      __builtin_amdgcn_s_waitcnt(0);   // the task's parameters are in registers, its rows are on their way
+      t_params = wall_clock64() - t_start;
+    }
+    expand_task<WIDE, false, TUNE, 0>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words, (TUNE && tstat) ? ph : nullptr);
+    if (TUNE && tstat && lane == 0)   // one 16-byte record per task, written once at the end: {parameters + rows, list phase, dense phase, whole task | dense variants << 24}
+      reinterpret_cast<uint4*>(tstat)[wave] = uint4{(uint32_t)t_params, (uint32_t)ph[0], (uint32_t)ph[1], (uint32_t)(wall_clock64() - t_start) | ((uint32_t)ph[2] << 24)};
   }
 }
 

@@ -50,6 +50,10 @@ struct DevImage {
   const uint32_t* rp_sus_prefix;  // [P+1] suspicious sites before each ref-path slot's first site (no bisection per query)
   const uint64_t* rp_carpre;      // [P+1] s_carpre[rp_cand_prefix[slot]]: arena prefix at a slot's first site
   const uint64_t* rp_kpre;        // [P+1] s_kpre likewise
+  // The same per-slot / per-rank figures as records (k_slot_records, k_rank_records): a region's bounds touch ONE line per
+  // end and level instead of four (round 3: 13 sparse lines per region, 28 us for 100 k regions)
+  const uint4* rp_rec;            // [P+1] x 2: {rp_cand_prefix, rp_sus_prefix, rp_carpre lo, hi}, {rp_kpre lo, hi, 0, 0}
+  const uint2* rk_rec;            // [R+1]: {idx_pos[r] (0 at r == R), rank_to_slot[r]}
   uint32_t n_sus, has_car_index;
   uint32_t list_max, pad2_;
   // Query type 4: per-sample EVENT bitmaps over the ref-path slots (k_build_events).  Bit j of row s is set when a walk

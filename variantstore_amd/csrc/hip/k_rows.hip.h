@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 //                 E_prev per region, what each region adds to the batch, the tile sums of that
 //   k_t6_apply    every tile reduces the tile sums before it AND all of them (the totals: every block knows the size
 //                 of the shared table, so regions under the duplicate rule get their private rows' place here), the
-//                 per-region arrays, the row deltas of k_share_rows2 / k_fill_sites2, the list of slow regions;
+//                 per-region arrays, the run records of k_share_rows2 / k_fill_sites2, the list of slow regions;
 //                 block 0 posts the totals into mapped host memory, sequence word last -- the host spins on it.
 // A thread owns `items` consecutive regions (1 up to a million regions per batch), so the number of tiles stays
 // within what a block reduces by itself whatever the batch.
@@ -96,11 +96,15 @@ __device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {
   const uint32_t nv = (uint32_t)r.q_nvar[q];
   return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q]} : ShareMax{0, 0};
 }
-// rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule), such regions
-struct Scan5 { uint64_t a, u, c, p, s; };
-__device__ __forceinline__ Scan5 operator+(Scan5 x, Scan5 y) { return Scan5{x.a + y.a, x.u + y.u, x.c + y.c, x.p + y.p, x.s + y.s}; }
+// rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule), such
+// regions, runs (maximal stretches of covered sites: a region starts one when no earlier region reaches its first site)
+struct Scan5 { uint64_t a, u, c, p, s, r; };
+__device__ __forceinline__ Scan5 operator+(Scan5 x, Scan5 y) { return Scan5{x.a + y.a, x.u + y.u, x.c + y.c, x.p + y.p, x.s + y.s, x.r + y.r}; }
 __device__ __forceinline__ Scan5 wave_shfl_up5(Scan5 v, int d) {
-  return Scan5{__shfl_up(v.a, d, 64), __shfl_up(v.u, d, 64), __shfl_up(v.c, d, 64), __shfl_up(v.p, d, 64), __shfl_up(v.s, d, 64)};
+  return Scan5{__shfl_up(v.a, d, 64), __shfl_up(v.u, d, 64), __shfl_up(v.c, d, 64), __shfl_up(v.p, d, 64), __shfl_up(v.s, d, 64), __shfl_up(v.r, d, 64)};
+}
+__device__ __forceinline__ Scan5 wave_shfl_xor5(Scan5 v, int d) {
+  return Scan5{__shfl_xor(v.a, d, 64), __shfl_xor(v.u, d, 64), __shfl_xor(v.c, d, 64), __shfl_xor(v.p, d, 64), __shfl_xor(v.s, d, 64), __shfl_xor(v.r, d, 64)};
 }
 __device__ __forceinline__ Scan5 block_exclusive_scan5(Scan5 v, Scan5* total) {
   __shared__ Scan5 wsum[kPlanBlock / 64];
@@ -112,14 +116,14 @@ __device__ __forceinline__ Scan5 block_exclusive_scan5(Scan5 v, Scan5* total) {
   }
   if (lane == 63) wsum[wid] = incl;
   __syncthreads();
-  Scan5 woff{0, 0, 0, 0, 0}, tot{0, 0, 0, 0, 0};
+  Scan5 woff{0, 0, 0, 0, 0, 0}, tot{0, 0, 0, 0, 0, 0};
   for (int w = 0; w < kPlanBlock / 64; ++w) {
     if (w < wid) woff = woff + wsum[w];
     tot = tot + wsum[w];
   }
   __syncthreads();
   *total = tot;
-  return Scan5{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c, woff.p + incl.p - v.p, woff.s + incl.s - v.s};
+  return Scan5{woff.a + incl.a - v.a, woff.u + incl.u - v.u, woff.c + incl.c - v.c, woff.p + incl.p - v.p, woff.s + incl.s - v.s, woff.r + incl.r - v.r};
 }
 // what region q adds to the batch, given the largest site end before it
 struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back, rback, pre_ns; };
@@ -145,6 +149,7 @@ struct PlanTotals {
   uint64_t not_sorted;  // the regions were not sorted by first site: nothing below is meaningful
   uint64_t reported;    // rows over all regions (a shared row once per region reporting it)
   uint64_t n_slow;      // regions under the duplicate rule
+  uint64_t n_runs;      // maximal stretches of covered sites (RunRec)
   uint64_t seq;         // written last, system-scope release: the host spins on it
 };
 
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r,
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) m = smax(m, share_elem(r, base + i));
   ShareMax tot;
   ShareMax ex = smax(block_exclusive_max(m, &tot), pm);
-  Scan5 s{0, 0, 0, 0, 0};
+  Scan5 s{0, 0, 0, 0, 0, 0};
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
     const uint64_t q = base + i;
     const ShareMax el = share_elem(r, q);
@@ -209,29 +214,35 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r,
     const ShareNew w = share_new(im, el.g0, nv, ex.g1);
     s.a += nv; s.u += w.n_new; s.c += w.arena_new;
     if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
+    if (nv && ex.g1 <= el.g0) s.r += 1;           // no earlier region reaches its first site: a run of covered sites starts here
     ex = smax(ex, el);
   }
   Scan5 t5;
   block_exclusive_scan5(s, &t5);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = t5;
 }
-// The per-region deltas that turn "row u of the shared table" into "site g and its arena offset" (k_share_rows2,
-// k_fill_sites2): g = u + dg, car_begin = s_carpre[g] + dc for every row u of the region's new part.
+// Rows of the shared table are in site order, so inside a RUN -- a maximal stretch of covered sites -- row number and
+// site index differ by a constant, and so do a list's arena offset and the site table's arena prefix: one record per
+// run turns "row u" into "site g and its arena offset" (k_share_rows2, k_fill_sites2): g = u + dg, car_begin =
+// s_carpre[g] + dc.  A batch that covers the chromosome has a handful of runs; one of short scattered regions as many
+// as regions.  coarse[k] = the run that owns row k * kCoarseRows (written when there are more than 64 runs).
+struct RunRec { uint64_t u_start, dg, dc, pad_; };
 struct RowDelta { uint64_t dg, dc; };
+constexpr uint32_t kCoarseRows = 64;
 template <bool RESIDENT>
 __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
-                                                         uint64_t* u_begin, RowDelta* delta, uint32_t* slow_list,
+                                                         RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                                          PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
   __shared__ Scan5 red[2][kPlanBlock / 64];
-  Scan5 pre{0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0};
+  Scan5 pre{0, 0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0, 0};
   for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) {
     const Scan5 v = tile_sums[t];
     all = all + v;
     if (t < blockIdx.x) pre = pre + v;
   }
   for (int d = 32; d >= 1; d >>= 1) {
-    pre = pre + Scan5{__shfl_xor(pre.a, d, 64), __shfl_xor(pre.u, d, 64), __shfl_xor(pre.c, d, 64), __shfl_xor(pre.p, d, 64), __shfl_xor(pre.s, d, 64)};
-    all = all + Scan5{__shfl_xor(all.a, d, 64), __shfl_xor(all.u, d, 64), __shfl_xor(all.c, d, 64), __shfl_xor(all.p, d, 64), __shfl_xor(all.s, d, 64)};
+    pre = pre + wave_shfl_xor5(pre, d);
+    all = all + wave_shfl_xor5(all, d);
   }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
   __syncthreads();
@@ -239,15 +250,16 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult 
   all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   const uint64_t U = all.u;
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
-  Scan5 s{0, 0, 0, 0, 0};
+  Scan5 s{0, 0, 0, 0, 0, 0};
   ShareNew w_first{0, 0, 0, 0, 0, 0};   // (items == 1, the usual case: what the region adds is worked out once)
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
     const uint64_t q = base + i;
-    const uint32_t nv = (uint32_t)r.q_nvar[q];
-    const ShareNew w = share_new(im, r.q_g0[q], nv, e_prev[q]);
+    const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q], ep = e_prev[q];
+    const ShareNew w = share_new(im, g0, nv, ep);
     if (i == 0) w_first = w;
     s.a += nv; s.u += w.n_new; s.c += w.arena_new;
     if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
+    if (nv && ep <= g0) s.r += 1;
   }
   Scan5 tot;
   Scan5 ex = block_exclusive_scan5(s, &tot) + pre;
@@ -257,16 +269,19 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult 
     const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q];
     const bool slow = (r.q_flags[q] & kRegionSlow) != 0;
     const ShareNew w = i == 0 ? w_first : share_new(im, g0, nv, e_prev[q]);
-    u_begin[q] = ex.u;
+    const bool run_start = nv && e_prev[q] <= g0;
+    if (run_start) runs[ex.r] = RunRec{ex.u, (uint64_t)g0 - ex.u, RESIDENT ? 0 : ex.c - w.pre_ns, 0};   // (a run starts at the region's first site: ns == g0)
+    if (all.r > 64 && w.n_new) {   // the region's own run, for every kCoarseRows-th row it is the first to cover
+      const uint32_t rid = (uint32_t)(ex.r + (run_start ? 1 : 0) - 1);
+      for (uint64_t m = (ex.u + kCoarseRows - 1) & ~(uint64_t)(kCoarseRows - 1); m < ex.u + w.n_new; m += kCoarseRows) coarse[m / kCoarseRows] = rid;
+    }
     // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
     r.var_begin[q] = slow ? U + ex.p : ex.u - w.rback;
     if (RESIDENT) {   // the lists ARE the index's arena: a site's list lies at s_carpre[g]
       const uint64_t pre0 = nv ? im.s_carpre[g0] : im.s_carpre[0];
-      delta[q] = RowDelta{(uint64_t)w.ns - ex.u, 0};
       r.car_base[q] = pre0;
       r.q_car_len[q] = im.s_carpre[(nv ? g0 : 0u) + nv] - pre0;
     } else {
-      delta[q] = RowDelta{(uint64_t)w.ns - ex.u, ex.c - w.pre_ns};
       r.car_base[q] = ex.c - w.back;
       r.q_car_len[q] = r.q_ncar[q];                  // the region's own padded arena extent
     }
@@ -277,13 +292,14 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult 
     }
     ex.a += nv; ex.u += w.n_new; ex.c += w.arena_new;
     if (slow) { ex.p += nv; ex.s += 1; }
+    if (run_start) ex.r += 1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const uint64_t arena = RESIDENT ? resident_entries : all.c;
-    r.var_begin[r.Q] = all.u + all.p; r.car_base[r.Q] = arena; u_begin[r.Q] = all.u;
+    r.var_begin[r.Q] = all.u + all.p; r.car_base[r.Q] = arena;
     const uint64_t ns = *status;
     totals_host->rows = all.u + all.p; totals_host->arena = arena; totals_host->shared_rows = all.u; totals_host->not_sorted = ns;
-    totals_host->reported = all.a; totals_host->n_slow = all.s;
+    totals_host->reported = all.a; totals_host->n_slow = all.s; totals_host->n_runs = all.r;
     __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -338,60 +354,54 @@ __global__ void __launch_bounds__(256) k_resident_bases(DevImage im, DevResult r
 }
 
 // ---------------------------------------------------------------------------
-// The shared rows, ROW-CENTRIC (round 4): a lane per row of the shared table.  Row u belongs to the region q with
-// u_begin[q] <= u < u_begin[q + 1] (the region that is the first to cover its site); with that region's deltas the row
-// is ONE 32-byte load of the static site row (DevImage::s_row: the row as a resident list would have it), one add, one
-// 32-byte store.  The time follows the rows, not the regions (round 3: one wave per region, eight SoA reads per row).
+// The shared rows, ROW-CENTRIC (round 4): a lane per row of the shared table.  With the record of the run a row lies
+// in, the row is ONE 32-byte load of the static site row (DevImage::s_row: the row as a resident list would have
+// it), one add, one 32-byte store.  The time follows the rows, not the regions (round 3: one wave per region, eight
+// SoA reads per row).
 //
-// shared_row_region: the wave finds the region of its FIRST row by a 64-ary search over u_begin (three dependent loads
-// for 100 k regions), loads the 64 region boundaries behind it together, and every lane counts the boundaries at or
-// below its own row by bisection over the lanes (six ds_bpermute).  A lane whose row lies beyond those 64 boundaries
-// (a run of regions that add nothing) bisects on its own.
+// shared_row_run: the lanes load 64 run records together -- all of them when the batch has at most 64 runs (one load,
+// the same addresses in every wave: cache hits), else the 64 from the run that owns the kCoarseRows-row block of the
+// wave's first row on (coarse index) -- and every lane counts the runs that start at or below its own row by bisection
+// over the lanes (six ds_bpermute).  A lane whose row lies beyond those 64 runs bisects the run table on its own.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shared_row_region(const uint64_t* __restrict__ u_begin, uint64_t Q, uint64_t u_first, uint32_t lane, uint32_t row_in_wave) {
-  // largest q in [0, Q) with u_begin[q] <= u_first   (u_begin[0] == 0, u_begin[Q] == U > u_first)
-  uint64_t lo = 0, hi = Q;
-  while (hi - lo > 1) {
-    const uint64_t step = (hi - lo + 63) / 64;
-    const uint64_t p = lo + (uint64_t)(lane + 1) * step;
-    const bool ok = p < hi && u_begin[p] <= u_first;
-    const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));     // the probes are monotone: a prefix of the lanes says yes
-    const uint64_t nlo = lo + (uint64_t)cnt * step, nhi = lo + (uint64_t)(cnt + 1) * step;
-    lo = nlo; hi = nhi < hi ? nhi : hi;
-  }
-  const uint64_t qf = lo;
-  const uint64_t bi = qf + 1 + lane;
-  const uint64_t b = u_begin[bi < Q ? bi : Q];                 // boundary behind region qf + lane
+__device__ __forceinline__ RowDelta shared_row_run(const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs, uint64_t u_first,
+                                                   uint32_t lane, uint32_t row_in_wave) {
+  const uint64_t base = n_runs <= 64 ? 0 : coarse[u_first / kCoarseRows];   // runs[base].u_start <= u_first
+  const uint64_t i = base + lane;
+  uint4 a{~0u, ~0u, 0, 0}, b{0, 0, 0, 0};
+  if (i < n_runs) { const uint4* p = reinterpret_cast<const uint4*>(runs + i); a = p[0]; b = p[1]; }
+  const uint64_t u_start = ((uint64_t)a.y << 32) | a.x;   // (~0 beyond the table)
   const uint64_t me = u_first + row_in_wave;
-  uint32_t cnt = 0;                                            // boundaries at or below my row, among the first 63
+  uint32_t cnt = 0;                                       // runs of the window that start at or below my row, among the first 63
 #pragma unroll
   for (uint32_t step = 32; step; step >>= 1) {
-    const uint64_t v = __shfl(b, (int)(cnt + step - 1), 64);
+    const uint64_t v = __shfl(u_start, (int)(cnt + step - 1), 64);
     if (v <= me) cnt += step;
   }
-  uint64_t q = qf + cnt;
-  const uint64_t b63 = __shfl(b, 63, 64);
-  if (cnt == 63 && b63 <= me) {                                // beyond the window: plain bisection (rare)
-    uint64_t l2 = qf + 64 < Q ? qf + 64 : Q, h2 = Q;           // u_begin[l2] <= me < u_begin[h2]
-    if (l2 > Q - 1) l2 = Q - 1;
+  if (cnt == 63 && __shfl(u_start, 63, 64) <= me) cnt = 64;
+  const int src = cnt ? (int)cnt - 1 : 0;
+  RowDelta d;
+  d.dg = ((uint64_t)(uint32_t)__shfl((int)a.w, src, 64) << 32) | (uint32_t)__shfl((int)a.z, src, 64);
+  d.dc = ((uint64_t)(uint32_t)__shfl((int)b.y, src, 64) << 32) | (uint32_t)__shfl((int)b.x, src, 64);
+  if (cnt == 64 && base + 64 < n_runs) {                  // maybe beyond the window (many short runs): plain bisection
+    uint64_t l2 = base + 63, h2 = n_runs;                 // runs[l2].u_start <= me < runs[h2].u_start (h2 == n_runs: +inf)
     while (h2 - l2 > 1) {
       const uint64_t m = (l2 + h2) >> 1;
-      if (u_begin[m] <= me) l2 = m; else h2 = m;
+      if (runs[m].u_start <= me) l2 = m; else h2 = m;
     }
-    q = l2;
+    d.dg = runs[l2].dg; d.dc = runs[l2].dc;
   }
-  return q;
+  return d;
 }
 // rows only (resident carrier lists; results whose expansion runs on another stream): u_site receives the site of every row
-__global__ void __launch_bounds__(256) k_share_rows2(DevImage im, DevResult r, const uint64_t* __restrict__ u_begin, const RowDelta* __restrict__ delta,
+__global__ void __launch_bounds__(256) k_share_rows2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
                                                      uint64_t U, uint32_t* u_site) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t u_first = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
   if (u_first >= U) return;
-  const uint64_t q = shared_row_region(u_begin, r.Q, u_first, lane, lane);
+  const RowDelta d = shared_row_run(runs, coarse, n_runs, u_first, lane, lane);
   const uint64_t u = u_first + lane;
   if (u >= U) return;
-  const RowDelta d = delta[q];
   const uint32_t g = (uint32_t)(u + d.dg);
   const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
   uint4 x = src[0], y = src[1];
@@ -401,6 +411,7 @@ __global__ void __launch_bounds__(256) k_share_rows2(DevImage im, DevResult r, c
   dst[0] = x; dst[1] = y;
   if (u_site) u_site[u] = g;
 }
+
 // The reference's "only add var if not seen before" rule (query.h:397-414),
 // literally, for the regions flagged by k_region_bounds.  One thread per region.
 __device__ __forceinline__ void dedup_region(const DevImage& im, const DevResult& r, uint64_t q) {

@@ -63,6 +63,20 @@ __global__ void __launch_bounds__(256) k_build_site_rows(DevImage im, VariantRow
             (im.s_flags[g] & kSiteAlwaysDrop) != 0, im.s_carpre[g]);
 }
 
+// per-slot and per-rank records of the region bounds (DevImage::rp_rec, rk_rec)
+__global__ void __launch_bounds__(256) k_slot_records(DevImage im, uint4* rec) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > im.P) return;
+  const uint64_t c = im.rp_carpre[i], k = im.rp_kpre[i];
+  rec[2 * i] = uint4{im.rp_cand_prefix[i], im.rp_sus_prefix[i], (uint32_t)c, (uint32_t)(c >> 32)};
+  rec[2 * i + 1] = uint4{(uint32_t)k, (uint32_t)(k >> 32), 0u, 0u};
+}
+__global__ void __launch_bounds__(256) k_rank_records(DevImage im, uint2* rec) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > im.R) return;
+  rec[r] = uint2{r < im.R ? im.idx_pos[r] : 0u, im.rank_to_slot[r]};
+}
+
 // nearest earlier site with the same (pos, alt); positions are sorted up to an
 // off-by-one (an insertion reports end-1, everything else end), so the backward
 // scan stops at the first site whose pos < p-1.
@@ -102,23 +116,28 @@ __device__ __forceinline__ RegionBounds region_bounds_of(const DevImage& im, uin
   const uint32_t rx = rank1_finish(lx), ry = rank1_finish(ly);
   const uint32_t R = (uint32_t)im.R, P = (uint32_t)im.P;
   const bool invalid = x < 1;                                            // the reference aborts (index.h:151-154)
-  const uint64_t sel = im.idx_pos[rx < R ? rx : R - 1];                  // select(rank(x) + 1)
+  // rank level: {select(rank + 1), first slot} records; find(x) = rank(x) - 1 is the neighbour of rank(x): one line
+  uint64_t rf = (x >= im.ref_length) ? (uint64_t)R - 1 : (uint64_t)(rx ? rx - 1 : 0);
+  if (rf > (uint64_t)R - 1) rf = (uint64_t)R - 1;
+  const uint2 kx = im.rk_rec[rx < R ? rx : R - 1], kf = im.rk_rec[rf], ky = im.rk_rec[ry < R ? ry : R];
+  const uint64_t sel = kx.x;                                             // select(rank(x) + 1)
   // is_empty: x beyond the reference, select past the last one (defined as empty), or no node start in (.., y]
   const bool empty = x > im.ref_length || rx >= R || !(sel - 1 <= y);
   // find(x): rank(x) >= 1 for every x >= 1 because a node starts at index 1
-  uint64_t rf = (x >= im.ref_length) ? (uint64_t)R - 1 : (uint64_t)(rx ? rx - 1 : 0);
-  if (rf > (uint64_t)R - 1) rf = (uint64_t)R - 1;
-  const uint32_t s0 = im.rank_to_slot[rf];
+  const uint32_t s0 = kf.y;
   // first slot whose node ends at or after y stops the walk; node ends tile the reference, so that is the slot before
   // the first start >= y (rank_to_slot[R] == P)
-  const uint32_t s1raw = im.rank_to_slot[ry < R ? ry : R];
+  const uint32_t s1raw = ky.y;
   uint32_t s1 = s1raw ? s1raw - 1 : 0;
   if (s1 < s0) s1 = s0;
   if (s1 > P) s1 = P;
-  uint32_t g0 = im.rp_cand_prefix[s0], g1 = im.rp_cand_prefix[s1];
+  // slot level: one 32-byte record per end {first site, suspicious sites before it, arena prefix, carrier prefix}
+  const uint4 a0 = im.rp_rec[2 * (uint64_t)s0], a1 = im.rp_rec[2 * (uint64_t)s0 + 1], b0 = im.rp_rec[2 * (uint64_t)s1], b1 = im.rp_rec[2 * (uint64_t)s1 + 1];
+  uint32_t g0 = a0.x, g1 = b0.x;
   // can the "already seen" rule fire inside [g0,g1)?  (g0, g1 are slot boundaries: the list range is tabulated)
-  uint32_t lo = im.rp_sus_prefix[s0], hi = im.rp_sus_prefix[s1];
-  uint64_t pre0 = im.rp_carpre[s0], npad = im.rp_carpre[s1] - pre0, nkept = im.rp_kpre[s1] - im.rp_kpre[s0];
+  uint32_t lo = a0.y, hi = b0.y;
+  uint64_t pre0 = ((uint64_t)a0.w << 32) | a0.z, npad = (((uint64_t)b0.w << 32) | b0.z) - pre0;
+  uint64_t nkept = (((uint64_t)b1.y << 32) | b1.x) - (((uint64_t)a1.y << 32) | a1.x);
   const bool walk = !invalid && !empty && x < y;
   if (!walk) { g0 = 0; g1 = 0; lo = 0; hi = 0; pre0 = 0; npad = 0; nkept = 0; }
   uint8_t fl = invalid ? kRegionInvalid : (empty ? kRegionEmpty : 0);
