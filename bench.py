@@ -335,7 +335,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from variantstore_amd import VariantStore
-    from variantstore_amd.parallel import allgather_hit_lists, shard_bounds
+    from variantstore_amd.parallel import allgather_hit_lists, allgather_region_records, make_comm, shard_bounds
 
     w = WORKLOADS[args.workload]
     strong = args.scaling == "strong"
@@ -372,6 +372,15 @@ def main():
     torch.cuda.synchronize()
 
     in_flight = []   # collectives of earlier steps still running beside this step's kernels: (work handle, tensors kept alive)
+    # The data-path collective goes through the C ABI (vs_comm_allgather_regions: the engine calls ncclAllGather itself, on the
+    # communicator's own stream); torch.distributed only carries the unique id, the barrier and the timing reduction.
+    # VS_BENCH_TORCH_COLLECTIVE=1: rounds 2-3's all_gather_into_tensor instead.
+    torch_collective = os.environ.get("VS_BENCH_TORCH_COLLECTIVE") == "1"
+    comm = make_comm(vs, rank, world) if (use_dist and not torch_collective) else None
+
+    class _CommWork:   # (the wait handle of a vs_comm all-gather: one in flight per communicator)
+        def wait(self):
+            comm.wait()
 
     def step():
         res = vs.get_var_in_ref(regions) if host_regions else vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
@@ -379,8 +388,14 @@ def main():
         if use_dist:
             # the shard sizes are known to every rank without asking (shard_bounds / the fixed per-rank batch); the
             # all-gather of this step's hit lists runs on RCCL's stream beside the next step's kernels, one step deep
-            recs, cnts, work = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True, counts=counts,
-                                                   async_op=True)
+            if comm is not None:
+                while in_flight:                     # (the communicator's send buffer is reused: the previous gather first)
+                    in_flight.pop(0)[0][0].wait()
+                recs, cnts = allgather_region_records(comm, res, region_base, torch.device("cuda", local_rank), counts, async_op=True)
+                work = (_CommWork(), None)
+            else:
+                recs, cnts, work = allgather_hit_lists(res, region_base, torch.device("cuda", local_rank), compact=True, counts=counts,
+                                                       async_op=True)
             in_flight.append((work, recs))
             while len(in_flight) > 1:
                 in_flight.pop(0)[0][0].wait()
@@ -411,28 +426,41 @@ def main():
         ms = done.fill_ms()
         return ms if ms >= 0 else None
 
+    # A batch call returns when the batch is enqueued (engine option async_submit, the default): its timing is read one step
+    # late, from the result's OWN pair of HIP events around the expansion kernel on the stream it ran on -- reading the
+    # handle's events right after the call would wait for the batch and put the host back between the batches.
     prev = None
+    fill_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         res, _g = step()
-        t = vs.last_timing()
-        tot_ms += t.ms_total
-        emit_ms += t.ms_emit
-        if not pipelined:
-            fill_ms += t.ms_fill
         if prev is not None:
-            if pipelined:
-                f = account(prev)
-                fill_ms += f if f is not None else 0.0
-                tot_ms += f if f is not None else 0.0
+            f = account(prev)
+            if f is not None:
+                fill_ms += f
+                fill_steps += 1
             prev.close()
         prev = res
     fence()
     elapsed = time.perf_counter() - t0
-    if pipelined:
-        f = account(res)
-        fill_ms += f if f is not None else 0.0
-        tot_ms += f if f is not None else 0.0
+    f = account(res)
+    if f is not None:
+        fill_ms += f
+        fill_steps += 1
+    if fill_steps == 0:   # (a form without per-result events: private rows -- the handle's events of one more batch)
+        res2, _g = step()
+        fill_ms, fill_steps = vs.last_timing().ms_fill * args.steps, args.steps
+        res2.close()
+    else:
+        fill_ms *= args.steps / fill_steps
+    # phase times of the pipeline (plan, rows, expansion) by the handle's events, from three batches outside the timed region
+    for _i in range(3):
+        r3, _g = step()
+        t = vs.last_timing()
+        tot_ms += t.ms_total * args.steps / 3
+        emit_ms += t.ms_emit * args.steps / 3
+        r3.close()
+    fence()
     vs.set_option("async_fill", 0)
     if use_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -802,7 +830,9 @@ def main():
                                           "site refers to them (its rows are a range of the shared table), as REF/ALT refer to the sequence "
                                           "pool" if lists_shared else None,
                                   "private_rows_and_lists_for_comparison": private},
-                "sharding": f"regions x{world}, index replicated" + (", RCCL all-gatherv of hit lists (per-region site ranges)" if use_dist else ""),
+                "sharding": f"regions x{world}, index replicated" + ((", RCCL all-gatherv of hit lists (per-region site ranges) through "
+                                                                        + ("torch.distributed" if torch_collective else "the C ABI (vs_comm_allgather_regions)"))
+                                                                       if use_dist else ""),
                 "index": {"vertices": info.num_vertices, "csr_edges": info.num_edges_csr, "sites": info.num_sites,
                           "classes": info.num_classes, "carrier_records": info.num_carriers,
                           "hbm_image_bytes": info.device_bytes, "build_s": round(t_build, 1)},
@@ -858,12 +888,17 @@ def main():
             # rank 0, at every N (the other ranks wait in the barrier below): the oracle on one host thread and the parity
             # stamp of this run's own kernels; at N > 1 a shorter sample and no all-cores leg (the other ranks' processes are
             # holding their cores and their copies of the index)
+            if comm is not None:
+                comm.close()
+                comm = None
             vs.close()   # (the slice index of the baseline leg takes its place on the GPU)
             if world > 1:
                 os.environ["VS_BENCH_SKIP_ALLCORES"] = "1"
             out["cpu_baseline"], parity = cpu_baseline(w, local_rank, budget_s=20.0 if world == 1 else 8.0)
             out.update(parity)
         print(json.dumps(out), file=real_stdout, flush=True)
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -98,6 +98,9 @@ typedef struct {
   uint32_t list_max;         /* classes of at most this many carriers are expanded from decoded id lists (16-bit entries up
                               * to 4032 samples, else 32-bit), denser ones from their bit row; 0: explicit-id cohort   */
   uint32_t reserved_;
+  uint64_t t4_rows_bytes;    /* of device_bytes: the per-sample event and hold rows of query type 4 (O(samples x ref-path slots):
+                              * taken when they fit half of the free HBM and 176 GB -- VS_T4_ROWS_MAX_GB in the environment
+                              * lowers the cap; 0: not built, the walks then visit every vertex) */
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);
 /* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */
@@ -218,25 +221,31 @@ typedef struct {
   const uint64_t* row_begin;     /* [n_regions] first table row of each region */
   const uint64_t* row_count;     /* [n_regions] rows it reports (including dropped ones) */
   const uint64_t* var_count;     /* [n_regions] variants the reference reports */
-  const uint64_t* car_base;      /* [n_regions] arena offset of the region's first row */
-  const uint64_t* car_len;       /* [n_regions] arena extent of the region's rows */
+  const uint64_t* car_base;      /* [n_regions] arena offset of the region's first row (NULL: shared bit 2) */
+  const uint64_t* car_len;       /* [n_regions] arena extent of the region's rows (NULL: shared bit 2) */
   uint64_t n_rows;
   const vs_variant_row* rows;    /* [n_rows], page-locked */
   uint64_t arena_entries;
   uint32_t carrier_bytes;        /* 2 or 4 */
   const void* arena;             /* [arena_entries], page-locked; NULL when carriers were not copied */
   const char* seq_pool;
-  int shared;                    /* bit 0: rows and lists shared between regions (vs_result_layout); bit 1: `arena` is the
+  int shared;                    /* bit 2: lists shared per VERTEX (query types 4 / 5): a region's carriers are not one arena
+                                  * range -- car_base / car_len are NULL, rows[].car_begin alone addresses the lists;
+                                  * bit 0: rows and lists shared between regions (vs_result_layout); bit 1: `arena` is the
                                   * handle's host mirror of the index's RESIDENT carrier lists ("resident_lists"): nothing
                                   * but the rows was copied for this result, and the pointer stays valid until the index
                                   * is closed */
 } vs_result_raw;
 int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw);
 
-/* Option "async_fill" (vs_index_set_option): a type-6 batch call returns as soon as rows and per-region arrays are in
- * HBM, while the carrier expansion still runs on the handle's second stream -- the next batch's bounds, scans and rows
- * then run beside it.  Every accessor that reads carriers waits for the expansion by itself; vs_result_fill_ms reports
- * its duration (HIP events on the stream it ran on; -1 when the expansion was not asynchronous). */
+/* Duration of the result's carrier expansion by its OWN pair of HIP events on the stream the kernel ran on (waits for the
+ * kernel): every type-6 batch that shares rows and lists carries one, as does every "async_fill" batch; -1 for the other
+ * result forms (vs_index_last_timing().ms_fill has it then).
+ * "async_submit" (default 1): a type-6 batch of more than 64 regions returns when it is ENQUEUED -- sizes known, buffers
+ * allocated, last kernel launched.  Everything that reads the result is ordered behind the batch on the handle's stream
+ * (copies, digests, packs, the collective) or waits for it (this call, vs_index_last_timing); freeing it early is safe.
+ * "async_fill" (default 0): the call returns as soon as rows and per-region arrays are in HBM while the expansion runs
+ * on the handle's second stream beside the next batch's plan and rows; accessors that read carriers wait by themselves. */
 int vs_result_fill_ms(vs_result* r, float* ms);
 
 /* Type 6 with delivery: the (sorted) batch is answered in chunks of `chunk_regions`, and while one chunk is computed the
@@ -281,19 +290,52 @@ int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_rec
                            uint64_t* n_records);
 void vs_result_free(vs_result* r);
 
-/* ---- switches of one handle (tests and tuning; nothing here is needed in production) ----
+/* ---- multi-GPU: the hit-list collective (one process per GPU, RCCL over xGMI) ----
+ * north_star: "a batch of thousands of independent region queries shards trivially across the 8 GPUs of one node with
+ * an RCCL all-gatherv of hit lists over xGMI".  The reference's loop over the regions is serial and single-process
+ * (src/commands.cc:145); these entry points are what its query_main would call once per batch after sharding the sorted
+ * region list into contiguous pieces.  RCCL is loaded at run time: VS_ERR_UNSUPPORTED when
+ * no librccl.so can be found.
+ *   vs_comm_unique_id   rank 0 makes the id (VS_COMM_ID_BYTES bytes) and hands it to the other ranks by whatever means
+ *                       the host program has (a file, a pipe, MPI, a torch broadcast)
+ *   vs_comm_init        every rank, with the handle whose device it computes on (ncclCommInitRank: collective)
+ *   vs_comm_allgather_regions   packs the result's per-region records (vs_result_pack_regions' format) and all-gathers
+ *                       them, padded to max_count records per rank: device_dst receives world x max_count records, rank k's
+ *                       at record k * max_count, of which the first (regions of rank k) are valid.  async_op != 0: returns
+ *                       once the collective is enqueued (on the communicator's own stream, behind the result's kernels);
+ *                       vs_comm_wait -- or the next vs_comm_allgather_regions -- waits for it.
+ *   Any rank can then rebuild rows and carrier lists of the whole batch from the records: vs_query_expand_site_ranges. */
+#define VS_COMM_ID_BYTES 128
+typedef struct vs_comm vs_comm;
+int vs_comm_unique_id(void* id_out);
+int vs_comm_init(vs_index* idx, int rank, int world, const void* id, vs_comm** out);
+int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, uint64_t max_count, void* device_dst, int async_op);
+/* the same into HOST memory (world x max_count records; synchronous) for callers that hold no device memory of their own */
+int vs_comm_allgather_regions_host(vs_comm* c, vs_result* r, uint64_t region_base, uint64_t max_count, void* host_dst);
+int vs_comm_wait(vs_comm* c);
+void vs_comm_destroy(vs_comm* c);
+
+/* ---- switches of one handle ----
  * The environment is read once when a handle is opened; afterwards only this call changes a
- * switch.  Keys: "latency_server" 0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first
- * small query; "server_blocks" 1..64; "t4_skip" 0 = query type 4 walks every vertex of the sample's path (the literal
- * form the event bitmaps shortcut); "fill_chunk" 0 / 16 / 64 variant slots per wave task of the carrier expansion (0 =
- * chosen from the batch's shape); "share_lists" 0 = every region gets private rows and carrier lists even in a sorted
- * batch, 1 (default) = shared when the handle's last shared batch showed that it pays, 2 = shared whether or not it pays; "t4_coop" 8 (default) / 16 lanes per region in the type-4 walk, 0 = one lane per region; "t4_two_walks", "seq_two_walks" force the count-then-emit fallbacks; "lat_debug";
- * "async_fill" 1 = the carrier expansion of a type-6 batch runs on a second stream and the call returns while it is in
- * flight (see vs_result_fill_ms; default 0); "resident_lists" 1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
- * 4 bytes per carrier record; VS_ERR_UNSUPPORTED when that does not fit): batches of query types 6 and 4 then emit rows
- * that point into it, expand nothing and own no arena, and a raw copy moves the rows only (default 0; VS_RESIDENT_LISTS=1
- * in the environment builds it when the handle is opened);
- * "fill_ablate", "fill_lds_pad" (tuning builds only, VS_ERR_UNSUPPORTED otherwise). */
+ * switch.  The production library has EIGHT keys:
+ *   "latency_server"  0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first small query
+ *   "server_blocks"   1..64 blocks of the resident server
+ *   "share_lists"     1 (default): a type-6 batch of more than 64 regions holds one row and one carrier list per covered
+ *                     site, shared by the regions that report it (type 4 / 5: one list per reported vertex); 0: private rows
+ *                     and lists per region
+ *   "resident_lists"  1 = expand every carrier list of the index ONCE into an arena that stays in HBM with the handle (2 or
+ *                     4 bytes per carrier record; VS_ERR_UNSUPPORTED when that does not fit): batches of query types 6 and 4
+ *                     then emit rows that point into it, expand nothing and own no arena, and a raw copy moves the rows only
+ *                     (default 0; VS_RESIDENT_LISTS=1 in the environment builds it when the handle is opened)
+ *   "async_submit"    see vs_result_fill_ms (default 1)
+ *   "async_fill"      see vs_result_fill_ms (default 0)
+ *   "t4_walk"         the walk of query type 4: 2 cooperative (8 lanes per region; default), 1 one lane per region jumping
+ *                     over uneventful ref-path runs, 0 literal (every vertex of the sample's path)
+ *   "force_fallbacks" 1 = query types 2 - 5 take the count-then-emit pair of walks they fall back to when a region outgrows
+ *                     the capacity of its recording walk (tests of that path)
+ * Tuning builds (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) add "lat_debug", "fill_fused", "fill_chunk",
+ * "fill_stats", "walk_stats", "fill_ablate", "fill_lds_pad"; VS_ERR_UNSUPPORTED in the production library, whose kernels
+ * do not carry the code. */
 int vs_index_set_option(vs_index* idx, const char* key, int64_t value);
 
 /* ---- timing of the last batch on this handle ----

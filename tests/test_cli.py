@@ -192,3 +192,27 @@ def test_query_batch_file_with_resident_lists(golden_dir, tmp_path):
         assert texts[0][1].count("#region ") == 150
         outs.append(texts[0][1])
     assert outs[0] != outs[1]
+
+
+@pytest.mark.gpu
+def test_query_nprocs_form_matches_the_single_process(golden_dir, tmp_path):
+    """`--nprocs 1`: the multi-process form of the drop-in CLI at world size 1 -- the parent forks before anything touches
+    the GPU, the rank answers its shard, the per-region records go through the C ABI's own collective (vs_comm_*: RCCL)
+    and the log lines are printed from the GATHERED records: same count lines, same --batch-out text as the plain form."""
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    rfile = str(tmp_path / "regions.txt")
+    with open(rfile, "w") as f:
+        for i in range(120):
+            f.write(f"{1 + 11 * i}:{1 + 11 * i + 35 + (i % 5) * 40}\n")
+    got = []
+    for flag in ([], ["--nprocs", "1"]):
+        bfile = str(tmp_path / f"b{len(flag)}.txt")
+        out = subprocess.run([CLI, "query", "-p", d, "-t", "6", "-r", "@" + rfile, "-m", "1", "-o", str(tmp_path / "o.txt"),
+                              "--batch-out", bfile] + flag, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = [ln for ln in out.stdout.split("\n") if ln.startswith("Number of variants")]
+        msgs = [m for m in _msgs(out.stdout) if m.startswith("6. Get variants")]
+        assert len(lines) == 120 and len(msgs) == 120
+        got.append((lines, msgs, open(bfile).read()))
+    assert got[0] == got[1]

@@ -90,9 +90,9 @@ def test_bench_cohort_shape_type4_matches_oracle(chr1_slice, skip):
     nreg = 4000 if skip else 1500
     regions = bench.make_regions(sub, 777, nreg)
     per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)
-    vs.set_option("t4_skip", skip)
+    vs.set_option("t4_walk", 2 if skip else 0)     # the cooperative walk over the event bitmaps / the literal walk
     res = vs.get_sample_var_in_ref(regions, per_region)
-    vs.set_option("t4_skip", 1)
+    vs.set_option("t4_walk", 2)
     view = res.view(with_carriers=False)
     nvar = 0
     for q, (x, y) in enumerate(regions):

@@ -70,3 +70,45 @@ def test_gathered_site_ranges_expand_to_the_local_result(nccl_world1, tmp_path):
     assert np.array_equal(rows["pos"], v["pos"]) and np.array_equal(rows["car_count"], v["car_count"])
     local.close()
     vs.close()
+
+
+def test_c_abi_collective_round_trip(tmp_path):
+    """The same round trip through the C ABI's own collective (vs_comm_*: the engine calls RCCL directly, no torch.distributed):
+    world size 1, real records -> vs_comm_allgather_regions (synchronous, then asynchronous with vs_comm_wait) ->
+    vs_query_expand_site_ranges -> the local result and the oracle's text.  The unique id travels through a file, as it
+    would between the processes of the CLI's --nprocs form."""
+    import torch
+    from variantstore_amd.parallel import allgather_region_records, make_comm, unpack_region_records
+    fasta, vcf, _ = write_random_cohort(str(tmp_path), 412, n_rows=400, ref_len=6000, n_samples=90, carrier_p=0.35,
+                                        p_near=0.6, p_multi=0.25, p_same=0.3)
+    vs = VariantStore.from_vcf(fasta, vcf, device=0)
+    plain = os.path.join(tmp_path, "plain.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    regions = sorted(random_regions(np.random.default_rng(6), vs.info().ref_length, 400))
+    dev = torch.device("cuda", 0)
+    comm = make_comm(vs, 0, 1, id_file=os.path.join(tmp_path, "uid"))
+    local = vs.get_var_in_ref(regions)
+    for async_op in (False, True):
+        gathered, cnt = allgather_region_records(comm, local, 0, dev, [len(regions)], async_op=async_op)
+        if async_op:
+            comm.wait()
+        rec = unpack_region_records(gathered, cnt)[0]
+        assert np.array_equal(rec["region"], np.arange(len(regions), dtype=np.uint64))
+        assert int(rec["variants"].sum()) == local.totals()[1] and int(rec["carriers"].sum()) == local.totals()[2]
+        back = vs.expand_site_ranges(gathered[0].contiguous().data_ptr(), len(regions))
+        assert back.totals() == local.totals() and back.digest() == local.digest()
+        for q, (x, y) in enumerate(regions):
+            n, _, text = orc.get_var_in_ref(x, y)
+            if n >= 0:
+                assert back.region_text(q) == local.region_text(q) == text, (q, x, y)
+        back.close()
+    # a padded gather: max_count larger than this rank's count, the tail is never read
+    out = torch.zeros((len(regions) + 7, 4), dtype=torch.int64, device=dev)
+    comm.allgather_regions(local, 1000, len(regions) + 7, out.data_ptr())
+    assert int(out[0, 0]) == 1000 and int(out[len(regions) - 1, 0]) == 1000 + len(regions) - 1
+    with pytest.raises(Exception):
+        comm.allgather_regions(local, 0, len(regions) - 1, out.data_ptr())     # max_count below this rank's count
+    comm.close()
+    local.close()
+    vs.close()

@@ -150,19 +150,18 @@ def test_type4_event_bitmap_walk_equals_the_literal_walk_at_full_size(big):
     fast = vs.get_sample_var_in_ref(regions, sids)
     tf, df = fast.totals(), fast.digest()
     assert tf[1] > 500_000
-    for coop in (16, 0):                      # the 16-lane groups and the one-lane-per-region form of the same walk
-        vs.set_option("t4_coop", coop)
-        try:
-            other = vs.get_sample_var_in_ref(regions, sids)
-        finally:
-            vs.set_option("t4_coop", 8)
-        assert (other.totals(), other.digest()) == (tf, df), coop
-        other.close()
-    vs.set_option("t4_skip", 0)
+    vs.set_option("t4_walk", 1)               # the one-lane-per-region form of the same walk (jumps, no groups)
+    try:
+        other = vs.get_sample_var_in_ref(regions, sids)
+    finally:
+        vs.set_option("t4_walk", 2)
+    assert (other.totals(), other.digest()) == (tf, df)
+    other.close()
+    vs.set_option("t4_walk", 0)               # the literal walk: every vertex of the sample's path
     try:
         slow = vs.get_sample_var_in_ref(regions, sids)
     finally:
-        vs.set_option("t4_skip", 1)
+        vs.set_option("t4_walk", 2)
     assert (slow.totals(), slow.digest()) == (tf, df)
     for q in (0, 17, 50_001, 99_999):
         assert fast.region_text(q) == slow.region_text(q)

@@ -729,14 +729,14 @@ def test_tcga_shaped_cohort_mixed_types(tmp_path):
     sub = sorted(regions[:240])
     per = [carriers[i % len(carriers)] for i in range(len(sub))]
     want4 = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(sub, per)]
-    for coop in (8, 16, 0):
-        vs.set_option("t4_coop", coop)
+    for walk in (2, 1):
+        vs.set_option("t4_walk", walk)
         r4 = vs.get_sample_var_in_ref(sub, per)
         for q, (n, _, text) in enumerate(want4):
             if n >= 0:
-                assert r4.region_text(q) == text, (coop, q, sub[q], per[q])
+                assert r4.region_text(q) == text, (walk, q, sub[q], per[q])
         r4.close()
-    vs.set_option("t4_coop", 8)
+    vs.set_option("t4_walk", 2)
     r5 = vs.get_sample_var_in_sample(sub, per)
     f5 = r5.view(False)["region_flags"]
     for q, ((x, y), sm) in enumerate(zip(sub, per)):
@@ -951,15 +951,15 @@ def test_type4_regions_that_outgrow_their_scratch_capacity(tmp_path):
     L = vs.info().ref_length
     regions = [(int(x), int(x) + int(rng.integers(0, 6))) for x in rng.integers(1, L, size=300)]
     per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
-    for coop in (8, 16, 0):
-        vs.set_option("t4_coop", coop)
+    for walk in (2, 1):
+        vs.set_option("t4_walk", walk)
         res = vs.get_sample_var_in_ref(regions, per)
         for q, (x, y) in enumerate(regions):
             n, _, text = orc.get_sample_var_in_ref(x, y, per[q])
             if n >= 0:
-                assert res.region_text(q) == text, (coop, q, x, y, per[q])
+                assert res.region_text(q) == text, (walk, q, x, y, per[q])
         res.close()
-    vs.set_option("t4_coop", 8)
+    vs.set_option("t4_walk", 2)
     # and a batch of ordinary regions right afterwards (the claims' generation moves on)
     regions = sorted(random_regions(rng, L, 200, max_len=700))
     per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
@@ -990,7 +990,7 @@ def test_async_fill_results_are_the_same(tmp_path):
         n, _, text = orc.get_var_in_ref(x, y)
         if n >= 0:
             assert small.region_text(q) == text
-    assert flight[2].fill_ms() >= 0 and sync[2].fill_ms() == -1
+    assert flight[2].fill_ms() >= 0 and sync[2].fill_ms() >= 0   # (round 4: every shared batch carries its own pair of events around its expansion)
     for k in (2, 0, 1):
         assert (flight[k].digest(), flight[k].totals()) == want[k]
         for q in range(0, len(batches[k]), 9):
@@ -1025,16 +1025,14 @@ def test_type4_long_backward_searches(seed, n_samples, carrier_p, tmp_path):
     per = [names[int(i)] for i in rng.integers(0, len(names), size=len(regions))]
     want = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(regions, per)]
     assert sum(1 for n, _, _ in want if n >= 0) > 200
-    for coop, skip in ((8, 1), (16, 1), (0, 1), (0, 0)):
-        vs.set_option("t4_coop", coop)
-        vs.set_option("t4_skip", skip)
+    for walk in (2, 1, 0):                        # cooperative, one lane per region with jumps, literal
+        vs.set_option("t4_walk", walk)
         res = vs.get_sample_var_in_ref(regions, per)
         for q, (n, _, text) in enumerate(want):
             if n >= 0:
-                assert res.region_text(q) == text, (coop, skip, q, regions[q], per[q])
+                assert res.region_text(q) == text, (walk, q, regions[q], per[q])
         res.close()
-    vs.set_option("t4_coop", 8)
-    vs.set_option("t4_skip", 1)
+    vs.set_option("t4_walk", 2)
     r5 = vs.get_sample_var_in_sample(regions, per)
     f5 = r5.view(False)["region_flags"]
     for q, ((x, y), sm) in enumerate(zip(regions, per)):

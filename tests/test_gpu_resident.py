@@ -107,8 +107,8 @@ def test_type4_over_resident_lists(seed, kw, tmp_path):
     names = [vs.sample_name(int(i)) for i in rng.integers(1, ns, size=len(regions))]
     before = vs.get_sample_var_in_ref(regions, names)
     vs.set_option("resident_lists", 1)
-    for coop in (8, 16, 0):
-        vs.set_option("t4_coop", coop)
+    for coop in (2, 1):
+        vs.set_option("t4_walk", coop)
         res = vs.get_sample_var_in_ref(regions, names)
         assert res.layout()[2] == 0
         assert res.digest() == before.digest() and res.totals() == before.totals()
@@ -120,16 +120,16 @@ def test_type4_over_resident_lists(seed, kw, tmp_path):
         for key in va:
             assert np.array_equal(va[key], vb[key]), (coop, key)
         res.close()
-    vs.set_option("t4_coop", 8)
+    vs.set_option("t4_walk", 2)
     # one sample for the whole batch, and the count-then-emit fallback (keeps a private arena)
     one = vs.get_sample_var_in_ref(regions, names[0])
     for q, (x, y) in enumerate(regions[:60]):
         n, _, text = orc.get_sample_var_in_ref(x, y, names[0])
         if n >= 0:
             assert one.region_text(q) == text
-    vs.set_option("t4_two_walks", 1)
+    vs.set_option("force_fallbacks", 1)
     two = vs.get_sample_var_in_ref(regions, names)
-    vs.set_option("t4_two_walks", 0)
+    vs.set_option("force_fallbacks", 0)
     assert two.layout()[2] > 0 and two.digest() == before.digest()
 
 

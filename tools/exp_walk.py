@@ -21,7 +21,7 @@ per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)
 digests = {}
 for skip, coop in ((1, 16), (1, 8), (1, 0), (0, 0)):
     vs.set_option("t4_skip", skip)
-    vs.set_option("t4_coop", coop)
+    vs.set_option("t4_walk", 2 if coop else 1)
     try:
         vs.set_option("walk_stats", 1)
     except Exception as e:

@@ -17,8 +17,7 @@ regions = bench.make_regions(w, 0, nreg)
 ns = vs.info().num_samples
 sids16 = [1 + (i * 157) % (ns - 1) for i in range(16)]
 per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)
-vs.set_option("t4_coop", int(os.environ.get("VS_T4_COOP", "1")))
-vs.set_option("t4_skip", int(os.environ.get("VS_T4_SKIP", "1")))
+vs.set_option("t4_walk", int(os.environ.get("VS_T4_WALK", "2")))
 for _ in range(5):
     r = vs.get_sample_var_in_ref(regions, per_region)
     t = vs.last_timing()

@@ -98,10 +98,9 @@ for c in range(n_cohorts):
         # type 4 with one sample per region, through the cooperative walk, the serial walk and the literal (no-jump) walk
         per = [names[int(i)] for i in rng.integers(0, len(names), size=100)]
         want4 = [orc.get_sample_var_in_ref(x, y, sm) for (x, y), sm in zip(regions[:100], per)]
-        for coop, skip in ((8, 1), (16, 1), (0, 1), (0, 0)):
-            vs.set_option("t4_coop", coop)
-            vs.set_option("t4_skip", skip)
-            stage(f"type 4 coop {coop} skip {skip}")
+        for coop, skip in ((2, 1), (1, 1), (0, 0)):
+            vs.set_option("t4_walk", coop)
+            stage(f"type 4 walk {coop}")
             rm = vs.get_sample_var_in_ref(regions[:100], per)
             for q, (n, early, text) in enumerate(want4):
                 if n < 0:
@@ -111,8 +110,7 @@ for c in range(n_cohorts):
                     bad += 1
                     print(f"MISMATCH t4 (coop {coop} skip {skip}) cohort {seed} sample {per[q]} region {regions[q]}")
             rm.close()
-        vs.set_option("t4_coop", 1)
-        vs.set_option("t4_skip", 1)
+        vs.set_option("t4_walk", 2)
         # resident carrier lists: the whole unsorted batch, its sorted form and the type-4 batch again, rows only
         stage("resident lists")
         vs.set_option("resident_lists", 1)

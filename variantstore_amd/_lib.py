@@ -33,7 +33,8 @@ class IndexInfo(C.Structure):
                 ("ref_path_nodes", C.c_uint64), ("index_nodes", C.c_uint64), ("num_classes", C.c_uint64),
                 ("num_sites", C.c_uint64), ("num_carriers", C.c_uint64), ("seq_length", C.c_uint64),
                 ("num_samples", C.c_uint32), ("use_bit_vector", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("device", C.c_int), ("num_topology_keys", C.c_uint64), ("list_max", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("device", C.c_int), ("num_topology_keys", C.c_uint64), ("list_max", C.c_uint32), ("reserved_", C.c_uint32),
+                ("t4_rows_bytes", C.c_uint64)]
 
 
 class ResultView(C.Structure):
@@ -111,6 +112,12 @@ SYMBOLS = {
     "vs_result_pack_headers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vs_result_pack_regions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vs_result_free": (None, [_P]),
+    "vs_comm_unique_id": (C.c_int, [_P]),
+    "vs_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "vs_comm_allgather_regions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int]),
+    "vs_comm_allgather_regions_host": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
+    "vs_comm_wait": (C.c_int, [_P]),
+    "vs_comm_destroy": (None, [_P]),
     "vs_index_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "vs_index_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
 }

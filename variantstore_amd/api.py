@@ -152,7 +152,7 @@ class QueryResult:
                 "row_count": arr(rr.row_count, q, np.uint64), "var_count": arr(rr.var_count, q, np.uint64),
                 "car_base": arr(rr.car_base, q, np.uint64), "car_len": arr(rr.car_len, q, np.uint64),
                 "rows": rows, "arena": arena, "carrier_bytes": int(rr.carrier_bytes), "shared": bool(rr.shared & 1),
-                "resident": bool(rr.shared & 2)}
+                "resident": bool(rr.shared & 2), "scattered": bool(rr.shared & 4)}
 
     def num_header_records(self):
         n = C.c_uint64()
@@ -199,6 +199,48 @@ class QueryResult:
                     pairs.append((name, gt))
             out.append(Variant(int(pos), ref, alt, pairs))
         return out
+
+
+class Comm:
+    """The hit-list collective of one rank (vs_comm_*: RCCL called directly by the engine, no torch.distributed).
+    `Comm.unique_id()` on rank 0, the 128 bytes handed to every rank by whatever means the host program has, then
+    `Comm(store, rank, world, uid)` on every rank."""
+
+    def __init__(self, store, rank, world, uid):
+        self._lib = store._lib
+        self._store = store     # (keeps the index handle alive)
+        self.rank, self.world = int(rank), int(world)
+        buf = C.create_string_buffer(bytes(uid), 128)
+        h = C.c_void_p()
+        _check(self._lib.vs_comm_init(store._h, self.rank, self.world, C.cast(buf, C.c_void_p), C.byref(h)), "vs_comm_init")
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        _check(lib.vs_comm_unique_id(C.cast(buf, C.c_void_p)), "vs_comm_unique_id")
+        return bytes(buf.raw)
+
+    def allgather_regions(self, result, region_base, max_count, device_dst, async_op=False):
+        """Pack `result`'s per-region records and all-gather them, padded to max_count per rank, into device memory at
+        `device_dst` (world x max_count x 32 bytes; rank k's records start at record k * max_count)."""
+        _check(self._lib.vs_comm_allgather_regions(self._h, result._h, int(region_base), int(max_count), C.c_void_p(int(device_dst)),
+                                                   1 if async_op else 0), "vs_comm_allgather_regions")
+
+    def wait(self):
+        _check(self._lib.vs_comm_wait(self._h), "vs_comm_wait")
+
+    def close(self):
+        if self._h:
+            self._lib.vs_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class VariantStore:

@@ -13,11 +13,19 @@
 //   --device N          GPU ordinal (default 0)
 //   --resident-lists    expand every carrier list of the index once, when it is opened, into an arena that stays in
 //                       HBM (vs_index_set_option "resident_lists"): batches then copy rows only across PCIe
+//   --nprocs N          query type 6 as N PROCESSES, one per GPU (device .. device + N - 1): the parent forks before anything
+//                       touches a GPU, every rank answers its contiguous shard, the ranks all-gather the per-region hit-list
+//                       records through the C ABI's collective (vs_comm_*: RCCL over xGMI; the unique id travels through a
+//                       file) and rank 0 prints the log lines of ALL regions from the gathered records; --batch-out text is
+//                       written per rank and concatenated in rank order.  --ngpus (threads in one process, no collective)
+//                       remains the fallback.
 //   --ngpus N           shard the sorted region list over GPUs device .. device + N - 1 (query types 4, 5, 6): one handle
 //                       and one host thread per GPU, contiguous shards (the reference's serial loop, commands.cc:145,
 //                       carries no state between regions), results printed in region order
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -102,7 +110,7 @@ struct Args {
   uint64_t hops = 0;
   bool have_hops = false;
   bool have_type = false, have_mode = false, verbose = false;
-  int device = 0, ngpus = 1;
+  int device = 0, ngpus = 1, nprocs = 0;
   bool resident_lists = false;
 };
 
@@ -111,7 +119,7 @@ int usage() {
                "        variantstore construct -r <reference-file> -v <vcf-file> -p <output-prefix>\n"
                "        variantstore query -p <output-prefix> -t <query-type> -r <region> -m <mode> [-o <outfile>]\n"
                "                     [-s <sample-name>] [-a <alt-seq>] [-b <ref-seq>] [-v]\n"
-               "                     [--batch-out <file>] [--device <n>] [--ngpus <n>] [--resident-lists]\n"
+               "                     [--batch-out <file>] [--device <n>] [--ngpus <n>] [--nprocs <n>] [--resident-lists]\n"
                "        variantstore draw -p <output-prefix> -r <region> -h <hops> [-s <sample-name>]\n"
                "        variantstore help\n\n"
                "OPTIONS\n"
@@ -314,7 +322,136 @@ int draw_main(const Args& a) {
   return EXIT_SUCCESS;
 }
 
+// `--nprocs N`: one process per GPU and the hit-list collective of the C ABI (see the header comment).
+int query_multiproc_main(const Args& a) {
+  auto regions = read_regions(a.region);
+  std::vector<vs_region> batch;
+  for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
+  const int world = (int)std::min<size_t>((size_t)a.nprocs, std::max<size_t>(batch.size(), 1));
+  char tmpl[] = "/tmp/vs_nprocs_XXXXXX";
+  if (!mkdtemp(tmpl)) { error("cannot create a temporary directory"); return EXIT_FAILURE; }
+  const std::string dir = tmpl, uid_file = dir + "/uid";
+  auto shard = [&](int k, size_t* lo, size_t* hi) {
+    const size_t base = batch.size() / world, rem = batch.size() % world;
+    *lo = k * base + std::min<size_t>(k, rem);
+    *hi = *lo + base + ((size_t)k < rem ? 1 : 0);
+  };
+  size_t max_count = 0;
+  for (int k = 0; k < world; ++k) { size_t lo, hi; shard(k, &lo, &hi); max_count = std::max(max_count, hi - lo); }
+  std::vector<pid_t> kids;
+  fflush(stdout);
+  for (int rank = 0; rank < world; ++rank) {
+    const pid_t pid = fork();   // (nothing in this process has touched a GPU)
+    if (pid < 0) { error("fork failed"); return EXIT_FAILURE; }
+    if (pid > 0) { kids.push_back(pid); continue; }
+    // ---- rank `rank` ----
+    struct timeval start, end;
+    if (rank == 0) { info("Loading Index ..."); info("Loading variant graph ..."); info(a.mode == 0 ? "Read index only .." : "Read complete graph .."); }
+    vs_index* idx = nullptr;
+    int rc = vs_index_open(a.prefix.c_str(), a.device + rank, &idx);
+    if (rc != VS_OK) die(rc, "load");
+    if (rank == 0) {
+      vs_index_info inf;
+      vs_index_get_info(idx, &inf);
+      info("Graph stats:");
+      info(std::string("Chromosome: ") + vs_index_chr(idx) + " #Vertices: " + std::to_string(inf.num_topology_keys) +
+           " #Edges: 0 Seq length: " + std::to_string(inf.seq_length));
+    }
+    if (a.resident_lists && vs_index_set_option(idx, "resident_lists", 1) != VS_OK)
+      log_line("warning", std::string("--resident-lists: ") + vs_last_error() + " (lists are expanded per batch)");
+    // the communicator: rank 0 makes the unique id, the others wait for its file
+    unsigned char uid[VS_COMM_ID_BYTES];
+    if (rank == 0) {
+      rc = vs_comm_unique_id(uid);
+      if (rc != VS_OK) die(rc, "vs_comm_unique_id");
+      std::ofstream f(uid_file + ".tmp", std::ios::binary);
+      f.write((const char*)uid, sizeof(uid));
+      f.close();
+      rename((uid_file + ".tmp").c_str(), uid_file.c_str());
+    } else {
+      for (int tries = 0;; ++tries) {
+        std::ifstream f(uid_file, std::ios::binary);
+        if (f && f.read((char*)uid, sizeof(uid))) break;
+        if (tries > 60000) { error("no unique id from rank 0"); _exit(EXIT_FAILURE); }
+        usleep(2000);
+      }
+    }
+    vs_comm* comm = nullptr;
+    rc = vs_comm_init(idx, rank, world, uid, &comm);
+    if (rc != VS_OK) die(rc, "vs_comm_init");
+    size_t lo, hi;
+    shard(rank, &lo, &hi);
+    gettimeofday(&start, nullptr);
+    vs_result* res = nullptr;
+    rc = vs_query_var_in_ref(idx, batch.data() + lo, hi - lo, &res);
+    if (rc != VS_OK) die(rc, "query");
+    std::vector<uint64_t> recs((size_t)world * max_count * 4);
+    rc = vs_comm_allgather_regions_host(comm, res, lo, max_count, recs.data());
+    if (rc != VS_OK) die(rc, "vs_comm_allgather_regions_host");
+    if (!a.batch_out.empty()) {   // this rank's shard of the text
+      std::ofstream out(dir + "/out." + std::to_string(rank));
+      for (size_t k = 0; k < hi - lo; ++k) {
+        const char* text; uint64_t len;
+        if (vs_result_format_region(res, k, &text, &len) == VS_OK) {
+          out << "#region " << (lo + k) << " " << batch[lo + k].x << ":" << batch[lo + k].y << "\n";
+          out.write(text, len);
+        }
+      }
+    }
+    if (a.verbose && hi == batch.size() && hi > lo) {   // the -o file holds the last region (query.h:774-781)
+      const char* text; uint64_t len;
+      if (vs_result_format_region(res, hi - lo - 1, &text, &len) == VS_OK) { std::ofstream out(a.outfile); out.write(text, len); }
+    }
+    int status = EXIT_SUCCESS;
+    if (rank == 0) {   // the log lines of every region, from the gathered records
+      uint32_t query_num = 0;
+      for (int k = 0; k < world && status == EXIT_SUCCESS; ++k) {
+        size_t klo, khi;
+        shard(k, &klo, &khi);
+        for (size_t j = 0; j < khi - klo; ++j) {
+          const uint64_t* rec = &recs[((size_t)k * max_count + j) * 4];
+          const uint64_t i = rec[0], flags = (rec[1] >> 32) & 0xFF, nvar = rec[2] >> 32;
+          info("6. Get variants in ref coordinate. " + std::to_string(i));
+          if (flags & VS_REGION_INVALID) { error("Can't find node corresponding to pos " + std::to_string(batch[i].x)); status = EXIT_FAILURE; break; }
+          const char* label = !(flags & VS_REGION_EMPTY) ? "get_var_in_ref" : "get_sample_var_in_ref";   // query.h:746
+          std::cout << "Number of variants " << label << ": " << nvar << '\n';
+          query_num += 1;
+          if (query_num == 10 || query_num == 100 || query_num == 1000) {
+            gettimeofday(&end, nullptr);
+            print_time_elapsed("Query" + std::to_string(query_num) + ": ", start, end);
+          }
+        }
+      }
+      gettimeofday(&end, nullptr);
+      print_time_elapsed("Query" + std::to_string(query_num) + ": (query_var_in_ref) ", start, end);
+    }
+    fflush(stdout);
+    vs_result_free(res);
+    vs_comm_destroy(comm);
+    vs_index_close(idx);
+    _exit(status);
+  }
+  int failed = 0;
+  for (pid_t pid : kids) {
+    int st = 0;
+    waitpid(pid, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != EXIT_SUCCESS) failed = 1;
+  }
+  if (!failed && !a.batch_out.empty()) {
+    std::ofstream out(a.batch_out, std::ios::binary);
+    for (int k = 0; k < world; ++k) {
+      std::ifstream in(dir + "/out." + std::to_string(k), std::ios::binary);
+      out << in.rdbuf();
+    }
+  }
+  for (int k = 0; k < world; ++k) remove((dir + "/out." + std::to_string(k)).c_str());
+  remove(uid_file.c_str());
+  rmdir(dir.c_str());
+  return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+}
+
 int query_main(const Args& a) {
+  if (a.nprocs >= 1 && a.type == 6) return query_multiproc_main(a);
   info("Loading Index ...");
   info("Loading variant graph ...");
   info(a.mode == 0 ? "Read index only .." : "Read complete graph ..");
@@ -472,6 +609,7 @@ int main(int argc, char** argv) {
       else if (f == "--batch-out") a.batch_out = need(i);
       else if (f == "--device") a.device = atoi(need(i).c_str());
       else if (f == "--ngpus") a.ngpus = std::max(1, atoi(need(i).c_str()));
+      else if (f == "--nprocs") a.nprocs = std::max(1, atoi(need(i).c_str()));
       else if (f == "--resident-lists") a.resident_lists = true;
       else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
     }

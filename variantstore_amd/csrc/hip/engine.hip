@@ -52,28 +52,34 @@ struct DevBuf { void* p; size_t cap; };
 // Switches of one handle.  The environment is read ONCE, when the handle is opened (read_env_opts); afterwards only
 // vs_index_set_option changes them -- no getenv on any query path.
 struct EngineOpts {
-  int server = 1;               // latency path: 0 never use the resident server, 1 start it for a back-to-back streak of
-                                // small queries only (default), 2 start it with the first small query
-  unsigned srv_blocks = 16;     // grid of the resident server (>= 1)
+  // ---- the production switches (vs_index_set_option; eight keys) ----
+  int server = 1;               // "latency_server": 0 never use the resident server, 1 start it for a back-to-back streak of small queries
+                                // only (default), 2 start it with the first small query
+  unsigned srv_blocks = 16;     // "server_blocks": grid of the resident server (>= 1)
+  bool share_lists = true;      // "share_lists": type-6 batches of more than 64 regions hold one row and one carrier list per covered site, shared
+                                // by the regions that report it; type-4 / 5 batches one list per reported vertex
+  bool resident_lists = false;  // "resident_lists": carrier lists expanded once into an arena that stays with the index (build_resident_lists)
+  bool async_submit = true;     // "async_submit": a type-6 batch of more than 64 regions returns once it is ENQUEUED (its sizes are known, its
+                                // buffers allocated, its last kernel launched); everything that reads the result is ordered behind it on the
+                                // handle's stream, so callers see no difference except that the host is free while the GPU works
+  bool async_fill = false;      // "async_fill": the carrier expansion of a type-6 batch runs on a second stream and the call returns while it
+                                // is in flight (every accessor of the result waits for it): the next batch's plan and rows run beside it
+  int t4_walk = 2;              // "t4_walk": the walk of query type 4 -- 2 cooperative (8 lanes per region, episodes in parallel; default),
+                                // 1 one lane per region jumping over uneventful ref-path runs, 0 literal (every vertex of the sample's path)
+  bool force_fallbacks = false; // "force_fallbacks": the count-then-emit pairs of walks that query types 2 - 5 fall back to when a region
+                                // outgrows the capacity of its recording walk (tests of those paths)
+  // ---- read from the environment when the handle is opened ----
+  bool no_t4_events = false;    // VS_T4_NO_EVENTS: do not build the event bitmaps at all
+  // ---- tuning builds only (VS_TUNING: VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) ----
   bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
-  bool t4_two_walks = false;    // force the count-then-emit fallback of query types 4 / 5 (tests of that path)
-  bool seq_two_walks = false;   // the same for types 2 / 3
-  bool t4_skip = true;          // type 4: jump over uneventful ref-path runs with the per-sample event bitmaps
-  int t4_coop = 8;              // type 4: lanes per region of the cooperative walk (8 or 16; k_sample_walk_coop); 0: one lane per region
-  bool fill_stats = false;      // tuning builds only: device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
-  bool walk_stats = false;      // tuning builds only: print iteration counts and device-clock ticks of k_sample_walk
-  bool fill_split = false;      // expansion as two launches side by side: listed variants / denser variants
-  bool async_fill = false;      // type-6 batches: the carrier expansion runs on a second stream and the call returns while it is
-                                // in flight (every accessor of the result waits for it): the next batch's bounds, scans and rows
-                                // run beside it
-  bool resident_lists = false;  // carrier lists expanded once into an arena that stays with the index (build_resident_lists): results hold rows only
   bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
-  bool share_lists = true;      // type-6 batches: one row and one carrier list per covered site, shared by the regions that report it
-  uint32_t fill_chunk = 0;      // slots per task of k_fill_carriers: 0 = by the batch's shape, else 16 or 64
-  bool no_t4_events = false;    // do not build the event bitmaps at all (VS_T4_NO_EVENTS, read when the handle is opened)
-  uint32_t fill_ablate = 0;     // tuning builds only (VS_TUNING): skip a regime of k_fill_carriers
-  size_t fill_lds_pad = 0;      // tuning builds only: pad the fill kernel's LDS block (occupancy experiments)
+  uint32_t fill_chunk = 0;      // rows per task of the expansion: 0 = by the batch's shape, else 8 / 16 / 32 / 64
+  bool fill_stats = false;      // device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
+  bool walk_stats = false;      // iteration counts and device-clock ticks of k_sample_walk
+  uint32_t fill_ablate = 0;     // skip a regime of the expansion
+  size_t fill_lds_pad = 0;      // pad the fill kernel's LDS block (occupancy experiments)
 };
+
 
 struct vs_index {
   HostGraph g;
@@ -84,17 +90,22 @@ struct vs_index {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<void*> image_allocs;
   uint64_t device_bytes = 0;
+  uint64_t t4_rows_bytes = 0;   // of which: the per-sample event and hold rows of query type 4
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
   std::vector<DevBuf> pool;
   unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
   uint64_t t4_gen = 0;
-  hipStream_t fill_stream = nullptr;        // second stream of the split expansion (fill_split)
+  hipStream_t fill_stream = nullptr;        // second stream: the expansion of an async_fill batch
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
   bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
   uint32_t sort_probe_in = 0;
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
+  bool batch_in_flight = false;             // a batch returned when it was enqueued (async_submit) and nothing has synchronised the stream since
+  bool timing_pending = false;              // the last batch returned before its kernels had finished: vs_index_last_timing reads the events then
+  uint64_t timing_fill_launches = 0;
+  std::vector<hipEvent_t> ev_pool;          // timing events of results (two per shared batch), reused between results
   // resident carrier lists (DevImage::v_abegin): the arena, its length in entries, and -- once a caller has asked for
   // carriers on the host -- its page-locked host mirror, shared by every result of the handle
   void* res_arena = nullptr;
@@ -161,6 +172,7 @@ struct vs_result {
   std::vector<VariantRow> sl_rows;
   // the RAW host copy (vs_result_get_raw): variant table and arena exactly as they lie in HBM, in page-locked memory
   DevBuf raw_pin{nullptr, 0};
+  std::vector<DevBuf> old_pins;   // earlier raw copies of this result (rows only, then rows + carriers): pointers handed out stay valid until it is freed
   const VariantRow* raw_rows = nullptr;
   const uint8_t* raw_arena = nullptr;   // NULL: carriers not copied
   int kind = 0;  // 7: samples_has_var result (vs_result_format_region writes the sample line); 2 / 3: sequences
@@ -474,7 +486,7 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, sus_g, &d.sus_g));
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
-  //      what this part has plenty of).  Skipped when they would take more than a third of the free memory or 64 GB. ----
+  //      what this part has plenty of).  Skipped when they would take more than half of the free memory or the cap below. ----
   d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0;
   if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
     const uint64_t stride = (im.P + 63) / 64 + 1, hstride = (im.V + 63) / 64 + 1;
@@ -482,7 +494,12 @@ static int build_device_image(vs_index* idx) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // (10,000 samples x 20 M variants: 125 GB of rows on a 288 GB part, next to a 5 GB image -- memory is what this GPU has)
-    if (bytes + hbytes <= (176ull << 30) && bytes + hbytes <= free_b / 2) {
+    // Budget: half of the free memory, at most 176 GB -- or VS_T4_ROWS_MAX_GB from the environment; vs_index_get_info
+    // reports what was taken (t4_rows_bytes).
+    uint64_t cap = 176ull << 30;
+    if (const char* gb = getenv("VS_T4_ROWS_MAX_GB")) cap = (uint64_t)std::max(0.0, atof(gb)) << 30;
+    if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
+      idx->t4_rows_bytes = bytes + hbytes;
       uint64_t *events = nullptr, *hold = nullptr;
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
@@ -512,15 +529,15 @@ static void read_env_opts(vs_index* idx) {
   if (getenv("VS_NO_SERVER")) o.server = 0;
   else if (const char* sv = getenv("VS_SERVER")) o.server = std::max(0, std::min(2, atoi(sv)));
   if (const char* sb = getenv("VS_SRV_BLOCKS")) o.srv_blocks = (unsigned)std::max(1, std::min(64, atoi(sb)));
-  o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
-  o.t4_two_walks = getenv("VS_T4_TWO_WALKS") != nullptr;
-  o.seq_two_walks = getenv("VS_SEQ_TWO_WALKS") != nullptr;
-  if (getenv("VS_T4_NO_SKIP")) o.t4_skip = false;
   if (getenv("VS_NO_SHARED_LISTS")) o.share_lists = false;
   o.async_fill = getenv("VS_ASYNC_FILL") != nullptr;
+  if (getenv("VS_SYNC_SUBMIT")) o.async_submit = false;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
+#ifdef VS_TUNING
+  o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
+#endif
 }
 
 static int build_resident_lists(vs_index* idx);
@@ -571,12 +588,12 @@ static size_t fill_lds_bytes(const vs_index* idx) {
 }
 
 // one launch of the carrier expansion: over the rows of a private-row result or over the shared rows of a sorted batch
-template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
+template <bool WIDE, uint32_t CH, bool TUNE>
 static void launch_fill(vs_index* idx, const DevResult& d, bool share, const uint32_t* u_site, uint64_t n_fill, unsigned blocks, size_t lds_bytes,
                         uint32_t ablate, uint32_t gt_words, hipStream_t stream = nullptr) {
   if (!stream) stream = idx->stream;
-  if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, u_site, n_fill, ablate, gt_words);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE, PART>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, ablate, gt_words);
+  if (share) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, u_site, n_fill, ablate, gt_words);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_carriers<WIDE, CH, TUNE>), dim3(blocks), dim3(256), lds_bytes, stream, idx->d, d, ablate, gt_words);
 }
 
 static int ensure_fill_stream(vs_index* idx) {
@@ -584,6 +601,29 @@ static int ensure_fill_stream(vs_index* idx) {
   HIP_TRY(hipStreamCreateWithFlags(&idx->fill_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[0], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&idx->fill_ev[1], hipEventDisableTiming));
+  return VS_OK;
+}
+static int result_events(vs_result* r) {   // the result's own pair of timing events around its expansion, from the handle's pool
+  vs_index* idx = r->idx;
+  for (auto& e : r->ev_fill) {
+    if (e) continue;
+    if (!idx->ev_pool.empty()) { e = idx->ev_pool.back(); idx->ev_pool.pop_back(); }
+    else HIP_TRY(hipEventCreate(&e));
+  }
+  return VS_OK;
+}
+// The phase times of a batch from the handle's events (the batch's last event has completed or is waited for here).
+static int collect_timing(vs_index* idx) {
+  if (!idx->timing_pending) return VS_OK;
+  idx->timing_pending = false;
+  vs_timing& t = idx->timing;
+  HIP_TRY(hipEventSynchronize(idx->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  t.fill_launches = idx->timing_fill_launches;
   return VS_OK;
 }
 // An asynchronous expansion (option "async_fill") must have finished before anything reads the result or returns its
@@ -621,18 +661,6 @@ static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint3
       constexpr bool kTune = false;
 #endif
       const bool wide = idx->d.wpc > 63;
-      if (idx->opts.fill_split && share && !wide && idx->d.use_bv && !on) {
-        // the listed variants (64 rows per task: lane per group of 8 carriers) and the denser ones (16 rows per task: wave per
-        // variant) as two launches side by side on two streams
-        VS_TRY(ensure_fill_stream(idx));
-        HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
-        HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
-        const unsigned blocks64 = (unsigned)(((n_fill + 63) / 64 + 3) / 4), blocks16 = (unsigned)(((n_fill + 15) / 16 + 3) / 4);
-        launch_fill<false, 64, kTune, 1>(idx, d, share, u_site, n_fill, blocks64, lds_bytes, ablate, gt_words, idx->fill_stream);
-        launch_fill<false, 16, kTune, 2>(idx, d, share, u_site, n_fill, blocks16, lds_bytes, ablate, gt_words);
-        HIP_TRY(hipEventRecord(idx->fill_ev[1], idx->fill_stream));
-        HIP_TRY(hipStreamWaitEvent(idx->stream, idx->fill_ev[1], 0));
-      } else
       switch (chunk) {
         case 8:  wide ? launch_fill<true, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on)
                       : launch_fill<false, 8, kTune>(idx, d, share, u_site, n_fill, (unsigned)blocks, lds_bytes, ablate, gt_words, on); break;
@@ -915,7 +943,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     // (rows, per-region arrays); the next batch's plan and rows then run beside it.  The call's temporaries (the site
     // index the expansion reads) stay with the result until it is freed.
     VS_TRY(ensure_fill_stream(idx));
-    for (auto& e : r->ev_fill) if (!e) HIP_TRY(hipEventCreate(&e));
+    VS_TRY(result_events(r));
     HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
     HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
     HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
@@ -946,9 +974,13 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
       HIP_TRY(hipMemsetAsync(tstat, 0, ((U + chunk - 1) / chunk + 4) * 16, idx->stream));
     }
 #endif
+    VS_TRY(result_events(r));   // the kernel's own duration, whenever the result is asked for it (vs_result_fill_ms)
+    HIP_TRY(hipEventRecord(r->ev_fill[0], idx->stream));
     if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
     else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(r->ev_fill[1], idx->stream));
+    r->pending = true;
 #ifdef VS_TUNING
     if (tstat) {
       const uint64_t nt = (U + chunk - 1) / chunk;
@@ -973,36 +1005,57 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
-  {
+  idx->timing_pending = true;
+  idx->timing_fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
+  // async_submit: the batch is enqueued, its sizes are known (the plan's totals) and its buffers are the result's -- the call
+  // returns here.  Whatever reads the result (copies, digests, packs, the next batch's kernels that reuse the temporaries
+  // released below) is ordered behind the batch on the handle's stream; the timing events are read when asked for.
+  const bool async_submit = allow_async && idx->opts.async_submit && !async_fill && !idx->opts.lat_debug;
+  if (!async_submit) {
     uint64_t* done = idx->pinned + vs_index::kPinDone;
     const uint64_t seq = ++idx->done_seq;
     hipLaunchKernelGGL(k_post_done, dim3(1), dim3(1), 0, idx->stream, done, seq);
     HIP_TRY(hipGetLastError());
     VS_TRY(wait_posted(idx, done, seq, 2000));
+    idx->batch_in_flight = false;
   }
   if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
-  scratch.release();
-  vs_timing& t = idx->timing;
-  HIP_TRY(hipEventSynchronize(idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
-  t.fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
+  if (async_submit) { release_bufs(idx, scratch.bufs); idx->batch_in_flight = true; }   // (stream-ordered reuse: no wait)
+  else scratch.release();
+  if (!async_submit) VS_TRY(collect_timing(idx));
   return VS_OK;
 }
 
-// sample_id == kNone: query type 6 (site-table range); otherwise query type 4 (literal path walk).
-// point_mode 1 / 7: one next_variant_in_ref call per position (closest_var / samples_has_var).
-static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id = kNone,
-                          const uint32_t* sample_ids = nullptr, uint32_t point_mode = 0, const PointStrings* strings = nullptr,
-                          int walk_mode = 4, bool regions_on_device = false, const uint64_t* site_records = nullptr, bool allow_async = false) {
-  const bool t4 = sample_id != kNone || sample_ids != nullptr;
-  // query type 6 over more than 64 regions: rows and carrier lists shared between the regions of the batch
-  if (!t4 && !point_mode && idx->opts.share_lists && n > 64) return run_type6_shared(idx, regions, n, r, regions_on_device, site_records, allow_async);
+// ---------------------------------------------------------------------------------------------------------------------
+// The batches whose regions own PRIVATE rows (query types 4 and 5, the point queries, type 6 with share_lists = 0 or from
+// a handful of regions' records) run through the same four stages, each a function that reads only what the stage
+// before it left in the batch's context -- a mode cannot reach into another mode's temporaries:
+//   batch_setup       per-region arrays of the result, regions (and sample ids) on the device
+//   <mode>: bounds    k_region_bounds / k_bounds_from_records / k_point_bounds -- or the recording walk of types 4 / 5
+//   batch_sizes       offsets of rows and arena by one scan; the totals cross in mapped host memory
+//   batch_tables      rows (+ the expansion's per-row parameters) and arena of exactly that size
+//   <mode>: rows      k_emit_headers + k_dedup_slow (+ k_has_var_filter) -- or k_emit_from_walk / the emitting walk
+//   batch_fill        k_fill_carriers over the rows (async_fill: on the handle's second stream)
+//   batch_finish      synchronise, temporaries back to the pool, phase times from the handle's events
+// (A type-6 batch of more than 64 regions shares rows and lists between its regions: run_type6_shared above.)
+// ---------------------------------------------------------------------------------------------------------------------
+struct BatchCtx {
+  vs_index* idx;
+  vs_result* r;
+  uint64_t n;
+  ScratchBufs scratch;
+  uint32_t* dsids = nullptr;     // one sample per region (types 4 / 5), on the device
+  bool resident = false;         // rows point into the index's resident arena: nothing is expanded
+  bool async_fill = false;
+  BatchCtx(vs_index* i, vs_result* res, uint64_t nn) : idx(i), r(res), n(nn), scratch(i) {}
+};
+
+static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_device, const uint32_t* sample_ids) {
+  vs_index* idx = c.idx;
+  vs_result* r = c.r;
+  const uint64_t n = c.n;
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
-  uint32_t* dsids = nullptr;
+  idx->timing_pending = false;
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1019,20 +1072,159 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
   if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
   else if (n) HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
   if (sample_ids && n) {
-    VS_TRY(ralloc(r, n, &dsids));
-    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
+    VS_TRY(ralloc(r, n, &c.dsids));
+    HIP_TRY(hipMemcpyAsync(c.dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
-  ScratchBufs scratch(idx);
-  uint64_t totals[2] = {0, 0};
-  // Type 4, single walk: capacities from the type-6 bounds of the same regions, one recording walk, headers from
-  // the record.  A region that outgrows its capacity (not seen in practice) sends the batch down the two-walk path.
+  return VS_OK;
+}
+
+// Offsets of the rows and of the arena from the per-region counts the bounds / the walk left (q_nvar, q_ncar); the totals
+// arrive in mapped host memory (read after the caller's synchronisation: batch_totals).
+static int batch_sizes(BatchCtx& c) {
+  DevResult& d = c.r->d;
+  return scan_offsets(c.idx, d.q_nvar, d.q_ncar, c.n, d.var_begin, d.car_base, c.idx->pinned + vs_index::kPinBatch, &c.scratch.bufs);
+}
+static void batch_totals(const BatchCtx& c, uint64_t* rows, uint64_t* arena) {
+  const volatile uint64_t* pin = c.idx->pinned + vs_index::kPinBatch;
+  *rows = pin[0]; *arena = pin[1];
+}
+
+// The variant table (+ the per-row parameters of k_fill_carriers) and the arena, of exactly the sizes the scan found.
+static int batch_tables(BatchCtx& c, uint64_t rows, uint64_t arena, bool shared_per_vertex, bool walking) {
+  vs_index* idx = c.idx;
+  vs_result* r = c.r;
+  DevResult& d = r->d;
+  d.A = rows;
+  d.S = arena;
+  VS_TRY(ralloc(r, d.A, &d.rows));
+  if (!c.resident) {
+    VS_TRY(ralloc(r, d.A, &d.r_class));
+    VS_TRY(ralloc(r, d.A, &d.r_gt0));
+  }
+  r->n_rows_reported = d.A;
+  r->shared_lists = shared_per_vertex;
+  r->resident = c.resident;
+  r->scattered_lists = shared_per_vertex || (c.resident && walking);   // a region's lists are not one arena range: texts come from a raw copy
+  r->n_unique_sites = c.resident ? 0 : d.A;
+  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  if (c.resident) d.carriers = idx->res_arena;
+  else {
+    uint8_t* a = nullptr;
+    VS_TRY(ralloc(r, d.S * d.car_width + 16, &a));
+    d.carriers = a;
+  }
+  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  return VS_OK;
+}
+
+// The carrier expansion over the rows; async_fill: on the handle's second stream behind an event, the call then returns
+// once the FIRST stream is done and the call's temporaries stay with the result until it is freed.
+static int batch_fill(BatchCtx& c, bool allow_async) {
+  vs_index* idx = c.idx;
+  vs_result* r = c.r;
+  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  const uint64_t n_fill = c.resident ? 0 : r->d.A;
+  c.async_fill = allow_async && idx->opts.async_fill && n_fill > 0;
+  if (c.async_fill) {
+    VS_TRY(ensure_fill_stream(idx));
+    VS_TRY(result_events(r));
+    HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
+    HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
+    HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
+    VS_TRY(fill_lists(idx, r->d, false, nullptr, n_fill, idx->fill_stream));
+    HIP_TRY(hipEventRecord(r->ev_fill[1], idx->fill_stream));
+    r->pending = true;
+  } else VS_TRY(fill_lists(idx, r->d, false, nullptr, n_fill));
+  idx->timing_fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
+  return VS_OK;
+}
+
+static int batch_finish(BatchCtx& c) {
+  vs_index* idx = c.idx;
+  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  idx->batch_in_flight = false;
+  if (c.async_fill) { c.r->bufs.insert(c.r->bufs.end(), c.scratch.bufs.begin(), c.scratch.bufs.end()); c.scratch.bufs.clear(); }
+  c.scratch.release();
+  idx->timing_pending = true;
+  return collect_timing(idx);
+}
+
+// Query type 6 with private rows (share_lists = 0, or few regions' records), and the point queries (point_mode 1 / 7: one
+// next_variant_in_ref call per position -- closest_var / samples_has_var).
+static int run_private_batch(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
+                             uint32_t point_mode, const PointStrings* strings, bool allow_async) {
+  BatchCtx c(idx, r, n);
+  VS_TRY(batch_setup(c, regions, regions_on_device, nullptr));
+  DevResult& d = r->d;
+  if (n) {   // ---- bounds ----
+    if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
+    else if (site_records) hipLaunchKernelGGL(k_bounds_from_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, site_records);
+    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  c.resident = idx->opts.resident_lists && idx->res_arena && !point_mode;
+  VS_TRY(batch_sizes(c));
+  if (c.resident) {   // the rows point into the index's arena; a region's lists ARE the arena range of its sites
+    VS_TRY(ralloc(r, n, &d.q_car_len));   // (before the header kernels overwrite q_ncar with the reported carriers)
+    hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, idx->res_entries);
+  }
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  uint64_t rows = 0, arena = 0;
+  batch_totals(c, &rows, &arena);
+  if (c.resident) arena = idx->res_entries;
+  VS_TRY(batch_tables(c, rows, arena, false, false));
+  if (n) {   // ---- rows ----
+    if (c.resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
+    hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
+    if (strings) {
+      uint8_t* dchars = nullptr;
+      uint64_t* doff = nullptr;
+      VS_TRY(ralloc(r, strings->chars->size() + 8, &dchars));
+      VS_TRY(ralloc(r, strings->off->size(), &doff));
+      if (!strings->chars->empty())
+        HIP_TRY(hipMemcpyAsync(dchars, strings->chars->data(), strings->chars->size(), hipMemcpyHostToDevice, idx->stream));
+      HIP_TRY(hipMemcpyAsync(doff, strings->off->data(), strings->off->size() * 8, hipMemcpyHostToDevice, idx->stream));
+      hipLaunchKernelGGL(k_has_var_filter, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d,
+                         (const uint8_t*)dchars, (const uint64_t*)doff);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  VS_TRY(batch_fill(c, allow_async && !point_mode));
+  return batch_finish(c);
+}
+
+// Query type 6: more than 64 regions share rows and carrier lists (unless share_lists is 0).
+static int run_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records, bool allow_async) {
+  if (idx->opts.share_lists && n > 64) return run_type6_shared(idx, regions, n, r, regions_on_device, site_records, allow_async);
+  return run_private_batch(idx, regions, n, r, regions_on_device, site_records, 0, nullptr, allow_async);
+}
+
+// Query types 4 (walk_mode 4: get_sample_var_in_ref, one sample's path in reference coordinates) and 5 (walk_mode 5:
+// get_sample_var_in_sample).  sample_id: the one sample of the batch, or kNone with one sample per region in sample_ids.
+//   walk   capacities from the type-6 bounds of the same regions (k_walk_caps_sc for type 5), ONE recording walk
+//          (cooperative, serial with jumps, or literal: option t4_walk); a region that outgrows its capacity -- not seen
+//          in practice; option force_fallbacks -- sends the batch down the count-then-emit pair of walks
+//   claims one carrier list per reported VERTEX, shared by the rows that report it (k_t4_claim)
+static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode) {
+  BatchCtx c(idx, r, n);
+  VS_TRY(batch_setup(c, regions, false, sample_ids));
+  DevResult& d = r->d;
+  ScratchBufs& scratch = c.scratch;
+  const uint32_t* dsids = c.dsids;
   WalkScratch ws{};
   uint64_t ws_capacity = 0;
   bool single_walk = false;
   DevImage dwalk = idx->d;   // what the type-4 walk sees: with or without the event bitmaps
-  if (!idx->opts.t4_skip) dwalk.t4_events = nullptr;
-  if (n && t4 && !idx->opts.t4_two_walks) {
+  if (idx->opts.t4_walk == 0) dwalk.t4_events = nullptr;
+  auto counting_walk = [&]() {
+    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, WalkScratch{});
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
+  };
+  if (n && !idx->opts.force_fallbacks) {
     if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     uint64_t* cap_begin = nullptr;
@@ -1057,12 +1249,10 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
       HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, idx->stream));
     }
 #endif
-    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, ws);
-    else if (dwalk.t4_events && idx->opts.t4_coop == 8)   // 8 or 16 lanes per region: the episodes of a region run in parallel
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
-    else if (dwalk.t4_events && idx->opts.t4_coop)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<16>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, ws);
+    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, ws);
+    else if (dwalk.t4_events && idx->opts.t4_walk == 2)   // 8 lanes per region: the episodes of a region run in parallel
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
   }
@@ -1078,29 +1268,15 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
             h[0], h[1] / nr, h[2] / nr, h[3] / nr, h[4] / nr, h[7] / nr, h[5] / nr, h[6] / nr, h[12] / nr, h[8], h[9], h[10], h[11]);
   }
 #endif
-  if (single_walk) {
-  } else if (n) {
-    if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
-    else if (point_mode) hipLaunchKernelGGL(k_point_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, point_mode);
-    else if (site_records) hipLaunchKernelGGL(k_bounds_from_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, site_records);
-    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
-    HIP_TRY(hipGetLastError());
-  }
+  if (!single_walk && n) { counting_walk(); HIP_TRY(hipGetLastError()); }
   HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
-  uint64_t* pin_totals = idx->pinned + vs_index::kPinBatch;
-  // Resident carrier lists: the rows point into the index's arena; nothing is expanded, the result owns no arena.
-  bool resident = idx->opts.resident_lists && idx->res_arena && !point_mode && !(t4 && !single_walk);
+  c.resident = idx->opts.resident_lists && idx->res_arena && single_walk;
   ListClaims lc{};
-  bool share_t4 = false;   // type 4, recording walk: one carrier list per reported VERTEX, shared by the rows that report it
+  bool share_t4 = false;   // one carrier list per reported VERTEX, shared by the rows that report it
   uint64_t t4_arena = 0;
-  VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
+  VS_TRY(batch_sizes(c));
   if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
-  if (resident && !t4) {
-    VS_TRY(ralloc(r, n, &d.q_car_len));   // (before the header kernels overwrite q_ncar with the reported carriers)
-    hipLaunchKernelGGL(k_resident_bases, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, idx->d, d, idx->res_entries);
-  }
-  if (single_walk && idx->opts.share_lists && n > 64 && !resident) {
+  if (single_walk && idx->opts.share_lists && n > 64 && !c.resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
     const uint64_t cap_rows = ws_capacity;
     if (!idx->t4_claim) {
@@ -1121,96 +1297,34 @@ static int run_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, v
     share_t4 = true;
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));
-  totals[0] = ((volatile uint64_t*)pin_totals)[0];
-  totals[1] = ((volatile uint64_t*)pin_totals)[1];
-  if (share_t4 && !walk_overflow) totals[1] = t4_arena;
-  if (resident && !(single_walk && walk_overflow)) totals[1] = idx->res_entries;
+  uint64_t rows = 0, arena = 0;
+  batch_totals(c, &rows, &arena);
+  if (share_t4 && !walk_overflow) arena = t4_arena;
+  if (c.resident && !walk_overflow) arena = idx->res_entries;
   if (single_walk && walk_overflow) {   // redo the sizes with a counting walk; the emitting walk follows below
     single_walk = false;
     share_t4 = false;
-    resident = false;
-    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
-    VS_TRY(scan_offsets(idx, d.q_nvar, d.q_ncar, n, d.var_begin, d.car_base, pin_totals, &scratch.bufs));
+    c.resident = false;
+    counting_walk();
+    VS_TRY(batch_sizes(c));
     HIP_TRY(hipStreamSynchronize(idx->stream));
-    totals[0] = ((volatile uint64_t*)pin_totals)[0];
-    totals[1] = ((volatile uint64_t*)pin_totals)[1];
+    batch_totals(c, &rows, &arena);
   }
-  d.A = totals[0];
-  d.S = totals[1];
-  VS_TRY(ralloc(r, d.A, &d.rows));
-  if (!resident) {   // row parameters of k_fill_carriers
-    VS_TRY(ralloc(r, d.A, &d.r_class));
-    VS_TRY(ralloc(r, d.A, &d.r_gt0));
-  }
-  r->n_rows_reported = d.A;
-  r->shared_lists = share_t4;
-  r->resident = resident;
-  r->scattered_lists = share_t4 || (resident && t4);   // a region's lists are not one arena range: texts come from a raw copy
-  r->n_unique_sites = resident ? 0 : d.A;
-  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
-  if (resident) d.carriers = idx->res_arena;
-  else {
-    uint8_t* arena = nullptr;
-    VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
-    d.carriers = arena;
-  }
-  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
-  if (n) {
-    if (t4 && single_walk && walk_mode == 5 && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk && walk_mode == 5 && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk && resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 0>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (t4 && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, (const uint32_t*)dsids, WalkScratch{});
-    else if (t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, (const uint32_t*)dsids, WalkScratch{});
-    else {
-      if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_headers<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d);
-      hipLaunchKernelGGL(k_dedup_slow, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d);
-      if (strings) {
-        uint8_t* dchars = nullptr;
-        uint64_t* doff = nullptr;
-        VS_TRY(ralloc(r, strings->chars->size() + 8, &dchars));
-        VS_TRY(ralloc(r, strings->off->size(), &doff));
-        if (!strings->chars->empty())
-          HIP_TRY(hipMemcpyAsync(dchars, strings->chars->data(), strings->chars->size(), hipMemcpyHostToDevice, idx->stream));
-        HIP_TRY(hipMemcpyAsync(doff, strings->off->data(), strings->off->size() * 8, hipMemcpyHostToDevice, idx->stream));
-        hipLaunchKernelGGL(k_has_var_filter, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d,
-                           (const uint8_t*)dchars, (const uint64_t*)doff);
-      }
-    }
+  VS_TRY(batch_tables(c, rows, arena, share_t4, true));
+  if (n) {   // ---- rows ----
+    const dim3 g16((unsigned)((n + 15) / 16)), g64((unsigned)((n + 63) / 64));
+    if (single_walk && walk_mode == 5 && c.resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 2>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (single_walk && walk_mode == 5 && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 1>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (single_walk && walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<false, 0>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (single_walk && c.resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 0>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    else if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), g64, dim3(64), 0, idx->stream, idx->d, d, dsids, WalkScratch{});
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), g64, dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
-  const uint64_t n_fill = resident ? 0 : d.A;   // lists to expand: every row; none with resident lists
-  // async_fill: the expansion goes to the handle's second stream behind an event and the call returns once the FIRST
-  // stream is done (rows, per-region arrays); the next batch's bounds, scans and rows then run beside it.  The call's
-  // temporaries (the site index the expansion reads) stay with the result until it is freed.
-  const bool async_fill = allow_async && idx->opts.async_fill && !t4 && !point_mode && n_fill > 0;
-  if (async_fill) {
-    VS_TRY(ensure_fill_stream(idx));
-    for (auto& e : r->ev_fill) if (!e) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipEventRecord(idx->fill_ev[0], idx->stream));
-    HIP_TRY(hipStreamWaitEvent(idx->fill_stream, idx->fill_ev[0], 0));
-    HIP_TRY(hipEventRecord(r->ev_fill[0], idx->fill_stream));
-    VS_TRY(fill_lists(idx, d, false, nullptr, n_fill, idx->fill_stream));
-    HIP_TRY(hipEventRecord(r->ev_fill[1], idx->fill_stream));
-    r->pending = true;
-  } else VS_TRY(fill_lists(idx, d, false, nullptr, n_fill));
-  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
-  HIP_TRY(hipStreamSynchronize(idx->stream));
-  if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
-  scratch.release();
-  vs_timing& t = idx->timing;
-  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
-  t.fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
-  return VS_OK;
+  VS_TRY(batch_fill(c, false));
+  return batch_finish(c);
 }
 
 template <typename T>
@@ -1300,6 +1414,7 @@ static int fetch_headers(vs_result* r) {
 static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r) {
   DevSeqResult& q = r->sq;
   if (idx->srv_alive) VS_TRY(server_stop(idx));
+  idx->timing_pending = false;
   q.Q = n;
   r->d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1322,7 +1437,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   uint64_t totals[2] = {0, 0};
   // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
   // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
-  bool single_walk = n > 0 && !idx->opts.seq_two_walks;
+  bool single_walk = n > 0 && !idx->opts.force_fallbacks;
   if (single_walk) {
     VS_TRY(ralloc(r, 1, &q.overflow));
     HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
@@ -1483,7 +1598,12 @@ static int server_ensure(vs_index* idx) {
 // spins on.  Returns 1 if the device found the slab too small (cannot happen unless host and device disagree; the
 // caller then takes the general path).
 static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r) {
+  if (idx->batch_in_flight) {   // the latency path's server runs on a stream of its own and takes its slab from the pool a batch in
+    idx->batch_in_flight = false;   // flight has already returned its temporaries to: that batch first
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+  }
   const auto host_enter = std::chrono::steady_clock::now();
+  idx->timing_pending = false;
   DevResult& d = r->d;
   uint64_t capA = 0, capS = 0, ntasks = 0;
   for (uint64_t q = 0; q < n; ++q) {
@@ -1665,6 +1785,7 @@ void vs_index_close(vs_index* idx) {
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->fill_stream) (void)hipStreamDestroy(idx->fill_stream);
     for (auto& e : idx->fill_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : idx->ev_pool) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     if (idx->pinned) (void)hipHostFree(idx->pinned);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1760,6 +1881,7 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   for (uint32_t v : idx->g.topo_val) info->num_topology_keys += v != 0;
   info->list_max = idx->im.use_bit_vector ? idx->im.list_max : 0;
   info->reserved_ = 0;
+  info->t4_rows_bytes = idx->t4_rows_bytes;
   return VS_OK;
 }
 
@@ -1805,33 +1927,32 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value < 1 || value > 64) return fail(VS_ERR_ARG, "server_blocks takes 1..64");
     if (idx->device >= 0 && idx->srv_alive) { HIP_TRY(hipSetDevice(idx->device)); VS_TRY(server_stop(idx)); }
     o.srv_blocks = (unsigned)value;
-  } else if (k == "lat_debug") o.lat_debug = value != 0;
-  else if (k == "t4_two_walks") o.t4_two_walks = value != 0;
-  else if (k == "seq_two_walks") o.seq_two_walks = value != 0;
-  else if (k == "t4_skip") o.t4_skip = value != 0;
-  else if (k == "t4_coop") o.t4_coop = value == 16 ? 16 : (value ? 8 : 0);
-  else if (k == "share_lists") {
+  } else if (k == "share_lists") {
     if (value < 0 || value > 1) return fail(VS_ERR_ARG, "share_lists takes 0 (private rows and lists per region) or 1 (shared, default)");
     o.share_lists = value != 0;
-  }
-  else if (k == "resident_lists") {
+  } else if (k == "resident_lists") {
     if (value != 0 && value != 1) return fail(VS_ERR_ARG, "resident_lists takes 0 or 1");
     if (value) VS_TRY(build_resident_lists(idx));   // (kept once built: switching back to 0 only stops results from using it)
     o.resident_lists = value != 0;
-  }
-  else if (k == "async_fill") o.async_fill = value != 0;
-  else if (k == "fill_fused") o.fill_fused = value != 0;
-  else if (k == "fill_split") o.fill_split = value != 0;
-  else if (k == "fill_chunk") {
-    if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
-    o.fill_chunk = (uint32_t)value;
-  }
-  else if (k == "fill_ablate" || k == "fill_lds_pad" || k == "walk_stats" || k == "fill_stats") {
+  } else if (k == "async_fill") o.async_fill = value != 0;
+  else if (k == "async_submit") o.async_submit = value != 0;
+  else if (k == "t4_walk") {
+    if (value < 0 || value > 2) return fail(VS_ERR_ARG, "t4_walk takes 0 (literal), 1 (one lane per region, jumping) or 2 (cooperative, default)");
+    o.t4_walk = (int)value;
+  } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
+  else if (k == "lat_debug" || k == "fill_fused" || k == "fill_chunk" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
+           k == "fill_lds_pad") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
-    if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;
-    else if (k == "walk_stats") o.walk_stats = value != 0;
+    if (k == "lat_debug") o.lat_debug = value != 0;
+    else if (k == "fill_fused") o.fill_fused = value != 0;
+    else if (k == "fill_chunk") {
+      if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
+      o.fill_chunk = (uint32_t)value;
+    }
     else if (k == "fill_stats") o.fill_stats = value != 0;
+    else if (k == "walk_stats") o.walk_stats = value != 0;
+    else if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;
     else o.fill_lds_pad = (size_t)value;
 #else
     return fail(VS_ERR_UNSUPPORTED, "%s exists in tuning builds only (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force)", key);
@@ -1840,8 +1961,13 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   return VS_OK;
 }
 
-int vs_index_last_timing(const vs_index* idx, vs_timing* t) {
+int vs_index_last_timing(const vs_index* cidx, vs_timing* t) {
+  vs_index* idx = const_cast<vs_index*>(cidx);
   if (!idx || !t) return fail(VS_ERR_ARG, "null argument");
+  if (idx->timing_pending) {   // (the last batch returned when it was enqueued: its events are read -- waited for -- here)
+    HIP_TRY(hipSetDevice(idx->device));
+    VS_TRY(collect_timing(idx));
+  }
   *t = idx->timing;
   return VS_OK;
 }
@@ -1852,9 +1978,10 @@ void vs_result_free(vs_result* r) {
   if (r->idx) {
     (void)hipSetDevice(r->idx->device);
     (void)result_ready(r);
-    for (auto& e : r->ev_fill) if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->ev_fill) if (e) { r->idx->ev_pool.push_back(e); e = nullptr; }
     release_bufs(r->idx, r->bufs);
     pin_release(r->idx, r->raw_pin);
+    for (auto& b : r->old_pins) pin_release(r->idx, b);
     r->idx->live_results--;
     if (r->idx->close_pending && r->idx->live_results == 0) vs_index_close(r->idx);
   }
@@ -1876,7 +2003,7 @@ int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_
       r->d = DevResult{};
     }
   }
-  if (rc == 1) rc = run_var_in_ref(idx, regions, n, r, kNone, nullptr, 0, nullptr, 4, false, nullptr, /*allow_async=*/true);
+  if (rc == 1) rc = run_type6(idx, regions, n, r, false, nullptr, /*allow_async=*/true);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1889,7 +2016,7 @@ int vs_query_var_in_ref_device(vs_index* idx, const vs_region* device_regions, u
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  const int rc = run_var_in_ref(idx, device_regions, n, r, kNone, nullptr, 0, nullptr, 4, /*regions_on_device=*/true, nullptr, /*allow_async=*/true);
+  const int rc = run_type6(idx, device_regions, n, r, /*regions_on_device=*/true, nullptr, /*allow_async=*/true);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1902,7 +2029,7 @@ int vs_query_expand_site_ranges(vs_index* idx, const void* device_records, uint6
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  const int rc = run_var_in_ref(idx, nullptr, n, r, kNone, nullptr, 0, nullptr, 4, false, (const uint64_t*)device_records);
+  const int rc = run_type6(idx, nullptr, n, r, false, (const uint64_t*)device_records, /*allow_async=*/false);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1916,7 +2043,7 @@ int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  int rc = run_var_in_ref(idx, regions, n, r, sample_id);
+  int rc = run_walk_batch(idx, regions, n, r, sample_id, nullptr, 4);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1932,7 +2059,7 @@ int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
-  int rc = run_var_in_ref(idx, regions, n, r, kNone, sample_ids);
+  int rc = run_walk_batch(idx, regions, n, r, kNone, sample_ids, 4);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -1948,7 +2075,7 @@ static int run_point_batch(vs_index* idx, const uint64_t* positions, uint64_t n,
   r->idx = idx;
   r->kind = mode == 7 ? 7 : 0;
   idx->live_results++;
-  int rc = run_var_in_ref(idx, regions.data(), n, r, kNone, nullptr, mode, strings);
+  int rc = run_private_batch(idx, regions.data(), n, r, false, nullptr, mode, strings, false);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -2008,7 +2135,7 @@ int vs_query_sample_var_in_sample(vs_index* idx, const vs_region* regions, uint6
   r->idx = idx;
   idx->live_results++;
   static const uint32_t none = 0;
-  int rc = run_var_in_ref(idx, regions, n, r, kNone, n ? sample_ids : &none, 0, nullptr, 5);
+  int rc = run_walk_batch(idx, regions, n, r, kNone, n ? sample_ids : &none, 5);
   if (rc != VS_OK) return drop_result(r, rc);
   *out = r;
   return VS_OK;
@@ -2073,7 +2200,7 @@ static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) 
   if (r->raw_rows && (r->raw_arena || !with_carriers)) return VS_OK;
   if (with_carriers) VS_TRY(result_ready(r));
   if (with_carriers && r->resident) VS_TRY(ensure_resident_mirror(idx));   // the rows point into the handle's mirror of the resident arena
-  if (r->raw_pin.p) { pin_release(idx, r->raw_pin); r->raw_pin = DevBuf{nullptr, 0}; r->raw_rows = nullptr; r->raw_arena = nullptr; }
+  if (r->raw_pin.p) { r->old_pins.push_back(r->raw_pin); r->raw_pin = DevBuf{nullptr, 0}; r->raw_rows = nullptr; r->raw_arena = nullptr; }
   VS_TRY(pin_alloc(idx, row_bytes + arena_bytes + 64, &r->raw_pin));
   uint8_t* base = (uint8_t*)r->raw_pin.p;
   if (row_bytes) HIP_TRY(hipMemcpyAsync(base, d.rows, row_bytes, hipMemcpyDeviceToHost, stream));
@@ -2097,7 +2224,8 @@ static void fill_raw(vs_result* r, vs_result_raw* raw) {
   raw->carrier_bytes = r->d.car_width;
   raw->arena = r->raw_arena;
   raw->seq_pool = r->idx->seq_chars.data();
-  raw->shared = (r->shared_lists ? 1 : 0) | (r->resident ? 2 : 0);
+  raw->shared = (r->shared_lists ? 1 : 0) | (r->resident ? 2 : 0) | (r->scattered_lists ? 4 : 0);
+  if (r->scattered_lists) { raw->car_base = nullptr; raw->car_len = nullptr; }   // a region's lists are not one arena range: rows[].car_begin alone addresses them
 }
 
 int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw) {
@@ -2145,7 +2273,7 @@ int vs_query_var_in_ref_stream(vs_index* idx, const vs_region* regions, uint64_t
     vs_result* r = new vs_result();
     r->idx = idx;
     idx->live_results++;
-    rc = run_var_in_ref(idx, regions + first, cn, r);   // (returns with the chunk's kernels complete; the previous chunk's copy ran beside them)
+    rc = run_type6(idx, regions + first, cn, r, false, nullptr, /*allow_async=*/false);   // (returns with the chunk's kernels complete; the previous chunk's copy ran beside them)
     if (rc == VS_OK) rc = fetch_region_meta(r);
     if (rc != VS_OK) { drop_result(r, rc); break; }
     const int rcd = deliver();                           // the previous chunk
@@ -2435,3 +2563,5 @@ int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_rec
 }
 
 }  // extern "C"
+
+#include "comm.hip.h"

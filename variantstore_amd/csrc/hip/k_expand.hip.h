@@ -126,12 +126,10 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // one wave of occupancy -- is compiled out.
 // EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
 // per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
-// PART: 0 = the whole task; 1 = only its listed variants, 2 = only its denser ones (the two halves of a launch pair that
-// runs side by side on two streams: the list half is loads and stores, the row half LDS and vector work).
-template <bool WIDE, bool EARLY_NIB, bool TUNE = false, int PART = 0>
+template <bool WIDE, bool EARLY_NIB, bool TUNE = false>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
                                             uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words, unsigned long long* tstat = nullptr) {
-  const uint32_t ablate = (TUNE ? ablate_arg : 0u) | (PART == 2 ? 1u : 0u);   // production instantiations carry no ablation tests
+  const uint32_t ablate = TUNE ? ablate_arg : 0u;   // production instantiations carry no ablation tests
   // tuning builds (option fill_stats): device-clock ticks (10 ns) per phase of the task, summed over the waves
   const uint64_t t_enter = (TUNE && tstat) ? wall_clock64() : 0;
   const uint32_t wpc = im.wpc;
@@ -203,7 +201,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
 
   // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
   //                  list phase runs in the shadow of that memory latency ----------------
-  uint64_t dmask = PART == 1 ? 0ULL : __ballot(cnt > list_max && !explicit_ids);
+  uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
   uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
   uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
   if (dmask) {
@@ -538,7 +536,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   if (TUNE && tstat) tstat[1] = wall_clock64() - t_lists;
 }
 
-template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
+template <bool WIDE, uint32_t CH, bool TUNE>
 __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -560,13 +558,13 @@ __global__ void __launch_bounds__(256) k_fill_carriers(DevImage im, DevResult r,
       gt0 = __builtin_nontemporal_load(&r.r_gt0[a]);
       if (cls == kNone) cnt = 0;   // the row shares another row's list (k_t4_claim): nothing to expand here
     }
-    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
 // The same expansion over the UNIQUE sites of a batch whose carrier lists are shared: the slot parameters come straight
 // from the site table (sequential reads, each site once), the arena offset from k_unique_sites.
-template <bool WIDE, uint32_t CH, bool TUNE, int PART = 0>
+template <bool WIDE, uint32_t CH, bool TUNE>
 __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, const uint32_t* u_site, uint64_t U, uint32_t ablate, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -585,7 +583,7 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, co
       cls = im.s_class[g];
       gt0 = im.s_gt0[g];
     }
-    expand_task<WIDE, false, TUNE, PART>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
+    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words);
   }
 }
 
@@ -626,7 +624,7 @@ __global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, c
       __builtin_amdgcn_s_waitcnt(0);   // the task's parameters are in registers, its rows are on their way
       t_params = wall_clock64() - t_start;
     }
-    expand_task<WIDE, false, TUNE, 0>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words, (TUNE && tstat) ? ph : nullptr);
+    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words, (TUNE && tstat) ? ph : nullptr);
     if (TUNE && tstat && lane == 0)   // one 16-byte record per task, written once at the end: {parameters + rows, list phase, dense phase, whole task | dense variants << 24}
       reinterpret_cast<uint4*>(tstat)[wave] = uint4{(uint32_t)t_params, (uint32_t)ph[0], (uint32_t)ph[1], (uint32_t)(wall_clock64() - t_start) | ((uint32_t)ph[2] << 24)};
   }

@@ -165,7 +165,7 @@ __device__ __forceinline__ RecordBounds record_bounds(const DevImage& im, const 
   return RecordBounds{g0, nsites, fl, im.s_carpre[g0 + nsites] - im.s_carpre[g0]};
 }
 template <int SRC>
-__global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
+__device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult& r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
   ShareMax m{0, 0};
   for (uint32_t i = 0; i < items; ++i) {
@@ -189,9 +189,13 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult
   block_exclusive_max(m, &tot);
   if (threadIdx.x == 0) tile_max[blockIdx.x] = tot;
 }
+template <int SRC>
+__global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
+  plan_bounds<SRC>(im, r, recs, items, tile_max);
+}
 // per region: E_prev (kept for the last pass); per tile: the sums
-__global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
-                                                       uint32_t* status) {
+__device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
+                                         uint32_t* status) {
   __shared__ ShareMax red[kPlanBlock / 64];
   ShareMax pm{0, 0};   // the tiles before this one
   for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kPlanBlock) pm = smax(pm, tile_max[t]);
@@ -221,6 +225,10 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r,
   block_exclusive_scan5(s, &t5);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = t5;
 }
+__global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
+                                                       uint32_t* status) {
+  plan_mid(im, r, tile_max, items, e_prev, tile_sums, status);
+}
 // Rows of the shared table are in site order, so inside a RUN -- a maximal stretch of covered sites -- row number and
 // site index differ by a constant, and so do a list's arena offset and the site table's arena prefix: one record per
 // run turns "row u" into "site g and its arena offset" (k_share_rows2, k_fill_sites2): g = u + dg, car_begin =
@@ -230,9 +238,9 @@ struct RunRec { uint64_t u_start, dg, dc, pad_; };
 struct RowDelta { uint64_t dg, dc; };
 constexpr uint32_t kCoarseRows = 64;
 template <bool RESIDENT>
-__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
-                                                         RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
-                                                         PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
+__device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+                                           RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
+                                           PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
   __shared__ Scan5 red[2][kPlanBlock / 64];
   Scan5 pre{0, 0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0, 0};
   for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) {
@@ -303,6 +311,16 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult 
     __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+template <bool RESIDENT>
+__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+                                                         RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
+                                                         PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
+  plan_apply<RESIDENT>(im, r, e_prev, tile_sums, ntiles, items, runs, coarse, slow_list, totals_host, status, seq, resident_entries);
+}
+// (The three steps as ONE launch with hand-made grid barriers between them -- 512 resident blocks, a growing counter,
+//  agent-scope release / acquire around it -- was built and measured in round 4: 0.19 ms against 0.05 ms for the three
+//  launches.  A barrier across the eight XCDs costs an L2 write-back and invalidate per block: ~70 us each, an order
+//  of magnitude more than the launch gap it replaces.  Removed.)
 // end of a batch: one word into mapped host memory behind everything else on the stream (the host spins on it: the
 // runtime's completion wait costs tens of microseconds more)
 __global__ void k_post_done(uint64_t* flag, uint64_t seq) {

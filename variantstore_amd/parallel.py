@@ -66,6 +66,52 @@ def allgather_hit_lists(result, region_base, device, compact=False, counts=None,
     return out.view(world, max_n, 4), counts
 
 
+def make_comm(store, rank, world, id_file=None):
+    """A `Comm` (the engine's own RCCL communicator, vs_comm_*) for this rank.  The 128-byte unique id is made on rank 0
+    and reaches the other ranks through torch.distributed when a process group exists (any backend), else through
+    `id_file` (rank 0 writes it, the others wait for it)."""
+    import os
+    import time
+    from .api import Comm
+    if dist.is_available() and dist.is_initialized():
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    elif world == 1:
+        uid = Comm.unique_id()
+    else:
+        if id_file is None:
+            raise ValueError("make_comm needs a process group or an id_file")
+        if rank == 0:
+            uid = Comm.unique_id()
+            with open(id_file + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(id_file + ".tmp", id_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(id_file):
+                if time.time() - t0 > 120:
+                    raise TimeoutError(f"no unique id at {id_file}")
+                time.sleep(0.01)
+            with open(id_file, "rb") as f:
+                uid = f.read()
+    return Comm(store, rank, world, uid)
+
+
+def allgather_region_records(comm, result, region_base, device, counts, async_op=False):
+    """The compact all-gatherv of `allgather_hit_lists(compact=True, counts=...)` through the C ABI (vs_comm_allgather_regions:
+    ncclAllGather called by the engine on the communicator's own stream) instead of torch.distributed.  torch only lends
+    the receive buffer.  Returns (records[int64, world x max_n x 4], counts); with async_op the records are valid after
+    `comm.wait()` (or the next all-gather on this communicator)."""
+    world = comm.world
+    if len(counts) != world or int(counts[comm.rank]) != result.num_region_records():
+        raise ValueError("counts does not describe this batch")
+    max_n = max(int(max(counts)), 1)
+    out = torch.empty((world * max_n, 4), dtype=torch.int64, device=device)
+    comm.allgather_regions(result, region_base, max_n, out.data_ptr(), async_op=async_op)
+    return out.view(world, max_n, 4), torch.as_tensor(list(counts), dtype=torch.int64)
+
+
 def unpack_records(records, counts):
     """Host view of gathered records: list of dicts per rank with numpy arrays."""
     out = []
