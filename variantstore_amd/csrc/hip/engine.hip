@@ -75,6 +75,7 @@ struct EngineOpts {
   bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
   uint32_t fill_chunk = 0;      // rows per task of the expansion: 0 = by the batch's shape, else 8 / 16 / 32 / 64
   bool fill_stats = false;      // device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
+  int sc_group = 1;             // lanes per region of the walks of query types 2 / 3 / 5: 1, or 8 lanes running the same chain
   bool walk_stats = false;      // iteration counts and device-clock ticks of k_sample_walk
   uint32_t fill_ablate = 0;     // skip a regime of the expansion
   size_t fill_lds_pad = 0;      // pad the fill kernel's LDS block (occupancy experiments)
@@ -1203,6 +1204,20 @@ static int run_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_res
   return run_private_batch(idx, regions, n, r, regions_on_device, site_records, 0, nullptr, allow_async);
 }
 
+// lanes per region of the one-chain walks of query types 2, 3 and 5 (k_sample_walk_sc, k_sample_seq): 1, or kScGroup running the same chain
+template <int MODE>
+static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const uint32_t* dsids, const WalkScratch& ws) {
+  if (idx->opts.sc_group > 1)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, ws);
+}
+template <int MODE, int PASS>
+static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) {
+  if (idx->opts.sc_group > 1)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, q);
+}
+
 // Query types 4 (walk_mode 4: get_sample_var_in_ref, one sample's path in reference coordinates) and 5 (walk_mode 5:
 // get_sample_var_in_sample).  sample_id: the one sample of the batch, or kNone with one sample per region in sample_ids.
 //   walk   capacities from the type-6 bounds of the same regions (k_walk_caps_sc for type 5), ONE recording walk
@@ -1221,7 +1236,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
   DevImage dwalk = idx->d;   // what the type-4 walk sees: with or without the event bitmaps
   if (idx->opts.t4_walk == 0) dwalk.t4_events = nullptr;
   auto counting_walk = [&]() {
-    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, WalkScratch{});
+    if (walk_mode == 5) launch_walk_sc<0>(idx, d, n, dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
   };
   if (n && !idx->opts.force_fallbacks) {
@@ -1249,7 +1264,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
       HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, idx->stream));
     }
 #endif
-    if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, ws);
+    if (walk_mode == 5) launch_walk_sc<2>(idx, d, n, dsids, ws);
     else if (dwalk.t4_events && idx->opts.t4_walk == 2)   // 8 lanes per region: the episodes of a region run in parallel
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
@@ -1319,7 +1334,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     else if (single_walk && c.resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 2>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (single_walk && share_t4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 1>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     else if (single_walk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_from_walk<true, 0>), g16, dim3(256), 0, idx->stream, idx->d, d, ws, lc);
-    else if (walk_mode == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<1>), g64, dim3(64), 0, idx->stream, idx->d, d, dsids, WalkScratch{});
+    else if (walk_mode == 5) launch_walk_sc<1>(idx, d, n, dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<1>), g64, dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
     HIP_TRY(hipGetLastError());
   }
@@ -1432,7 +1447,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
-  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  
   ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
   // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
@@ -1449,8 +1464,8 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     VS_TRY(ralloc(r, totals[0], &q.seg_len));
     VS_TRY(ralloc(r, totals[0], &q.seg_dst));
     q.relative = 1;
-    if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 2>), grid, block, 0, idx->stream, idx->d, q);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 2>), grid, block, 0, idx->stream, idx->d, q);
+    if (mode == 2) launch_sample_seq<2, 2>(idx, q, n);
+    else launch_sample_seq<3, 2>(idx, q, n);
     HIP_TRY(hipGetLastError());
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
     uint64_t over = 0;
@@ -1467,8 +1482,8 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   }
   if (!single_walk) {
     if (n) {
-      if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 0>), grid, block, 0, idx->stream, idx->d, q);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 0>), grid, block, 0, idx->stream, idx->d, q);
+      if (mode == 2) launch_sample_seq<2, 0>(idx, q, n);
+      else launch_sample_seq<3, 0>(idx, q, n);
       HIP_TRY(hipGetLastError());
     }
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
@@ -1482,8 +1497,8 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     VS_TRY(ralloc(r, totals[1], &q.chars));
     r->seq_bytes = totals[1];
     if (n) {
-      if (mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<2, 1>), grid, block, 0, idx->stream, idx->d, q);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<3, 1>), grid, block, 0, idx->stream, idx->d, q);
+      if (mode == 2) launch_sample_seq<2, 1>(idx, q, n);
+      else launch_sample_seq<3, 1>(idx, q, n);
       hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, idx->stream, idx->d, q);
       HIP_TRY(hipGetLastError());
     }
@@ -1940,12 +1955,13 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value < 0 || value > 2) return fail(VS_ERR_ARG, "t4_walk takes 0 (literal), 1 (one lane per region, jumping) or 2 (cooperative, default)");
     o.t4_walk = (int)value;
   } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
-  else if (k == "lat_debug" || k == "fill_fused" || k == "fill_chunk" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
+  else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
     if (k == "lat_debug") o.lat_debug = value != 0;
     else if (k == "fill_fused") o.fill_fused = value != 0;
+    else if (k == "sc_group") o.sc_group = value > 1 ? 8 : 1;
     else if (k == "fill_chunk") {
       if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
       o.fill_chunk = (uint32_t)value;

@@ -202,11 +202,18 @@ __global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) 
   r.q_nvar[q] = (s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0) + 8;
 }
 
-// Query type 5.  One thread per region; MODE as in k_sample_walk (0 count, 1 emit, 2 record once).
-template <int MODE>
-__global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+// Query type 5.  MODE as in k_sample_walk (0 count, 1 emit, 2 record once).
+// SUB lanes per region, all of them running the SAME walk (round 4): a region's walk is one serial chain of dependent
+// look-ups, so the only parallelism is across regions -- and with one lane per region a batch of 100 k regions is 1,563
+// waves (1.5 per SIMD: nothing hides a memory latency) that each run 64 different chains one after the other (64-way
+// divergence).  With SUB = 8 the lanes of a group issue the same addresses (one request), a wave diverges 8 ways, and
+// the batch is 12,500 waves: every SIMD holds eight.  Lane 0 of a group writes.
+constexpr uint32_t kScGroup = 8;
+template <int MODE, uint32_t SUB = kScGroup>
+__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
   constexpr bool EMIT = MODE == 1;
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  const bool lead = (threadIdx.x % SUB) == 0;
   if (q >= r.Q) return;
   const uint32_t sid = sid_per_region[q];
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
@@ -285,12 +292,12 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           if (cur_ref_v != kNone) { ro = im.v_off[cur_ref_v]; rl = im.v_len[cur_ref_v]; }
         }
         const uint32_t c = ncar_v;
-        if (EMIT) {
+        if (EMIT && lead) {
           const uint64_t a = a0 + nvar;
           row_store(r.rows, a, (uint32_t)pos, ro, rl, ao, al, c, false, cb + ncar);
           r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
-        if (MODE == 2) {
+        if (MODE == 2 && lead) {
           const uint64_t s0 = ws.cap_begin[q];
           if (nvar < ws.cap_begin[q + 1] - s0) {
             const uint64_t s = s0 + nvar;
@@ -347,12 +354,12 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
           if (cur_ref_v != kNone) { const WalkVertex wr = walk_vertex(im, cur_ref_v); ro = wr.off; rl = wr.len; }
         }
         const uint32_t c = wc.ncar;
-        if (EMIT) {
+        if (EMIT && lead) {
           const uint64_t a = a0 + nvar;
           row_store(r.rows, a, (uint32_t)pos, ro, rl, ao, al, c, false, cb + ncar);
           r.r_class[a] = im.v_src[cur]; r.r_gt0[a] = im.v_car_begin[cur];
         }
-        if (MODE == 2) {
+        if (MODE == 2 && lead) {
           const uint64_t s0 = ws.cap_begin[q];
           if (nvar < ws.cap_begin[q + 1] - s0) {
             const uint64_t s = s0 + nvar;
@@ -369,6 +376,7 @@ __global__ void __launch_bounds__(64) k_sample_walk_sc(DevImage im, DevResult r,
       cur = nxt;
     }
   }
+  if (!lead) return;
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
   else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
 }
@@ -389,19 +397,19 @@ struct DevSeqResult {
   uint32_t relative, pad_;          // single-walk mode: pieces sit at seg_begin[q] .. + q_nseg[q], seg_begin = capacities' scan
 };
 
-struct SeqSink {
-  uint64_t nseg, nbytes;
-};
-
 // PASS 0 counts, PASS 1 writes the pieces at their scanned places (second walk), PASS 2 is the single walk: pieces go
 // to the region's slice of a capacity-sized list with byte offsets relative to the region's first byte.
+struct SeqSink {
+  uint64_t nseg, nbytes;
+  bool lead;   // this lane writes for its region (lane 0 of the group that walks it)
+};
 template <int PASS>
 __device__ __forceinline__ void seq_append(const DevSeqResult& r, SeqSink& s, uint64_t seg0, uint64_t byte0, uint32_t off,
                                            uint64_t len, uint64_t cap) {
   if (len == 0) return;
   if (PASS == 1 || (PASS == 2 && s.nseg < cap)) {
-    r.seg_src[seg0 + s.nseg] = off; r.seg_len[seg0 + s.nseg] = (uint32_t)len; r.seg_dst[seg0 + s.nseg] = byte0 + s.nbytes;
-  } else if (PASS == 2) *r.overflow = 1;
+    if (s.lead) { r.seg_src[seg0 + s.nseg] = off; r.seg_len[seg0 + s.nseg] = (uint32_t)len; r.seg_dst[seg0 + s.nseg] = byte0 + s.nbytes; }
+  } else if (PASS == 2 && s.lead) *r.overflow = 1;
   s.nseg++; s.nbytes += len;
 }
 
@@ -431,16 +439,17 @@ __device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uin
   return 0;
 }
 
-template <int MODE, int PASS>
-__global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// (SUB lanes per region running the same walk, lane 0 writing: see k_sample_walk_sc)
+template <int MODE, int PASS, uint32_t SUB = kScGroup>
+__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, DevSeqResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
   if (q >= r.Q) return;
   if (PASS == 1 && r.q_flags[q]) return;
   const uint32_t sid = r.sids[q];
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   const uint64_t seg0 = PASS ? r.seg_begin[q] : 0, byte0 = PASS == 1 ? r.byte_begin[q] : 0;
   const uint64_t cap = PASS == 2 ? r.seg_begin[q + 1] - seg0 : 0;
-  SeqSink s{0, 0};
+  SeqSink s{0, 0, (threadIdx.x % SUB) == 0};
   uint8_t fl = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t cur = 0;
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(64) k_sample_seq(DevImage im, DevSeqResult r) 
       cur = nxt;
     }
   }
-  if (PASS != 1) {
+  if (PASS != 1 && s.lead) {
     r.q_flags[q] = fl;
     r.q_nseg[q] = fl ? 0 : s.nseg;
     r.q_nbytes[q] = fl ? 0 : s.nbytes;
