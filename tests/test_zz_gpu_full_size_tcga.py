@@ -1,0 +1,220 @@
+"""BASELINE.json configs[4] at FULL size on the GPU: the TCGA-shaped cohort of `bench.py --workload tcga-10k` (10,000 samples,
+20 M variants incl. 10 % indels, somatic-like sparse carriers -> explicit sample ids, wide 32-bit carrier words), 100,000
+regions of 10 kb, mixed query types 3 / 6 / 7 (src/commands.cc:161-189).  The CPU oracle cannot hold this index in
+reasonable time, so exactness at this size rests on size-independent properties -- shared against private rows and lists,
+additivity over batch splits, a region's answer whatever batch it travels in, type 4 inside type 6 -- and, for the same
+generator at 1/50 of the length, on the oracle itself for the three types in one run.  (Named to run last: the index
+takes ~2.5 minutes of host time to build.)"""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+from oracle.oracle import Oracle
+from variantstore_amd import VariantStore
+
+pytestmark = pytest.mark.gpu
+
+W = bench.WORKLOADS["tcga-10k"]
+
+
+@pytest.fixture(scope="module")
+def tcga():
+    vs = VariantStore.synthetic(device=0, sample_coordinates=True, **bench.synth_kwargs(W))
+    regions = bench.make_regions(W, 0, W["regions"])
+    yield vs, regions
+    vs.close()
+
+
+def _parse_rows(text):
+    out = []
+    for line in text.split("\n")[1:]:
+        if line:
+            pos, ref, alt, _ = line.split("\t")
+            out.append((int(pos), ref, alt))
+    return out
+
+
+def test_type6_shared_private_and_split_batches_agree(tcga):
+    vs, regions = tcga
+    info = vs.info()
+    assert not info.use_bit_vector and info.num_samples == 10_001 and info.num_sites > 19_000_000
+    a = vs.get_var_in_ref(regions)
+    slots, table, arena, lists, shared = a.layout()
+    ta, da = a.totals(), a.digest()
+    assert shared and ta[0] == 100_000 and ta[1] > 50_000_000 and lists <= table < slots
+    b = vs.get_var_in_ref(regions)
+    assert (b.totals(), b.digest()) == (ta, da)
+    b.close()
+    # additivity over batch splits (each split shares among its own regions: other tables, the same per-region answers)
+    parts = [vs.get_var_in_ref(regions[i::4]) for i in range(4)]
+    assert tuple(sum(p.totals()[k] for p in parts) for k in range(4)) == ta
+    for p in parts:
+        p.close()
+    # private rows and lists: the same digest over the whole batch
+    vs.set_option("share_lists", 0)
+    try:
+        p = vs.get_var_in_ref(regions)
+    finally:
+        vs.set_option("share_lists", 1)
+    assert not p.layout()[4] and p.layout()[1] == slots and (p.totals(), p.digest()) == (ta, da)
+    probes = (0, 1, 33_333, 99_999)
+    texts = {q: a.region_text(q) for q in probes}
+    for q in probes:
+        assert p.region_text(q) == texts[q]
+    p.close()
+    # a region's rows do not depend on the batch around it (latency path), nor on the order of the batch (device-side sort)
+    for q in probes:
+        single = vs.get_var_in_ref(regions[q:q + 1])
+        assert single.region_text(0) == texts[q]
+        single.close()
+    rev = vs.get_var_in_ref(regions[::-1].copy())
+    assert rev.totals() == ta
+    for q in probes:
+        assert rev.region_text(100_000 - 1 - q) == texts[q]
+    rev.close()
+    # structure of the carrier lists of 300 regions: sample ids in range ("ref" is never a carrier), a non-zero allele on every
+    # carrier, lists back to back in the view, positions inside their region
+    sub = vs.get_var_in_ref(regions[50_000:50_300])
+    v = sub.view(with_carriers=True)
+    car = v["carriers"]
+    ids = (car & np.uint32(0x1FFFFFFF)).astype(np.int64)
+    gt = car >> np.uint32(29)
+    assert len(car) == int(v["car_count"].sum()) > 100_000 and ids.min() >= 1 and ids.max() <= 10_000
+    assert ((gt & 6) != 0).all()
+    begin, cnt = v["car_begin"].astype(np.int64), v["car_count"].astype(np.int64)
+    assert (begin[1:] == begin[:-1] + cnt[:-1]).all() and begin[0] == 0
+    vb = v["var_begin"].astype(np.int64)
+    for q in range(300):
+        pq = v["pos"][vb[q]:vb[q + 1]].astype(np.int64)
+        if len(pq):
+            assert pq.min() >= int(regions[50_000 + q, 0]) and pq.max() < int(regions[50_000 + q, 1])
+    sub.close()
+    a.close()
+
+
+def test_type4_inside_type6_and_walk_forms_agree(tcga):
+    """Type 4 (one sample's variants over a region) reports a subset of type 6's positions; the cooperative and the
+    one-lane walk give the same digest over the whole batch (searches of thousands of ranks: the hop phase)."""
+    vs, regions = tcga
+    rng = np.random.default_rng(9)
+    per = rng.integers(1, 10_001, size=len(regions)).astype(np.uint32)
+    fast = vs.get_sample_var_in_ref(regions, per)
+    tf, df = fast.totals(), fast.digest()
+    vs.set_option("t4_walk", 1)
+    try:
+        other = vs.get_sample_var_in_ref(regions, per)
+    finally:
+        vs.set_option("t4_walk", 2)
+    assert (other.totals(), other.digest()) == (tf, df)
+    other.close()
+    # (SNPs only: the two queries report a deletion / an insertion at different coordinates -- query.h:336-393 against :680-704)
+    t6 = vs.get_var_in_ref(regions[:2000])
+    hits = 0
+    for q in range(0, 2000, 5):
+        snps4 = {(p, r, a) for p, r, a in _parse_rows(fast.region_text(q)) if len(r) == 1 and len(a) == 1}
+        if snps4:
+            assert snps4 <= set(_parse_rows(t6.region_text(q))), q
+            hits += len(snps4)
+    assert hits > 20
+    t6.close()
+    fast.close()
+
+
+def test_types_3_and_7_at_full_size(tcga):
+    """Type 7 finds every variant type 6 reports at the position `find` resolves (and a miss beside it); type 3 (a sample's
+    sequence in its own coordinates) is additive over batch splits and a region's sequence does not depend on its batch."""
+    vs, regions = tcga
+    t6 = vs.get_var_in_ref(regions[10_000:10_040])
+    rows = []
+    for q in range(40):
+        rows += _parse_rows(t6.region_text(q))
+    t6.close()
+    rows = rows[:600]
+    qs = [(p, r, a) for p, r, a in rows] + [(p + 1, r, a) for p, r, a in rows]
+    res = vs.samples_has_var([q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs])
+    fl = res.view(False)["region_flags"]
+    found = int((fl[:len(rows)] & 4 == 0).sum())
+    # (type 7 only finds a variant whose position `find` resolves to the start of its anchor node -- the reference's quirk,
+    #  SURVEY 4.3; the slice test below holds every answer against the oracle.  Here: some are found, every found one names
+    #  its carriers, and a second batch in another order gives the same flags)
+    assert found >= 10
+    for q in np.nonzero(fl[:len(rows)] & 4 == 0)[0][:50]:
+        assert res.region_text(int(q)).strip() != ""
+    res.close()
+    order = np.random.default_rng(4).permutation(len(qs))
+    res2 = vs.samples_has_var([qs[i][0] for i in order], [qs[i][1] for i in order], [qs[i][2] for i in order])
+    assert np.array_equal(res2.view(False)["region_flags"], fl[order])
+    res2.close()
+    rng = np.random.default_rng(10)
+    per = rng.integers(1, 10_001, size=20_000).astype(np.uint32)
+    sub = regions[:20_000]
+    whole = vs.query_sample_seq(sub, per, sample_coordinates=True)
+    fw, sw = whole.sequences()
+    nb = whole.totals()[3]
+    halves = [vs.query_sample_seq(sub[i::2], per[i::2], sample_coordinates=True) for i in range(2)]
+    assert sum(h.totals()[3] for h in halves) == nb
+    for i, h in enumerate(halves):
+        fh, sh = h.sequences()
+        assert np.array_equal(fh, fw[i::2]) and sh[:50] == sw[i::2][:50]
+        h.close()
+    ok = fw == 0
+    assert ok.sum() > 15_000 and all(len(sw[q]) > 9_000 for q in np.nonzero(ok)[0][:200])
+    whole.close()
+
+
+def test_one_fiftieth_slice_against_the_oracle_mixed_types(tmp_path):
+    """The same generator at 1/50 of the length (400,000 variants, 10,000 samples), types 3 / 6 / 7 mixed in one run,
+    against the CPU oracle as text."""
+    kw = bench.synth_kwargs(W)
+    kw["ref_length"] //= 50
+    kw["num_variants"] //= 50
+    vs = VariantStore.synthetic(device=0, sample_coordinates=True, **kw)
+    plain = os.path.join(tmp_path, "slice.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    sub = dict(W, **kw)
+    regions = [(int(x), int(y)) for x, y in bench.make_regions(sub, 77, 600)]
+    res = vs.get_var_in_ref(regions)
+    assert res.layout()[4]
+    rows, carriers = [], set()
+    for q, (x, y) in enumerate(regions):
+        n, _, text = orc.get_var_in_ref(x, y)
+        assert n >= 0 and res.region_text(q) == text, (q, x, y)
+        if q < 40:
+            rows += _parse_rows(text)
+            carriers |= {s.split("(")[0] for line in text.split("\n")[1:-1] for s in line.split("\t")[3].split()}
+    res.close()
+    qs = [(p, r, a) for p, r, a in rows[:300]] + [(p + 1, r, a) for p, r, a in rows[:300]]
+    r7 = vs.samples_has_var([q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs])
+    fl = r7.view(False)["region_flags"]
+    for q, (p, r, a) in enumerate(qs):
+        want = orc.samples_has_var(p, r, a)
+        assert (want is None) == bool(fl[q] & 4) and (want is None or r7.region_text(q) == want), qs[q]
+    r7.close()
+    names = sorted(carriers)[:5]
+    assert len(names) >= 3
+    per = [names[i % len(names)] for i in range(200)]
+    r4 = vs.get_sample_var_in_ref(regions[:200], per)      # (type 4 as well: the long backward searches of this cohort shape)
+    for q, (x, y) in enumerate(regions[:200]):
+        n, _, text = orc.get_sample_var_in_ref(x, y, per[q])
+        if n >= 0:
+            assert r4.region_text(q) == text, (q, x, y, per[q])
+    r4.close()
+    r3 = vs.query_sample_seq(regions[:200], per, sample_coordinates=True)
+    f3, seqs = r3.sequences()
+    good = 0
+    for q, (x, y) in enumerate(regions[:200]):
+        n, seq = orc.query_sample_from_sample(x, y, per[q])
+        if n == -1:
+            assert f3[q] & 8
+        elif n == -3:
+            assert f3[q] & 2
+        else:
+            assert not f3[q] and seqs[q] == seq, (per[q], x, y)
+            good += 1
+    assert good > 150
+    r3.close()
+    orc.close()
+    vs.close()

@@ -23,7 +23,8 @@ blob = None
 if dirs and dirs[0].startswith("--blob="):
     blob, dirs = dirs[0].split("=", 1)[1].strip(), dirs[1:]
 raw = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs))
-NAMES = ["k_fill_carriers", "k_fill_sites", "k_share_rows", "k_share_apply", "k_emit_headers", "k_region_bounds", "k_sample_walk_coop", "k_sample_walk_sc",
+NAMES = ["k_fill_carriers", "k_fill_sites2", "k_fill_sites", "k_share_rows2", "k_t6_bounds", "k_t6_mid", "k_t6_apply", "k_t6_slow", "k_emit_headers", "k_region_bounds",
+         "k_sample_walk_coop", "k_sample_walk_sc",
          "k_sample_walk", "k_emit_from_walk", "k_t4_claim", "k_point_bounds", "k_has_var_filter", "k_sample_seq", "k_copy_segments"]
 NAMES.sort(key=len, reverse=True)   # (longest first: k_sample_walk is a prefix of two others)
 kernels = {}

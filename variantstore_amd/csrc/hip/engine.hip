@@ -488,7 +488,7 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
   //      what this part has plenty of).  Skipped when they would take more than half of the free memory or the cap below. ----
-  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0;
+  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0; d.t4_irr = nullptr;
   if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
     const uint64_t stride = (im.P + 63) / 64 + 1, hstride = (im.V + 63) / 64 + 1;
     const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
@@ -501,7 +501,9 @@ static int build_device_image(vs_index* idx) {
     if (const char* gb = getenv("VS_T4_ROWS_MAX_GB")) cap = (uint64_t)std::max(0.0, atof(gb)) << 30;
     if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
       idx->t4_rows_bytes = bytes + hbytes;
-      uint64_t *events = nullptr, *hold = nullptr;
+      uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
+      VS_TRY(alloc_image(idx, (size_t)stride, &irr));
+      HIP_TRY(hipMemsetAsync(irr, 0, stride * 8, idx->stream));
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
       HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
@@ -509,15 +511,15 @@ static int build_device_image(vs_index* idx) {
       d.t4_stride = stride; d.t4_hold_stride = hstride;
       const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
       if (d.use_bv) {
-        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
+        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events, irr);
         hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, d, hold);
       } else {
-        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events);
+        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, irr);
         hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
         hipLaunchKernelGGL(k_hold_explicit, dim3((unsigned)((im.V + 255) / 256)), dim3(256), 0, idx->stream, d, hold);
       }
       HIP_TRY(hipGetLastError());
-      d.t4_events = events; d.t4_hold = hold;
+      d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr;
     }
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));

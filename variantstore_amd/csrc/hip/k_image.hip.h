@@ -63,6 +63,11 @@ struct DevImage {
   // the rank structure one to one) -- the walk then visits every vertex.
   const uint64_t* t4_events;
   uint64_t t4_stride;       // 64-bit words per sample row: ceil(P / 64) + 1
+  // Round 4: the sample-INDEPENDENT part of an event -- the node is irregular -- lives in ONE global row (t4_irr, t4_stride
+  // words) instead of in every sample's; t4_events holds "the node or an out-neighbour holds the sample" alone.  The walks
+  // jump by the OR of the two; the backward searches enumerate the sample's own bits only (every ~40th slot is irregular:
+  // on a cohort whose samples have a variant every 15 kb that was 97 % of a long search's candidates).
+  const uint64_t* t4_irr;
   // Per-sample HOLD rows over the vertex ids (k_build_hold): bit v of row s = vertex v holds sample s (what
   // get_sample_from_vertex_if_exists answers).  Vertex ids grow along the reference, so every test of one walk step --
   // the node, its neighbours, the neighbours' neighbours -- falls into one or two 64-bit words of the sample's row

@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
   // there; ref_pos, sample_pos and cur_ref advance with the path), and only a vertex that holds the sample pays the
   // look-up of its sample-coordinate index.
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0;
-  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
+  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
+  BitRow evw{ev.row, kNone, 0, fast ? im.t4_irr : nullptr};                             // | the irregular slots: the walk's jumps
   BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
   BitRow brk{im.seq_breaks, kNone, 0};
   const bool rewound = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
       if (slot1 && ref_pos == ridx) {
         const uint32_t s0 = slot1 - 1;
         const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;
-        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
+        uint32_t k = s0 < lim ? evw.next(s0, lim) : s0;
         if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];
@@ -458,7 +459,8 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
   // without a neighbour holding the sample, and the walk turns every uneventful run of ref-path slots into ONE piece.
   // (not for y < x: the window's `y - x` then wraps and is clipped to the VERTEX it is applied to -- a merged run would clip differently)
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x;
-  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
+  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
+  BitRow evw{ev.row, kNone, 0, fast ? im.t4_irr : nullptr};                             // | the irregular slots: the walk's jumps
   BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
   BitRow brk{im.seq_breaks, kNone, 0};
   if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
@@ -477,7 +479,7 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
       if (slot1 && (MODE != 2 || ref_pos == ridx)) {
         const uint32_t s0 = slot1 - 1;
         const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;   // (bounded look-ahead: a clear slot `lim` is as good a place to land)
-        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
+        uint32_t k = s0 < lim ? evw.next(s0, lim) : s0;
         if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];

@@ -22,7 +22,7 @@ __device__ __forceinline__ bool vertex_has_sample(const DevImage& im, uint32_t v
 }
 
 // ---------------------------------------------------------------------------
-// Event bitmaps of query type 4 (DevImage::t4_events), built once when an index is opened.
+// Event bitmaps of query type 4 (DevImage::t4_events + the global t4_irr), built once when an index is opened.
 // One wave per tile of 64 consecutive ref-path slots: lane j ORs the class rows of slot j's node and of its
 // out-neighbours one 64-sample word at a time, a 64 x 64 bit transpose through 64 ballots turns "samples of a slot"
 // into "slots of a sample", and lane t stores the tile's word of sample w * 64 + t.
@@ -38,7 +38,7 @@ __device__ __forceinline__ bool slot_is_irregular(const DevImage& im, uint64_t j
   return last_ref != succ;
 }
 
-__global__ void __launch_bounds__(256) k_build_events(DevImage im, uint64_t* events) {
+__global__ void __launch_bounds__(256) k_build_events(DevImage im, uint64_t* events, uint64_t* irr_row) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t tile = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t ntiles = (im.P + 63) >> 6;
@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) k_build_events(DevImage im, uint64_t* eve
   const uint64_t j = tile * 64 + lane;
   const bool valid = j < im.P;
   const uint64_t irr = __ballot(valid && slot_is_irregular(im, j));
+  if (lane == 0) irr_row[tile] = irr;   // the sample-independent part, once (round 4: it used to be OR-ed into every sample's row)
   const uint32_t v = valid ? im.rp_vid[j] : 0;
   const uint32_t e0 = valid ? im.row_ptr[v] : 0, e1 = valid ? im.row_ptr[v + 1] : 0;
   const uint32_t wpc = im.wpc;
@@ -62,20 +63,20 @@ __global__ void __launch_bounds__(256) k_build_events(DevImage im, uint64_t* eve
       if (lane == b) mine = m;
     }
     const uint32_t sample = w * 64 + lane;
-    if (sample >= 1 && sample < im.num_samples) events[(uint64_t)sample * im.t4_stride + tile] = mine | irr;
+    if (sample >= 1 && sample < im.num_samples) events[(uint64_t)sample * im.t4_stride + tile] = mine;
   }
 }
 
-// explicit-id cohorts (no class rows): the rows start as the irregular mask, then every carrier record of a slot's
-// node and of its out-neighbours sets its sample's bit
-__global__ void __launch_bounds__(256) k_events_irregular_rows(DevImage im, uint64_t* events) {
+// explicit-id cohorts (no class rows): the global irregular row, then every carrier record of a slot's node and of its
+// out-neighbours sets its sample's bit in the (zeroed) per-sample rows
+__global__ void __launch_bounds__(256) k_events_irregular_rows(DevImage im, uint64_t* irr_row) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t tile = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t ntiles = (im.P + 63) >> 6;
   if (tile >= ntiles) return;
   const uint64_t j = tile * 64 + lane;
   const uint64_t irr = __ballot(j < im.P && slot_is_irregular(im, j));
-  for (uint32_t s = 1 + lane; s < im.num_samples; s += 64) events[(uint64_t)s * im.t4_stride + tile] = irr;
+  if (lane == 0) irr_row[tile] = irr;
 }
 __global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* events) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,8 +199,9 @@ struct BitRow {
   const uint64_t* __restrict__ row;
   uint32_t w;          // index of the cached word (kNone: nothing cached)
   uint64_t word;
+  const uint64_t* __restrict__ row2 = nullptr;   // a second row OR-ed in (the walk's event row = the sample's events | the global irregular slots)
   __device__ __forceinline__ uint64_t at(uint32_t wi) {
-    if (wi != w) { w = wi; word = row[wi]; }
+    if (wi != w) { w = wi; word = row2 ? (row[wi] | row2[wi]) : row[wi]; }
     return word;
   }
   __device__ __forceinline__ bool bit(uint32_t i) { return (at(i >> 6) >> (i & 63)) & 1; }
@@ -460,7 +462,8 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0, rank0 = 0;
   const uint8_t fl = walk_prologue(im, cx, rank0);
   if (!fl) {
-    BitRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};
+    BitRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the search
+    BitRow evw{ev.row, kNone, 0, cx.use_ev ? im.t4_irr : nullptr};                                   // | the irregular slots: the walk's jumps
     BitRow hold{cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr, kNone, 0};
     const uint64_t t_s0 = VS_WALK_CLOCK();
     uint32_t st_iters = 0, st_lit = 0, st_jumps = 0, st_steps = 0;
@@ -487,8 +490,8 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       }
       nvar++; ncar += pad_car(em.c); ncar_kept += em.c;
     };
-    if (cx.use_ev) walk_serial<true>(im, cx, ev, hold, st, sink, st_jumps, st_steps);
-    else walk_serial<false>(im, cx, ev, hold, st, sink, st_jumps, st_steps);
+    if (cx.use_ev) walk_serial<true>(im, cx, evw, hold, st, sink, st_jumps, st_steps);
+    else walk_serial<false>(im, cx, evw, hold, st, sink, st_jumps, st_steps);
     const uint64_t t_s2 = VS_WALK_CLOCK();
     VS_WALK_STAT(0, 1); VS_WALK_STAT(1, st_iters); VS_WALK_STAT(2, st_lit); VS_WALK_STAT(3, st_jumps); VS_WALK_STAT(4, st_steps);
     VS_WALK_STAT(5, t_s1 - t_s0); VS_WALK_STAT(6, t_s2 - t_s1); VS_WALK_STAT(7, nvar);
@@ -561,7 +564,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
   uint32_t cur_slot = 0;     // slot at which the chain is in step
   uint64_t s0 = 0, scap = 0;
-  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0};
+  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0}, evw{nullptr, kNone, 0};   // ev: the sample's own events (search); evw: | the irregular slots (walk)
   WalkSt st{};
   const uint64_t t_c0 = VS_WALK_CLOCK();
   uint64_t t_c1 = t_c0, t_c2 = t_c0;
@@ -571,6 +574,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
     if (!fl) {
       ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
+      evw.row = ev.row; evw.row2 = cx.use_ev ? im.t4_irr : nullptr;
       hold.row = cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr;
       if (!cx.use_ev) serial = true;
     }
@@ -704,7 +708,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (busy) ++n_chunks;
     // the next 16 events at or after cur_slot, one per lane: lane l loads word l of the row from cur_slot's word on
     const uint32_t w0 = cur_slot >> 6, w_end = (cx.limit + 63) >> 6, wi = w0 + l;
-    uint64_t word = (busy && wi < w_end) ? ev.row[wi] : 0;
+    uint64_t word = (busy && wi < w_end) ? (ev.row[wi] | im.t4_irr[wi]) : 0;
     if (l == 0) word &= ~0ULL << (cur_slot & 63);
     if (busy && wi == (cx.limit >> 6) && (cx.limit & 63)) word &= (1ULL << (cx.limit & 63)) - 1;
     const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);
@@ -790,15 +794,15 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (serial) {
       uint32_t it = 0, lit = 0, jm = 0, sp = 0;
       nvar = 0; ncar = 0;
-      ev.w = kNone; hold.w = kNone;
+      ev.w = kNone; hold.w = kNone; evw.w = kNone;
       auto sink = [&](const WalkEmit& e1) {
         if (nvar < scap) {
           if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
         } else if (l == 0) *ws.overflow = 1;
         nvar++; ncar += pad_car(e1.c);
       };
-      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, ev, hold, st, sink, jm, sp); }
-      else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, ev, hold, st, sink, jm, sp); }
+      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, evw, hold, st, sink, jm, sp); }
+      else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, evw, hold, st, sink, jm, sp); }
     }
   }
   if (live && l == 0) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
