@@ -227,7 +227,6 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
   // look-up of its sample-coordinate index.
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0;
   BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
-  BitRow evw{ev.row, kNone, 0, fast ? im.t4_irr : nullptr};                             // | the irregular slots: the walk's jumps
   BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
   BitRow brk{im.seq_breaks, kNone, 0};
   const bool rewound = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)
@@ -251,7 +250,12 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
       if (slot1 && ref_pos == ridx) {
         const uint32_t s0 = slot1 - 1;
         const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;
-        uint32_t k = s0 < lim ? evw.next(s0, lim) : s0;
+        // (the sample's OWN events.  An irregular slot -- its LAST ref neighbour is not its successor -- sets ref_pos and cur_ref
+        //  for the NEXT vertex only, and those are read only if that vertex is reported, i.e. holds the sample: then the slot
+        //  has an out-neighbour holding the sample and is an event of its own.  Unlike type 4 the loop stops on sample_pos, which
+        //  advances by lengths alone.  What else could break a run -- the smallest-index ref neighbour is not the successor, ref
+        //  indexes that do not continue -- is in the break bits.)
+        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
         if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];
@@ -460,7 +464,6 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
   // (not for y < x: the window's `y - x` then wraps and is clipped to the VERTEX it is applied to -- a merged run would clip differently)
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x;
   BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
-  BitRow evw{ev.row, kNone, 0, fast ? im.t4_irr : nullptr};                             // | the irregular slots: the walk's jumps
   BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
   BitRow brk{im.seq_breaks, kNone, 0};
   if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
@@ -479,7 +482,9 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
       if (slot1 && (MODE != 2 || ref_pos == ridx)) {
         const uint32_t s0 = slot1 - 1;
         const uint32_t lim = s0 + 1024 < last_slot ? s0 + 1024 : last_slot;   // (bounded look-ahead: a clear slot `lim` is as good a place to land)
-        uint32_t k = s0 < lim ? evw.next(s0, lim) : s0;
+        // (the sample's OWN events: an irregular slot -- its LAST ref neighbour is not its successor -- is nothing to a sequence
+        //  walk, which follows the FIRST ref neighbour and the smallest-index one; what could break a run here is in the break bits)
+        uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
         if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];
