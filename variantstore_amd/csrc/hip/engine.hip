@@ -519,7 +519,7 @@ static int build_device_image(vs_index* idx) {
         hipLaunchKernelGGL(k_hold_explicit, dim3((unsigned)((im.V + 255) / 256)), dim3(256), 0, idx->stream, d, hold);
       }
       HIP_TRY(hipGetLastError());
-      d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr;
+      d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr; d.t4_irr_reach = im.irr_reach;
     }
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));

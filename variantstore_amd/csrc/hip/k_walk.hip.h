@@ -199,9 +199,17 @@ struct BitRow {
   const uint64_t* __restrict__ row;
   uint32_t w;          // index of the cached word (kNone: nothing cached)
   uint64_t word;
-  const uint64_t* __restrict__ row2 = nullptr;   // a second row OR-ed in (the walk's event row = the sample's events | the global irregular slots)
+  // a second row OR-ed in from bit `from2` on (the type-4 walk's event row = the sample's events | the global irregular slots
+  // near the region's stop slot)
+  const uint64_t* __restrict__ row2 = nullptr;
+  uint32_t from2 = 0;
+  __device__ __forceinline__ uint64_t word2(uint32_t wi) const {
+    if (wi < (from2 >> 6)) return 0;
+    const uint64_t x = row2[wi];
+    return wi == (from2 >> 6) ? x & (~0ULL << (from2 & 63)) : x;
+  }
   __device__ __forceinline__ uint64_t at(uint32_t wi) {
-    if (wi != w) { w = wi; word = row2 ? (row[wi] | row2[wi]) : row[wi]; }
+    if (wi != w) { w = wi; word = row2 ? (row[wi] | word2(wi)) : row[wi]; }
     return word;
   }
   __device__ __forceinline__ bool bit(uint32_t i) { return (at(i >> 6) >> (i & 63)) & 1; }
@@ -224,7 +232,7 @@ typedef BitRow EventRow;
 // Two data paths, chosen per region: BLOB (the sample has event + hold rows: records from the walk blob, "does v hold
 // the sample" from the hold row, jumps over uneventful runs) and plain (sample 0 = "ref", or an index without the rows:
 // the round-2 records, class rows, every vertex visited).  WalkVertex::row_begin indexes the blob resp. w_edge.
-struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; };
+struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; uint32_t irr_from; };   // irr_from: irregular slots count as events from here on (walk_prologue)
 struct WalkSt { uint32_t cur; WalkVertex wc; uint64_t ref_pos; uint32_t cur_ref_v, cur_slot1; };   // cur_slot1: ref-path slot + 1 of cur, 0 = off the path
 struct WalkEmit { uint64_t ref_pos; uint32_t cur, kind, cur_ref_v, c; };   // the walk's state at a reported vertex (-> resolve_walk_variant)
 
@@ -418,6 +426,11 @@ __device__ __forceinline__ uint8_t walk_prologue(const DevImage& im, WalkCtx& cx
   rank0 = (cx.x >= im.ref_length) ? im.R - 1 : (uint64_t)rx - 1;  // find(pos, rank)
   // first slot whose node starts at or after y: a walk that reaches it in step with the reference stops there
   cx.limit = (cx.use_ev && cx.y >= 1) ? im.rank_to_slot[ry < im.R ? ry : im.R] : 0;
+  // An irregular node's step sets ref_pos to its last ref neighbour's index for ONE step: read only if the next vertex is
+  // reported (then the node has an out-neighbour holding the sample: an event of its own) or by the stop test ref_pos >= y
+  // (then that neighbour lies at or beyond the stop slot: the node is within irr_reach slots of it).  Everywhere else an
+  // irregular-only slot is jumped over like any uneventful one (round 4; round 3 stopped at every ~40th slot).
+  cx.irr_from = cx.limit > im.t4_irr_reach ? cx.limit - im.t4_irr_reach : 0;
   return 0;
 }
 
@@ -453,7 +466,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   constexpr bool EMIT = MODE == 1;
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= r.Q) return;
-  WalkCtx cx{sid_per_region ? sid_per_region[q] : sid_all, r.regions[2 * q], r.regions[2 * q + 1], false, 0};
+  WalkCtx cx{sid_per_region ? sid_per_region[q] : sid_all, r.regions[2 * q], r.regions[2 * q + 1], false, 0, 0};
   // Event and hold rows of this sample (DevImage::t4_events, t4_hold): clear event bits are ref-path slots where neither
   // the node nor any of its out-neighbours holds the sample and the node is regular -- the reference's loops provably do
   // nothing there but step on, so both the backward search and the walk jump over them.  Everything that happens at a
@@ -463,7 +476,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   const uint8_t fl = walk_prologue(im, cx, rank0);
   if (!fl) {
     BitRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the search
-    BitRow evw{ev.row, kNone, 0, cx.use_ev ? im.t4_irr : nullptr};                                   // | the irregular slots: the walk's jumps
+    BitRow evw{ev.row, kNone, 0, cx.use_ev ? im.t4_irr : nullptr, cx.irr_from};                     // | the irregular slots near the stop slot: the walk's jumps
     BitRow hold{cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr, kNone, 0};
     const uint64_t t_s0 = VS_WALK_CLOCK();
     uint32_t st_iters = 0, st_lit = 0, st_jumps = 0, st_steps = 0;
@@ -554,7 +567,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
   const bool live = q < r.Q;
-  WalkCtx cx{0, 0, 0, false, 0};
+  WalkCtx cx{0, 0, 0, false, 0, 0};
   if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
   cx.use_ev = live && im.t4_events && cx.sid != 0;
   // group-uniform state: every lane of a group computes / receives the same values
@@ -574,7 +587,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
     if (!fl) {
       ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
-      evw.row = ev.row; evw.row2 = cx.use_ev ? im.t4_irr : nullptr;
+      evw.row = ev.row; evw.row2 = cx.use_ev ? im.t4_irr : nullptr; evw.from2 = cx.irr_from;
       hold.row = cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr;
       if (!cx.use_ev) serial = true;
     }
@@ -708,7 +721,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (busy) ++n_chunks;
     // the next 16 events at or after cur_slot, one per lane: lane l loads word l of the row from cur_slot's word on
     const uint32_t w0 = cur_slot >> 6, w_end = (cx.limit + 63) >> 6, wi = w0 + l;
-    uint64_t word = (busy && wi < w_end) ? (ev.row[wi] | im.t4_irr[wi]) : 0;
+    uint64_t word = (busy && wi < w_end) ? (ev.row[wi] | evw.word2(wi)) : 0;
     if (l == 0) word &= ~0ULL << (cur_slot & 63);
     if (busy && wi == (cx.limit >> 6) && (cx.limit & 63)) word &= (1ULL << (cx.limit & 63)) - 1;
     const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);

@@ -99,6 +99,11 @@ struct HostImage {
   // not its path successor, the successor's sequence does not follow its own in the pool or in ref coordinates, or it
   // ends the path.
   std::vector<uint64_t> seq_breaks;   // ceil(P / 64) + 1 words
+  // How far, in ref-path slots, the last ref neighbour of an IRREGULAR node (one whose last ref neighbour is not its path
+  // successor: a deletion edge listed after the successor) lies ahead of it, at most.  Such a node sets the walk's ref_pos
+  // to that neighbour's index for one step: observable to query type 4 only through its stop test ref_pos >= y, i.e. only
+  // for irregular nodes within this many slots of the stop slot.
+  uint32_t irr_reach = 1;
   // The backward search of get_prev_vertex_with_sample visits rank, rank - deg(previous(rank)), ...: a STATIC chain, so
   // the ranks form a forest (parent = the next rank of the chain) and "does the chain from r0 visit rank p" is "p is an
   // ancestor of r0": DFS interval labels {tin, subtree size} per chain rank, 2 words at index rank - 1 like rk_back.
@@ -401,17 +406,25 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     }
   }
   im.seq_breaks.assign((im.P + 63) / 64 + 1, 0);
+  im.irr_reach = 1;
   for (uint64_t k = 0; k < im.P; ++k) {
     const uint32_t R = im.rp_vid[k];
     bool brk = k + 1 >= im.P;
     if (!brk) {
       const uint32_t succ = im.rp_vid[k + 1];
-      uint32_t first_ref = VS_NONE, min_ref = VS_NONE, min_idx = 0xFFFFFFFFu;
+      uint32_t first_ref = VS_NONE, min_ref = VS_NONE, min_idx = 0xFFFFFFFFu, last_ref = VS_NONE;
       for (uint32_t e = im.row_ptr[R]; e < im.row_ptr[R + 1]; ++e) {
         const uint32_t n = im.col[e], nr = im.v_ridx[n];
         if (!nr) continue;
         if (first_ref == VS_NONE) first_ref = n;
         if (nr < min_idx) { min_idx = nr; min_ref = n; }
+        last_ref = n;
+      }
+      if (last_ref != VS_NONE && last_ref != succ) {   // irregular: how far ahead its last ref neighbour lies
+        const uint32_t s1 = im.w_vertex[(uint64_t)last_ref * 8 + 7];
+        // (a ref neighbour off the ref path or behind the node cannot be bounded: every irregular slot then counts everywhere)
+        if (s1 == 0 || s1 - 1 <= k) im.irr_reach = 0xFFFFFFFFu;
+        else if (im.irr_reach != 0xFFFFFFFFu && s1 - 1 - k > im.irr_reach) im.irr_reach = (uint32_t)(s1 - 1 - k);
       }
       brk = first_ref != succ || min_ref != succ || im.v_off[succ] != im.v_off[R] + im.v_len[R] || im.v_ridx[succ] != im.v_ridx[R] + im.v_len[R];
     }
