@@ -18,6 +18,8 @@ ns = vs.info().num_samples
 sids16 = [1 + (i * 157) % (ns - 1) for i in range(16)]
 per_region = np.array([sids16[i % 16] for i in range(nreg)], dtype=np.uint32)
 vs.set_option("t4_walk", int(os.environ.get("VS_T4_WALK", "2")))
+if os.environ.get("VS_FILL_CHUNK"):
+    vs.set_option("fill_chunk", int(os.environ["VS_FILL_CHUNK"]))   # (tuning builds)
 for _ in range(5):
     r = vs.get_sample_var_in_ref(regions, per_region)
     t = vs.last_timing()

@@ -139,6 +139,7 @@ struct vs_index {
   static constexpr size_t kPinBatch = 1040;   // [1040..1041] throughput path, private rows: slots and arena entries of the batch
   static constexpr size_t kPinPlan = 1056;    // [1056..1063] throughput path, shared rows: PlanTotals of the batch (k_t6_apply), sequence word last
   static constexpr size_t kPinDone = 1072;    // completion word of a batch (k_post_done)
+  static constexpr size_t kPinWords = 1080;   // [1080..1083] three device words + sequence (k_post_words: read_device_words)
 };
 
 struct vs_result {
@@ -648,7 +649,8 @@ static int fill_lists(vs_index* idx, const DevResult& d, bool share, const uint3
       // A task is 64 consecutive slots; batches of few, carrier-heavy variants (a type-4 batch: ~1 M variants of ~1300
       // carriers) take 16-slot tasks -- 17 k tasks of 64 would be two rounds of waves with a long tail.
       uint32_t chunk = idx->opts.fill_chunk;
-      if (chunk == 0) chunk = (share || (n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256)) ? 16 : 64;
+      // (8-slot tasks for the carrier-heavy shape: 0.36 ms against 0.40 with 16 on the bench's type-4 leg, tools/run_t4.py)
+      if (chunk == 0) chunk = share ? 16 : ((n_fill < 64ull * 8192 * 8 && d.S / n_fill >= 256) ? 8 : 64);
       const uint64_t nchunks = (n_fill + chunk - 1) / chunk;
       const uint64_t blocks = (nchunks + 3) / 4;
       if (blocks > 0x7FFFFFFFull) return fail(VS_ERR_ARG, "batch too large for one launch (%llu variant slots)", (unsigned long long)d.A);
@@ -779,6 +781,23 @@ static int wait_posted(vs_index* idx, volatile uint64_t* word, uint64_t seq, int
     if (*word != seq) return fail(VS_ERR_INTERNAL, "a batch kernel finished without posting its sequence word");
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  return VS_OK;
+}
+
+// Up to three 64-bit device words for the host, behind everything queued on the handle's stream: a one-thread kernel
+// copies them into mapped host memory and posts a sequence word the host spins on (a staged hipMemcpyAsync into pageable
+// memory + hipStreamSynchronize costs 20 - 30 us more, and the walking query types do it two or three times per batch).
+static int read_device_words(vs_index* idx, const uint64_t* a, uint64_t* va, const uint64_t* b = nullptr, uint64_t* vb = nullptr,
+                             const uint64_t* c = nullptr, uint64_t* vc = nullptr) {
+  uint64_t* dst = idx->pinned + vs_index::kPinWords;
+  const uint64_t seq = ++idx->done_seq;
+  hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, idx->stream, dst, a, b, c, seq);
+  HIP_TRY(hipGetLastError());
+  VS_TRY(wait_posted(idx, dst + 3, seq, 2000));
+  idx->batch_in_flight = false;
+  if (va) *va = ((volatile uint64_t*)dst)[0];
+  if (vb) *vb = ((volatile uint64_t*)dst)[1];
+  if (vc) *vc = ((volatile uint64_t*)dst)[2];
   return VS_OK;
 }
 
@@ -1248,8 +1267,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch.bufs));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch.bufs));
     uint64_t cap_total = 0;
-    HIP_TRY(hipMemcpyAsync(&cap_total, cap_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(read_device_words(idx, cap_begin + n, &cap_total));
     ws_capacity = cap_total;
     ws.cap_begin = cap_begin;
     VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch.bufs));
@@ -1292,7 +1310,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
   bool share_t4 = false;   // one carrier list per reported VERTEX, shared by the rows that report it
   uint64_t t4_arena = 0;
   VS_TRY(batch_sizes(c));
-  if (single_walk) HIP_TRY(hipMemcpyAsync(&walk_overflow, ws.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
+
   if (single_walk && idx->opts.share_lists && n > 64 && !c.resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
     const uint64_t cap_rows = ws_capacity;
@@ -1310,10 +1328,10 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
     VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
     hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, lc);
-    HIP_TRY(hipMemcpyAsync(&t4_arena, own_base + n, 8, hipMemcpyDeviceToHost, idx->stream));
     share_t4 = true;
   }
-  HIP_TRY(hipStreamSynchronize(idx->stream));
+  // the walk's overflow flag and the claims' arena total (the scan's totals are in mapped memory already)
+  VS_TRY(read_device_words(idx, single_walk ? ws.overflow : nullptr, &walk_overflow, share_t4 ? lc.own_base + n : nullptr, &t4_arena));
   uint64_t rows = 0, arena = 0;
   batch_totals(c, &rows, &arena);
   if (share_t4 && !walk_overflow) arena = t4_arena;
@@ -1460,8 +1478,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
     hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
-    HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0]));
     VS_TRY(ralloc(r, totals[0], &q.seg_src));
     VS_TRY(ralloc(r, totals[0], &q.seg_len));
     VS_TRY(ralloc(r, totals[0], &q.seg_dst));
@@ -1471,9 +1488,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     HIP_TRY(hipGetLastError());
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
     uint64_t over = 0;
-    HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipMemcpyAsync(&over, q.overflow, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(read_device_words(idx, q.byte_begin + n, &totals[1], q.overflow, &over));
     if (over) { single_walk = false; q.relative = 0; }
     else {
       VS_TRY(ralloc(r, totals[1], &q.chars));
@@ -1490,9 +1505,7 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     }
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
-    HIP_TRY(hipMemcpyAsync(&totals[0], q.seg_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipMemcpyAsync(&totals[1], q.byte_begin + n, 8, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0], q.byte_begin + n, &totals[1]));
     VS_TRY(ralloc(r, totals[0], &q.seg_src));
     VS_TRY(ralloc(r, totals[0], &q.seg_len));
     VS_TRY(ralloc(r, totals[0], &q.seg_dst));

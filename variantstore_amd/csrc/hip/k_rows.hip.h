@@ -326,6 +326,12 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult 
 __global__ void k_post_done(uint64_t* flag, uint64_t seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the same with up to three device words for the host (a scan's grand total, an overflow flag): dst[0..2] = *a, *b, *c
+// (NULL: 0), dst[3] = seq last -- instead of a staged device-to-host copy and a stream synchronisation
+__global__ void k_post_words(uint64_t* dst, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t seq) {
+  dst[0] = a ? *a : 0; dst[1] = b ? *b : 0; dst[2] = c ? *c : 0;
+  __hip_atomic_store(&dst[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // A batch that is NOT sorted by first site is sorted here -- a counting sort over the site index: histogram of the first
 // sites (regions without sites count as site 0), exclusive scan over the G + 1 buckets (the engine's scan kernels),
 // scatter through per-bucket cursors -- and then runs through the same kernels on sorted copies of its per-region
