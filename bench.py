@@ -376,7 +376,18 @@ def main():
     # communicator's own stream); torch.distributed only carries the unique id, the barrier and the timing reduction.
     # VS_BENCH_TORCH_COLLECTIVE=1: rounds 2-3's all_gather_into_tensor instead.
     torch_collective = os.environ.get("VS_BENCH_TORCH_COLLECTIVE") == "1"
-    comm = make_comm(vs, rank, world) if (use_dist and not torch_collective) else None
+    comm = None
+    if use_dist and not torch_collective:
+        try:
+            comm = make_comm(vs, rank, world)
+        except Exception as e:   # (RCCL not loadable from the engine: every rank then takes torch.distributed's collective)
+            sys.stderr.write(f"rank {rank}: vs_comm_init failed ({e}); falling back to torch.distributed's all-gather\n")
+        okf = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm, torch_collective = None, True
 
     class _CommWork:   # (the wait handle of a vs_comm all-gather: one in flight per communicator)
         def wait(self):
