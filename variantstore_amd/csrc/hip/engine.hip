@@ -489,13 +489,19 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
   // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
   //      what this part has plenty of).  Skipped when they would take more than half of the free memory or the cap below. ----
-  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0; d.t4_irr = nullptr;
+  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0; d.t4_irr = nullptr; d.t4_ev_shift = 0; d.t4_irr_reach = 1;
   if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
-    const uint64_t stride = (im.P + 63) / 64 + 1, hstride = (im.V + 63) / 64 + 1;
+    // Class-row cohorts: a bit per slot and sample, a bit per vertex and sample (3.0 + 4.6 GB at 2504 samples).  Explicit-id
+    // cohorts (thousands of samples, a handful of carriers per variant): one bit per EIGHT slots -- any superset of the
+    // events is exact, a coarse bit costs a few literal steps where the sample does have an event, and those are rare -- and
+    // no hold rows at all: "does v hold the sample" is read from v's carrier list (k_walk.hip.h: BitRow).  10,000 samples x
+    // 20 M variants: 6.3 GB instead of round 3's 125 GB.
+    const uint32_t shift = d.use_bv ? 0u : 3u;
+    const uint64_t istride = (im.P + 63) / 64 + 1;                                   // the global irregular row: a bit per slot
+    const uint64_t stride = d.use_bv ? istride : ((im.P >> shift) + 64) / 64 + 1, hstride = d.use_bv ? (im.V + 63) / 64 + 1 : 0;
     const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    // (10,000 samples x 20 M variants: 125 GB of rows on a 288 GB part, next to a 5 GB image -- memory is what this GPU has)
     // Budget: half of the free memory, at most 176 GB -- or VS_T4_ROWS_MAX_GB from the environment; vs_index_get_info
     // reports what was taken (t4_rows_bytes).
     uint64_t cap = 176ull << 30;
@@ -503,13 +509,15 @@ static int build_device_image(vs_index* idx) {
     if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
       idx->t4_rows_bytes = bytes + hbytes;
       uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
-      VS_TRY(alloc_image(idx, (size_t)stride, &irr));
-      HIP_TRY(hipMemsetAsync(irr, 0, stride * 8, idx->stream));
+      VS_TRY(alloc_image(idx, (size_t)istride, &irr));
+      HIP_TRY(hipMemsetAsync(irr, 0, istride * 8, idx->stream));
       VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
-      VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
       HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
-      HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
-      d.t4_stride = stride; d.t4_hold_stride = hstride;
+      if (hstride) {
+        VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
+        HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
+      }
+      d.t4_stride = stride; d.t4_hold_stride = hstride; d.t4_ev_shift = shift;
       const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
       if (d.use_bv) {
         hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events, irr);
@@ -517,7 +525,6 @@ static int build_device_image(vs_index* idx) {
       } else {
         hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, irr);
         hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
-        hipLaunchKernelGGL(k_hold_explicit, dim3((unsigned)((im.V + 255) / 256)), dim3(256), 0, idx->stream, d, hold);
       }
       HIP_TRY(hipGetLastError());
       d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr; d.t4_irr_reach = im.irr_reach;

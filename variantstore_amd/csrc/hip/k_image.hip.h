@@ -68,7 +68,7 @@ struct DevImage {
   // jump by the OR of the two; the backward searches enumerate the sample's own bits only (every ~40th slot is irregular:
   // on a cohort whose samples have a variant every 15 kb that was 97 % of a long search's candidates).
   const uint64_t* t4_irr;
-  uint32_t t4_irr_reach, pad4_;   // HostImage::irr_reach: an irregular slot matters to the type-4 walk only within this many slots of its stop slot
+  uint32_t t4_irr_reach, t4_ev_shift;   // t4_ev_shift: one bit of an event row stands for 2^shift slots (explicit-id cohorts: 3; class-row cohorts: 0);   // HostImage::irr_reach: an irregular slot matters to the type-4 walk only within this many slots of its stop slot
   // Per-sample HOLD rows over the vertex ids (k_build_hold): bit v of row s = vertex v holds sample s (what
   // get_sample_from_vertex_if_exists answers).  Vertex ids grow along the reference, so every test of one walk step --
   // the node, its neighbours, the neighbours' neighbours -- falls into one or two 64-bit words of the sample's row

@@ -128,25 +128,30 @@ __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& i
       // at) and that rank is on the chain from the start rank (ancestor labels, DevImage::rk_anc).
       const uint32_t tin0 = im.rk_anc[rank_in - 1].x;
       const uint32_t s_top = im.rk_back[rank - 1].x;
+      const uint32_t sh = ev.sh, c_top = s_top >> sh;   // (coarse rows: a bit stands for 2^sh slots, every one of them a candidate)
       uint32_t hit = kNone;
-      for (int64_t wi = s_top >> 6; wi >= 0 && hit == kNone; --wi) {
+      for (int64_t wi = c_top >> 6; wi >= 0 && hit == kNone; --wi) {
         uint64_t word = ev.row[wi];
-        if ((uint32_t)wi == (s_top >> 6) && (s_top & 63) != 63) word &= (1ULL << ((s_top & 63) + 1)) - 1;
-        while (word) {
+        if ((uint32_t)wi == (c_top >> 6) && (c_top & 63) != 63) word &= (1ULL << ((c_top & 63) + 1)) - 1;
+        while (word && hit == kNone) {
           const uint32_t bpos = 63u - (uint32_t)__builtin_clzll(word);
           word &= ~(1ULL << bpos);
-          const uint32_t k = (uint32_t)wi * 64u + bpos;
-          const uint32_t r = im.slot_rank[k];
-          if (r < 1) continue;                    // (the chain stops at rank <= 1 before it would look there)
-          if (im.rk_back[r].x != k) continue;     // not the first slot of its rank
-          const uint2 an = im.rk_anc[r];
-          if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
-          // the literal test of this node; if no neighbour holds the sample the search goes on below it
-          bool f2 = false;
-          const uint32_t deg = im.rk_back[r].y, rbk = im.blob_of_slot[k] + 1;
-          for (uint32_t e = rbk; e < rbk + deg; ++e)
-            if (hold.bit(im.wblob[2 * (uint64_t)e].x)) { f2 = true; break; }
-          if (f2) { hit = r; break; }
+          const uint32_t c = (uint32_t)wi * 64u + bpos;
+          for (uint32_t j = 1u << sh; j-- > 0;) {
+            const uint32_t k = (c << sh) + j;
+            if (k > s_top || k >= im.P) continue;
+            const uint32_t r = im.slot_rank[k];
+            if (r < 1) continue;                    // (the chain stops at rank <= 1 before it would look there)
+            if (im.rk_back[r].x != k) continue;     // not the first slot of its rank
+            const uint2 an = im.rk_anc[r];
+            if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
+            // the literal test of this node; if no neighbour holds the sample the search goes on below it
+            bool f2 = false;
+            const uint32_t deg = im.rk_back[r].y, rbk = im.blob_of_slot[k] + 1;
+            for (uint32_t e = rbk; e < rbk + deg; ++e)
+              if (hold.bit_n(im.wblob[2 * (uint64_t)e].x, im.wblob[2 * (uint64_t)e + 1].w)) { f2 = true; break; }
+            if (f2) { hit = r; break; }
+          }
         }
       }
       if (hit == kNone) { rank = 0; continue; }   // nothing below: the head of the path
@@ -159,7 +164,7 @@ __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& i
     for (uint32_t e = rb0; e < rb0 + back.y; ++e) {
       const uint4 a = im.wblob[2 * (uint64_t)e];
       if (a.y) { ref_pos = a.y; had_ref = true; }
-      if (hold.bit(a.x)) { fv = a.x; fr = a.y; fc = a.z; found = true; }
+      if (hold.bit_n(a.x, im.wblob[2 * (uint64_t)e + 1].w)) { fv = a.x; fr = a.y; fc = a.z; found = true; }
     }
     rank = rank > back.y ? rank - back.y : 0;
     if (found) {
@@ -226,8 +231,8 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
   // there; ref_pos, sample_pos and cur_ref advance with the path), and only a vertex that holds the sample pays the
   // look-up of its sample-coordinate index.
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0;
-  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
-  BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
+  BitRow ev = sample_event_row(im, sid, fast);   // the sample's own events: the searches, the walk's jumps
+  BitRow hold = sample_hold_row(im, sid, fast);
   BitRow brk{im.seq_breaks, kNone, 0};
   const bool rewound = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)
                             : rewind_to_sample_pos(im, x, sid, closest_v, ref_pos, sample_pos);
@@ -275,16 +280,16 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
         const uint4 a = im.wblob[2 * (uint64_t)e];
         if (a.y) { next_ref_pos = a.y; next_ref_v = a.x; }   // the last ref neighbour
         if (!by_sample) {
-          const bool holds = hold.bit(a.x);
+          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+          const bool holds = hold.bit_n(a.x, b.w);
           if (holds || (a.y && min_idx > a.y)) {
-            const uint4 b = im.wblob[2 * (uint64_t)e + 1];
             nxt = a.x; n_rbeg = a.w; n_deg = b.x; n_ridx = a.y; n_len = b.z; n_cls = a.z; n_ncar = b.w; n_slot1 = b.y;
             if (holds) by_sample = true; else min_idx = a.y;
           }
         }
       }
       uint32_t sidx = 0;
-      if (sample_pos > x && hold.bit(cur) && sample_entry_rec(im, cur, ridx, im.use_bv ? cls : 0u, sid, sidx)) {
+      if (sample_pos > x && hold.bit_n(cur, ncar_v) && sample_entry_rec(im, cur, ridx, im.use_bv ? cls : 0u, sid, sidx)) {
         uint64_t pos;
         uint32_t ro, rl, ao, al;
         if (ref_pos == next_ref_pos) {        // insertion
@@ -463,8 +468,8 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
   // without a neighbour holding the sample, and the walk turns every uneventful run of ref-path slots into ONE piece.
   // (not for y < x: the window's `y - x` then wraps and is clipped to the VERTEX it is applied to -- a merged run would clip differently)
   const bool fast = im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x;
-  BitRow ev{fast ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the searches
-  BitRow hold{fast ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
+  BitRow ev = sample_event_row(im, sid, fast);   // the sample's own events: the searches, the walk's jumps
+  BitRow hold = sample_hold_row(im, sid, fast);
   BitRow brk{im.seq_breaks, kNone, 0};
   if (MODE == 2) cur = fast ? prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos) : prev_vertex_with_sample(im, x, sid, ref_pos, sample_pos);
   else ok = fast ? rewind_to_sample_pos_ev(im, x, sid, ev, hold, cur, ref_pos, sample_pos) : rewind_to_sample_pos(im, x, sid, cur, ref_pos, sample_pos);
@@ -512,9 +517,9 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
         const uint4 a = im.wblob[2 * (uint64_t)e];
         if (a.y && !have_ref) { next_ref_pos = a.y; have_ref = true; }   // the FIRST ref neighbour (query.h:150-153)
         if (!by_sample) {                                                 // get_neighbor_vertex
-          const bool holds = hold.bit(a.x);
+          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+          const bool holds = hold.bit_n(a.x, b.w);
           if (holds || (a.y && min_idx > a.y)) {
-            const uint4 b = im.wblob[2 * (uint64_t)e + 1];
             nxt = a.x; n_rbeg = a.w; n_deg = b.x; n_ridx = a.y; n_len = b.z; n_slot1 = b.y;
             if (holds) by_sample = true; else min_idx = a.y;
           }

@@ -82,14 +82,15 @@ __global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* 
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= im.P) return;
   const uint32_t v = im.rp_vid[j];
-  const unsigned long long bit = 1ULL << (j & 63);
+  const uint64_t c = j >> im.t4_ev_shift;            // (coarse rows: one bit per 2^shift slots)
+  const unsigned long long bit = 1ULL << (c & 63);
   const uint32_t e0 = im.row_ptr[v], e1 = im.row_ptr[v + 1];
   for (uint32_t e = e0; e <= e1; ++e) {             // e == e1: the node itself
     const uint32_t u = e < e1 ? im.col[e] : v;
     const uint64_t b = im.v_car_begin[u];
     for (uint32_t i = 0; i < im.v_ncar[u]; ++i) {
       const uint32_t sid = im.car_sid[b + i];
-      if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&events[(uint64_t)sid * im.t4_stride + (j >> 6)], bit);
+      if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&events[(uint64_t)sid * im.t4_stride + (c >> 6)], bit);
     }
   }
 }
@@ -114,16 +115,6 @@ __global__ void __launch_bounds__(256) k_build_hold(DevImage im, uint64_t* hold)
     if (sample >= 1 && sample < im.num_samples) hold[(uint64_t)sample * im.t4_hold_stride + tile] = mine;
   }
 }
-__global__ void __launch_bounds__(256) k_hold_explicit(DevImage im, uint64_t* hold) {
-  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= im.V) return;
-  const uint64_t b = im.v_car_begin[v];
-  for (uint32_t i = 0; i < im.v_ncar[v]; ++i) {
-    const uint32_t sid = im.car_sid[b + i];
-    if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&hold[(uint64_t)sid * im.t4_hold_stride + (v >> 6)], 1ULL << (v & 63));
-  }
-}
-
 // Walk records (device_image.hpp): one step of a path walk reads the current vertex in one 32-byte record and each
 // neighbour in one 16-byte edge record instead of gathering a dozen 4-byte fields from as many arrays.
 struct WalkVertex { uint32_t row_begin, deg, ridx, off, len, cls, ncar; };
@@ -195,37 +186,80 @@ __device__ __forceinline__ WalkVariant resolve_walk_variant(const DevImage& im, 
 
 // One 64-bit-word cache in front of a per-sample bit row (event rows over slots, hold rows over vertex ids): consecutive
 // look-ups of a walk fall into the same word more often than not.
+// Two compact forms for EXPLICIT-ID cohorts (somatic-like: a handful of carriers per variant, thousands of samples), whose
+// full rows are O(samples x slots) -- 125 GB at 10,000 samples x 20 M variants (round 4):
+//  * `sh`: one bit of an EVENT row stands for 2^sh consecutive slots ("some slot of the block has an event").  Everything
+//    an event row is used for is an acceleration around literal code -- a walk lands on a slot and steps literally, a
+//    search tests a candidate literally -- so any SUPERSET of the true events is exact; a coarse bit just makes up to 2^sh
+//    cheap literal steps where the full row made one.
+//  * `x_sid`: a HOLD row that is not there -- "does vertex v hold the sample" is answered from v's explicit carrier list
+//    (v_car_begin / v_ncar / car_sid: most neighbours of a walk are ref vertices without carriers, the rest hold ~8 ids).
 struct BitRow {
   const uint64_t* __restrict__ row;
   uint32_t w;          // index of the cached word (kNone: nothing cached)
   uint64_t word;
-  // a second row OR-ed in from bit `from2` on (the type-4 walk's event row = the sample's events | the global irregular slots
-  // near the region's stop slot)
-  const uint64_t* __restrict__ row2 = nullptr;
-  uint32_t from2 = 0;
-  __device__ __forceinline__ uint64_t word2(uint32_t wi) const {
-    if (wi < (from2 >> 6)) return 0;
-    const uint64_t x = row2[wi];
-    return wi == (from2 >> 6) ? x & (~0ULL << (from2 & 63)) : x;
-  }
+  uint32_t sh = 0;
+  const uint32_t* __restrict__ x_sid = nullptr;
+  const uint64_t* __restrict__ x_begin = nullptr;
+  const uint32_t* __restrict__ x_ncar = nullptr;
+  uint32_t x_id = 0;
   __device__ __forceinline__ uint64_t at(uint32_t wi) {
-    if (wi != w) { w = wi; word = row2 ? (row[wi] | word2(wi)) : row[wi]; }
+    if (wi != w) { w = wi; word = row[wi]; }
     return word;
   }
-  __device__ __forceinline__ bool bit(uint32_t i) { return (at(i >> 6) >> (i & 63)) & 1; }
-  // first index >= m whose bit is set, or `limit` when there is none below it (m < limit)
+  __device__ __forceinline__ bool bit(uint32_t i) {
+    if (x_sid) return holds_explicit(i, x_ncar[i]);
+    const uint32_t c = i >> sh;
+    return (at(c >> 6) >> (c & 63)) & 1;
+  }
+  // the same for a vertex whose number of carriers the caller already has in a record (a hold row that is not there then
+  // costs nothing for a vertex without carriers -- every ref vertex -- and one look-up of the list's start otherwise)
+  __device__ __forceinline__ bool bit_n(uint32_t i, uint32_t ncar) {
+    if (x_sid) return holds_explicit(i, ncar);
+    return (at(i >> 6) >> (i & 63)) & 1;
+  }
+  __device__ __forceinline__ bool holds_explicit(uint32_t i, uint32_t n) const {
+    if (!n) return false;
+    const uint64_t b0 = x_begin[i];
+    for (uint32_t k = 0; k < n; ++k)
+      if (x_sid[b0 + k] == x_id) return true;
+    return false;
+  }
+  // first index >= m whose bit is set, or `limit` when there is none below it (m < limit); a coarse row answers with m
+  // itself when m's block is set, else with the first index of the next set block
   __device__ __forceinline__ uint32_t next(uint32_t m, uint32_t limit) {
-    uint32_t wi = m >> 6;
-    const uint32_t w_end = (limit + 63) >> 6;
-    uint64_t x = at(wi) & (~0ULL << (m & 63));
+    const uint32_t cm = m >> sh, c_end = ((limit - 1) >> sh) + 1;
+    uint32_t wi = cm >> 6;
+    const uint32_t w_end = (c_end + 63) >> 6;
+    uint64_t x = at(wi) & (~0ULL << (cm & 63));
     while (!x) {
       if (++wi >= w_end) return limit;
       x = at(wi);
     }
-    const uint32_t k = (wi << 6) + (uint32_t)__builtin_ctzll(x);
+    const uint32_t c = (wi << 6) + (uint32_t)__builtin_ctzll(x);
+    if (c >= c_end) return limit;
+    const uint32_t k = c == cm ? m : c << sh;
     return k < limit ? k : limit;
   }
 };
+// the rows of one sample (NULL rows: the index has none, or the walk does not use them)
+__device__ __forceinline__ BitRow sample_event_row(const DevImage& im, uint32_t sid, bool use) {
+  BitRow r{use ? im.t4_events + (uint64_t)sid * im.t4_stride : nullptr, kNone, 0};
+  r.sh = im.t4_ev_shift;
+  return r;
+}
+__device__ __forceinline__ BitRow sample_hold_row(const DevImage& im, uint32_t sid, bool use) {
+  BitRow r{(use && im.t4_hold) ? im.t4_hold + (uint64_t)sid * im.t4_hold_stride : nullptr, kNone, 0};
+  if (use && !im.t4_hold) { r.x_sid = im.car_sid; r.x_begin = im.v_car_begin; r.x_ncar = im.v_ncar; r.x_id = sid; }
+  return r;
+}
+__device__ __forceinline__ BitRow irregular_row(const DevImage& im, bool use) { return BitRow{use ? im.t4_irr : nullptr, kNone, 0}; }
+// the global irregular row's word wi, from slot `from` on
+__device__ __forceinline__ uint64_t irr_word_from(const uint64_t* __restrict__ irr, uint32_t wi, uint32_t from) {
+  if (wi < (from >> 6)) return 0;
+  const uint64_t x = irr[wi];
+  return wi == (from >> 6) ? x & (~0ULL << (from & 63)) : x;
+}
 typedef BitRow EventRow;
 
 // ---- the walk of get_sample_var_in_ref as reusable pieces (serial kernel k_sample_walk, cooperative k_sample_walk_coop) ----
@@ -233,6 +267,14 @@ typedef BitRow EventRow;
 // the sample" from the hold row, jumps over uneventful runs) and plain (sample 0 = "ref", or an index without the rows:
 // the round-2 records, class rows, every vertex visited).  WalkVertex::row_begin indexes the blob resp. w_edge.
 struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; uint32_t irr_from; };   // irr_from: irregular slots count as events from here on (walk_prologue)
+// The next slot >= m (m < cx.limit) at which the type-4 walk must step literally: the sample's next event, or an irregular slot
+// once the stop slot is within reach (walk_prologue: irr_from); cx.limit when neither comes first.
+__device__ __forceinline__ uint32_t next_walk_event(BitRow& ev, BitRow& irr, const WalkCtx& cx, uint32_t m) {
+  uint32_t k = ev.next(m, cx.limit);
+  const uint32_t m2 = m > cx.irr_from ? m : cx.irr_from;
+  if (m2 < k) k = irr.next(m2, k);     // (k itself when no irregular slot lies before it)
+  return k;
+}
 struct WalkSt { uint32_t cur; WalkVertex wc; uint64_t ref_pos; uint32_t cur_ref_v, cur_slot1; };   // cur_slot1: ref-path slot + 1 of cur, 0 = off the path
 struct WalkEmit { uint64_t ref_pos; uint32_t cur, kind, cur_ref_v, c; };   // the walk's state at a reported vertex (-> resolve_walk_variant)
 
@@ -246,8 +288,8 @@ struct StepOut {
 };
 // does vertex v hold the sample (get_sample_from_vertex_if_exists)?  BLOB: the sample's hold row; else class row / carrier list
 template <bool BLOB>
-__device__ __forceinline__ bool walk_holds(const DevImage& im, BitRow& hold, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t sid) {
-  if (BLOB) return hold.bit(v);
+__device__ __forceinline__ bool walk_holds(const DevImage& im, BitRow& hold, uint32_t v, uint32_t ridx, uint32_t cls, uint32_t ncar, uint32_t sid) {
+  if (BLOB) return hold.bit_n(v, ncar);
   return record_has_sample(im, v, ridx, cls, sid);
 }
 // One literal step's view of a vertex's out-edges: all edge records are requested together (one or two lines of the
@@ -272,7 +314,7 @@ __device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, BitRow& h
       const uint32_t n = a[i].x, nr = a[i].y;
       if (on && nr) { o.next_ref_pos = nr; o.next_ref_v = n; }  // last ref neighbour wins
       if (on && !nxt_by_sample) {
-        const bool holds = hold.bit(n);
+        const bool holds = hold.bit_n(n, b[i].w);
         if (holds || (nr && min_idx > nr)) {
           o.nxt = n; o.nxt_slot1 = b[i].y;
           o.wn = WalkVertex{a[i].w, b[i].x, a[i].y, 0u, b[i].z, a[i].z, b[i].w};
@@ -289,7 +331,7 @@ __device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, BitRow& h
     const uint32_t n = a.x, nr = a.y;
     if (nr) { o.next_ref_pos = nr; o.next_ref_v = n; }
     if (!nxt_by_sample) {  // get_neighbor_vertex: first neighbour holding the sample, else smallest ref index
-      const bool holds = sid != 0 && walk_holds<BLOB>(im, hold, n, nr, a.z, sid);
+      const bool holds = sid != 0 && walk_holds<BLOB>(im, hold, n, nr, a.z, b.w, sid);
       if (holds || (nr && min_idx > nr)) {
         o.nxt = n;
         o.nxt_slot1 = BLOB ? b.y : 0u;
@@ -306,7 +348,7 @@ __device__ __forceinline__ StepOut walk_step_edges(const DevImage& im, BitRow& h
 template <bool BLOB>
 __device__ __forceinline__ bool walk_literal_step(const DevImage& im, const WalkCtx& cx, BitRow& hold, WalkSt& st, WalkEmit& em, bool& done) {
   // does cur hold the sample?  (requested before the edges: it is independent of them)
-  const bool cur_holds = st.ref_pos >= cx.x && walk_holds<BLOB>(im, hold, st.cur, st.wc.ridx, st.wc.cls, cx.sid);
+  const bool cur_holds = st.ref_pos >= cx.x && walk_holds<BLOB>(im, hold, st.cur, st.wc.ridx, st.wc.cls, st.wc.ncar, cx.sid);
   const StepOut so = walk_step_edges<BLOB>(im, hold, st.wc, cx.sid, st.ref_pos + st.wc.len);
   bool emit = false;
   if (cur_holds) {
@@ -375,10 +417,9 @@ __device__ __forceinline__ void walk_start_search(const DevImage& im, const Walk
     if (BLOB) {
       const uint32_t rb0 = im.blob_of_slot[pslot] + 1;   // the edge records follow the slot's header
       for (uint32_t e = rb0; e < rb0 + deg; ++e) {
-        const uint4 a = im.wblob[2 * (uint64_t)e];
+        const uint4 a = im.wblob[2 * (uint64_t)e], b = im.wblob[2 * (uint64_t)e + 1];
         if (a.y) { ref_pos = a.y; had_ref = true; }
-        if (hold.bit(a.x)) {
-          const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+        if (hold.bit_n(a.x, b.w)) {
           start_v = a.x; found = true; have_start_rec = true; start_slot1 = b.y;
           wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
         }
@@ -437,7 +478,7 @@ __device__ __forceinline__ uint8_t walk_prologue(const DevImage& im, WalkCtx& cx
 // The serial walk of one region: the reference's loop, with jumps over uneventful runs in BLOB mode.  `sink(em)` takes
 // each reported vertex.
 template <bool BLOB, typename Sink>
-__device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& cx, BitRow& ev, BitRow& hold, WalkSt& st, Sink&& sink,
+__device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& cx, BitRow& ev, BitRow& irr, BitRow& hold, WalkSt& st, Sink&& sink,
                                             uint32_t& st_jumps, uint32_t& st_steps) {
   bool done = false;
   while (!done) {
@@ -447,7 +488,7 @@ __device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& c
       // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
       // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
       // stop at `limit` if that comes first.
-      const uint32_t k = ev.next(st.cur_slot1 - 1, cx.limit);
+      const uint32_t k = next_walk_event(ev, irr, cx, st.cur_slot1 - 1);
       if (k != st.cur_slot1 - 1) {
         if (k >= cx.limit) break;
         walk_arrive_at_slot(im, st, k);
@@ -475,9 +516,9 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
   uint64_t nvar = 0, ncar = 0, ncar_kept = 0, rank0 = 0;
   const uint8_t fl = walk_prologue(im, cx, rank0);
   if (!fl) {
-    BitRow ev{cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr, kNone, 0};   // the sample's own events: the search
-    BitRow evw{ev.row, kNone, 0, cx.use_ev ? im.t4_irr : nullptr, cx.irr_from};                     // | the irregular slots near the stop slot: the walk's jumps
-    BitRow hold{cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr, kNone, 0};
+    BitRow ev = sample_event_row(im, cx.sid, cx.use_ev);      // the sample's own events: the search, the walk's jumps
+    BitRow irr = irregular_row(im, cx.use_ev);                // | the irregular slots near the stop slot (next_walk_event)
+    BitRow hold = sample_hold_row(im, cx.sid, cx.use_ev);
     const uint64_t t_s0 = VS_WALK_CLOCK();
     uint32_t st_iters = 0, st_lit = 0, st_jumps = 0, st_steps = 0;
     WalkSt st;
@@ -503,8 +544,8 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
       }
       nvar++; ncar += pad_car(em.c); ncar_kept += em.c;
     };
-    if (cx.use_ev) walk_serial<true>(im, cx, evw, hold, st, sink, st_jumps, st_steps);
-    else walk_serial<false>(im, cx, evw, hold, st, sink, st_jumps, st_steps);
+    if (cx.use_ev) walk_serial<true>(im, cx, ev, irr, hold, st, sink, st_jumps, st_steps);
+    else walk_serial<false>(im, cx, ev, irr, hold, st, sink, st_jumps, st_steps);
     const uint64_t t_s2 = VS_WALK_CLOCK();
     VS_WALK_STAT(0, 1); VS_WALK_STAT(1, st_iters); VS_WALK_STAT(2, st_lit); VS_WALK_STAT(3, st_jumps); VS_WALK_STAT(4, st_steps);
     VS_WALK_STAT(5, t_s1 - t_s0); VS_WALK_STAT(6, t_s2 - t_s1); VS_WALK_STAT(7, nvar);
@@ -577,7 +618,8 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
   bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
   uint32_t cur_slot = 0;     // slot at which the chain is in step
   uint64_t s0 = 0, scap = 0;
-  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0}, evw{nullptr, kNone, 0};   // ev: the sample's own events (search); evw: | the irregular slots (walk)
+  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0}, irr{nullptr, kNone, 0};   // the sample's own events; "does v hold the sample"; the global irregular row
+  const uint32_t sh = im.t4_ev_shift;   // > 0: coarse event rows (explicit-id cohorts): the search below, then the one-lane walk from where it ends
   WalkSt st{};
   const uint64_t t_c0 = VS_WALK_CLOCK();
   uint64_t t_c1 = t_c0, t_c2 = t_c0;
@@ -586,9 +628,9 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     fl = walk_prologue(im, cx, rank0);
     s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
     if (!fl) {
-      ev.row = cx.use_ev ? im.t4_events + (uint64_t)cx.sid * im.t4_stride : nullptr;
-      evw.row = ev.row; evw.row2 = cx.use_ev ? im.t4_irr : nullptr; evw.from2 = cx.irr_from;
-      hold.row = cx.use_ev ? im.t4_hold + (uint64_t)cx.sid * im.t4_hold_stride : nullptr;
+      ev = sample_event_row(im, cx.sid, cx.use_ev);
+      irr = irregular_row(im, cx.use_ev);
+      hold = sample_hold_row(im, cx.sid, cx.use_ev);
       if (!cx.use_ev) serial = true;
     }
   }
@@ -620,10 +662,9 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       uint32_t rp = 0;
       const uint32_t rb0 = im.blob_of_slot[slot] + 1;   // the edge records follow the slot's header
       for (uint32_t ed = rb0; ed < rb0 + deg; ++ed) {
-        const uint4 a = im.wblob[2 * (uint64_t)ed];
+        const uint4 a = im.wblob[2 * (uint64_t)ed], b = im.wblob[2 * (uint64_t)ed + 1];
         if (a.y) { rp = a.y; hr = true; }
-        if (hold.bit(a.x)) {
-          const uint4 b = im.wblob[2 * (uint64_t)ed + 1];
+        if (hold.bit_n(a.x, b.w)) {
           f_v = a.x; found = true; f_slot1 = b.y;
           f_wc = WalkVertex{a.w, b.x, a.y, 0u, b.z, a.z, b.w};
         }
@@ -648,30 +689,36 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
 #pragma unroll
       for (uint32_t e = 0; e < E; ++e) {
         const bool visited = valid[e] && anc[e].x <= tin0 && tin0 - anc[e].x < anc[e].y;
-        ev_word[e] = visited ? ev.row[back[e].x >> 6] : 0ULL;
+        ev_word[e] = visited ? ev.row[(back[e].x >> sh) >> 6] : 0ULL;
       }
 #pragma unroll
       for (uint32_t e = 0; e < E; ++e)   // in chain order within the lane: the first visited node with a holder wins
-        if (!found && ((ev_word[e] >> (back[e].x & 63)) & 1)) check_node(back[e].x, back[e].y);
+        if (!found && ((ev_word[e] >> ((back[e].x >> sh) & 63)) & 1)) check_node(back[e].x, back[e].y);
     }
     if (searching && hop) {
       // A long search (a sample with few variants): from here on it goes by the SET BITS of the sample's event row, one
       // 64-slot word per lane and round, highest slot first.  A set bit is a candidate when its slot is the first of its
       // rank (the only node of a rank the chain looks at) and that rank is on the chain from rank0 (ancestor labels).
-      const int64_t wi = (int64_t)(s_top >> 6) - (int64_t)l;
+      // (coarse rows: a bit stands for 2^sh slots, every one of them a candidate -- highest first, none above s_top)
+      const uint32_t c_top = s_top >> sh;
+      const int64_t wi = (int64_t)(c_top >> 6) - (int64_t)l;
       uint64_t word = wi >= 0 ? ev.row[wi] : 0ULL;
-      if (l == 0 && (s_top & 63) != 63) word &= (1ULL << ((s_top & 63) + 1)) - 1;   // nothing above s_top
+      if (l == 0 && (c_top & 63) != 63) word &= (1ULL << ((c_top & 63) + 1)) - 1;   // nothing above s_top's block
       while (word && !found) {
         const uint32_t b = 63u - (uint32_t)__builtin_clzll(word);
         word &= ~(1ULL << b);
-        const uint32_t k = (uint32_t)wi * 64u + b;
-        const uint32_t r = im.slot_rank[k];               // chain rank r + 1 looks at the first slot of rank r
-        if (r < 1) continue;                              // (the chain stops at rank <= 1 before it would look there)
-        const uint2 bk = im.rk_back[r];
-        if (bk.x != k) continue;
-        const uint2 an = im.rk_anc[r];
-        if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
-        check_node(k, bk.y);
+        const uint32_t c = (uint32_t)wi * 64u + b;
+        for (uint32_t j = 1u << sh; j-- > 0 && !found;) {
+          const uint32_t k = (c << sh) + j;
+          if (k > s_top || k >= im.P) continue;
+          const uint32_t r = im.slot_rank[k];               // chain rank r + 1 looks at the first slot of rank r
+          if (r < 1) continue;                              // (the chain stops at rank <= 1 before it would look there)
+          const uint2 bk = im.rk_back[r];
+          if (bk.x != k) continue;
+          const uint2 an = im.rk_anc[r];
+          if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
+          check_node(k, bk.y);
+        }
       }
     }
     const uint32_t fb = (uint32_t)((__ballot(found) >> gbase) & kGroupMask);
@@ -692,12 +739,28 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
       } else if (!hop) {
         rank = rank > kSearchWindow ? rank - kSearchWindow : 0;   // the next window starts right below this one
         if (++windows >= kHopAfter && rank > 1 && im.slot_rank) { hop = true; s_top = im.rk_back[rank - 1].x; }
-      } else if ((s_top >> 6) >= SUB) s_top = (((s_top >> 6) - SUB) << 6) | 63u;
+      } else if (((s_top >> sh) >> 6) >= SUB) s_top = ((((((s_top >> sh) >> 6) - SUB) << 6) | 63u) << sh) | ((1u << sh) - 1u);   // the last slot of the word SUB words down
       else rank = 0;   // nothing left below: the head of the path
     }
   }
   t_c1 = VS_WALK_CLOCK();
-  if (live && !fl && cx.use_ev && !serial) {
+  bool walked = false;       // coarse event rows: the region was walked by the one-lane loop from the search's end state (below)
+  if (sh && live && !fl && cx.use_ev && !serial) {
+    // Explicit-id cohorts: a region has one to three events, there is nothing for episodes in parallel to win, and the
+    // coarse row's bits do not name slots.  The group-parallel search above did the long part (thousands of ranks on a
+    // 10,000-sample cohort); the walk itself runs the serial loop from the state the search left (redundant in the group,
+    // lane 0 writes).
+    uint32_t jm = 0, sp = 0;
+    auto sink = [&](const WalkEmit& e1) {
+      if (nvar < scap) {
+        if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
+      } else if (l == 0) *ws.overflow = 1;
+      nvar++; ncar += pad_car(e1.c);
+    };
+    walk_serial<true>(im, cx, ev, irr, hold, st, sink, jm, sp);
+    walked = true;
+  }
+  if (live && !fl && cx.use_ev && !serial && !walked) {
     // ---- head: literal steps from the start state until the walk is in step (redundant in the group) ----
     bool done = false, term = false;
     uint32_t steps = 0;
@@ -721,7 +784,7 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (busy) ++n_chunks;
     // the next 16 events at or after cur_slot, one per lane: lane l loads word l of the row from cur_slot's word on
     const uint32_t w0 = cur_slot >> 6, w_end = (cx.limit + 63) >> 6, wi = w0 + l;
-    uint64_t word = (busy && wi < w_end) ? (ev.row[wi] | evw.word2(wi)) : 0;
+    uint64_t word = (busy && wi < w_end) ? (ev.row[wi] | irr_word_from(irr.row, wi, cx.irr_from)) : 0;   // (sh == 0 here)
     if (l == 0) word &= ~0ULL << (cur_slot & 63);
     if (busy && wi == (cx.limit >> 6) && (cx.limit & 63)) word &= (1ULL << (cx.limit & 63)) - 1;
     const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);
@@ -807,15 +870,15 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     if (serial) {
       uint32_t it = 0, lit = 0, jm = 0, sp = 0;
       nvar = 0; ncar = 0;
-      ev.w = kNone; hold.w = kNone; evw.w = kNone;
+      ev.w = kNone; hold.w = kNone; irr.w = kNone;
       auto sink = [&](const WalkEmit& e1) {
         if (nvar < scap) {
           if (l == 0) { const uint64_t s = s0 + nvar; ws.pos[s] = e1.ref_pos; ws.cur[s] = e1.cur; ws.ro[s] = e1.kind; ws.rl[s] = e1.cur_ref_v; }
         } else if (l == 0) *ws.overflow = 1;
         nvar++; ncar += pad_car(e1.c);
       };
-      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, evw, hold, st, sink, jm, sp); }
-      else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, evw, hold, st, sink, jm, sp); }
+      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, ev, irr, hold, st, sink, jm, sp); }
+      else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, ev, irr, hold, st, sink, jm, sp); }
     }
   }
   if (live && l == 0) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
