@@ -105,7 +105,7 @@ __device__ __forceinline__ bool rewind_to_sample_pos(const DevImage& im, uint64_
 // get_prev_vertex_with_sample as in walk_start_search<true>: ranks whose node has no out-neighbour holding the sample
 // (clear event bit) are counted down without being read; the candidate's edge records come from the walk blob, "holds
 // the sample" from the hold row, and only the vertex that is found pays the look-up of its sample-coordinate index.
-constexpr uint32_t kSerialHopAfter = 48;   // skipped ranks before a one-lane backward search goes over to the event row's set bits
+constexpr uint32_t kSerialHopAfter = 4;   // skipped ranks before a one-lane backward search goes over to the event row's set bits
 template <bool WANT_INDEX = true>   // (type 2 never reads sample_pos: no look-up of the found vertex's index)
 __device__ __forceinline__ uint32_t prev_vertex_with_sample_ev(const DevImage& im, uint64_t pos, uint32_t sid, BitRow& ev, BitRow& hold,
                                                                uint64_t& ref_pos, uint64_t& sample_pos) {
