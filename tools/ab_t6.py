@@ -24,15 +24,18 @@ def run(label, opts, steps=30):
     torch.cuda.synchronize()
     acc = np.zeros(5)
     prev = None
+    fills = []
     t0 = time.perf_counter()
     for _ in range(steps):     # as bench.py's loop: a result is closed one step late, nothing waits for the batch inside the loop
         r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
         if prev is not None:
+            fills.append(prev.fill_ms())
             prev.close()
         prev = r
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps * 1e3
     prev.close()
+    label = f"{label} [fill in the loop {np.mean(fills):.4f}]"
     for _ in range(steps):     # phases by the handle's events (reading them waits for the batch)
         r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
         t = vs.last_timing()

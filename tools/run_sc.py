@@ -26,17 +26,26 @@ st = rng.integers(max(1, kw["first_pos"]), kw["ref_length"] - w["region_len"], s
 reg = np.stack([st, st + w["region_len"]], axis=1).astype(np.uint64)
 ns = vs.info().num_samples
 per = np.array([1 + ((i % 16) * 157) % (ns - 1) for i in range(n)], dtype=np.uint32)
-for name, call in (("type2", lambda: vs.query_sample_seq(reg, per, sample_coordinates=False)),
-                   ("type3", lambda: vs.query_sample_seq(reg, per, sample_coordinates=True)),
-                   ("type5", lambda: vs.get_sample_var_in_sample(reg, per))):
-    call().close()
-    torch.cuda.synchronize()
-    a = time.perf_counter()
-    for _ in range(3):
-        r = call()
-        t = vs.last_timing()
-        r.close()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - a) / 3
-    print(f"{name}: {n / dt / 1e6:.1f} M regions/s, {dt * 1e3:.3f} ms per batch | phases ms: total {t.ms_total:.3f} bounds/walk {t.ms_bounds:.3f} "
-          f"scan {t.ms_scan:.3f} emit {t.ms_emit:.3f} fill {t.ms_fill:.3f}", flush=True)
+forms = [int(v) for v in os.environ.get("VS_T4_WALK", "2").split(",")]   # walk forms to time: 2 cooperative, 1 one lane per region
+seen = {}
+for form in forms:
+  vs.set_option("t4_walk", form)
+  for name, call in (("type2",   lambda: vs.query_sample_seq(reg, per, sample_coordinates=False)),
+                     ("type3", lambda: vs.query_sample_seq(reg, per, sample_coordinates=True)),
+                     ("type5", lambda: vs.get_sample_var_in_sample(reg, per))):
+      call().close()
+      torch.cuda.synchronize()
+      a = time.perf_counter()
+      for _ in range(3):
+          r = call()
+          t = vs.last_timing()
+          r.close()
+      torch.cuda.synchronize()
+      dt = (time.perf_counter() - a) / 3
+      r = call()
+      key = (r.totals(), hash(r.sequences()[0].tobytes()), hash(tuple(r.sequences()[1][:2000]))) if name != "type5" else (r.totals(), r.digest())
+      r.close()
+      same = "" if name not in seen else ("  == first form" if seen[name] == key else "  DIFFERS from the first form")
+      seen.setdefault(name, key)
+      print(f"walk form {form} {name}: {n / dt / 1e6:.1f} M regions/s, {dt * 1e3:.3f} ms per batch | phases ms: total {t.ms_total:.3f} bounds/walk {t.ms_bounds:.3f} "
+            f"scan {t.ms_scan:.3f} emit {t.ms_emit:.3f} fill {t.ms_fill:.3f}{same}", flush=True)

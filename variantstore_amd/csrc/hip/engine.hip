@@ -97,6 +97,8 @@ struct vs_index {
   std::vector<DevBuf> pool;
   unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
   uint64_t t4_gen = 0;
+  hipStream_t plan_stream = nullptr;        // the plan of an async_submit batch runs here, beside the previous batch's expansion on `stream`
+  hipEvent_t plan_ev = nullptr;
   hipStream_t fill_stream = nullptr;        // second stream: the expansion of an async_fill batch
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
   bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
@@ -104,6 +106,9 @@ struct vs_index {
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
   bool batch_in_flight = false;             // a batch returned when it was enqueued (async_submit) and nothing has synchronised the stream since
+  hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the events collect_timing reads: the handle's own (ev[]) or, for a
+                                            // lean batch, the result's pair around its expansion (timing_owner)
+  vs_result* timing_owner = nullptr;
   bool timing_pending = false;              // the last batch returned before its kernels had finished: vs_index_last_timing reads the events then
   uint64_t timing_fill_launches = 0;
   std::vector<hipEvent_t> ev_pool;          // timing events of results (two per shared batch), reused between results
@@ -166,6 +171,8 @@ struct vs_result {
   // async_fill: the expansion of this result is (or was) in flight on the handle's second stream
   bool pending = false;
   hipEvent_t ev_fill[2] = {nullptr, nullptr};   // around the expansion, on the stream it runs on
+  hipEvent_t ev_done = nullptr;       // behind the LAST kernel of a batch that returned when it was enqueued (async_submit): nothing of the result
+                                      // -- its buffers, the call's temporaries it keeps -- goes back to the pool before this has happened
   float fill_ms = -1.0f;
   bool resident = false;              // the carrier arena is the index's (vs_index::res_arena), not this result's
   bool scattered_lists = false;       // lists shared per vertex (walking query types): a region's carriers are not one arena range
@@ -326,6 +333,7 @@ struct ScratchBufs {
   void release() { release_bufs(idx, bufs); }
   ~ScratchBufs() {
     if (bufs.empty()) return;
+    if (idx->plan_stream) (void)hipStreamSynchronize(idx->plan_stream);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     release_bufs(idx, bufs);
   }
@@ -623,17 +631,31 @@ static int result_events(vs_result* r) {   // the result's own pair of timing ev
   }
   return VS_OK;
 }
+static int pooled_event(vs_index* idx, hipEvent_t* e) {
+  if (*e) return VS_OK;
+  if (!idx->ev_pool.empty()) { *e = idx->ev_pool.back(); idx->ev_pool.pop_back(); return VS_OK; }
+  HIP_TRY(hipEventCreate(e));
+  return VS_OK;
+}
+static int ensure_plan_stream(vs_index* idx) {
+  if (idx->plan_stream) return VS_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&idx->plan_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&idx->plan_ev, hipEventDisableTiming));
+  return VS_OK;
+}
 // The phase times of a batch from the handle's events (the batch's last event has completed or is waited for here).
 static int collect_timing(vs_index* idx) {
   if (!idx->timing_pending) return VS_OK;
   idx->timing_pending = false;
   vs_timing& t = idx->timing;
-  HIP_TRY(hipEventSynchronize(idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, idx->ev[0], idx->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_scan, idx->ev[1], idx->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_emit, idx->ev[2], idx->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&t.ms_fill, idx->ev[3], idx->ev[4]));
+  hipEvent_t* e = idx->timing_owner ? idx->tev : idx->ev;
+  idx->timing_owner = nullptr;
+  HIP_TRY(hipEventSynchronize(e[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_total, e[0], e[4]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_bounds, e[0], e[1]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_scan, e[1], e[2]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_emit, e[2], e[3]));
+  HIP_TRY(hipEventElapsedTime(&t.ms_fill, e[3], e[4]));
   t.fill_launches = idx->timing_fill_launches;
   return VS_OK;
 }
@@ -642,8 +664,11 @@ static int collect_timing(vs_index* idx) {
 static int result_ready(vs_result* r) {
   if (!r->pending) return VS_OK;
   r->pending = false;
-  HIP_TRY(hipEventSynchronize(r->ev_fill[1]));
-  HIP_TRY(hipEventElapsedTime(&r->fill_ms, r->ev_fill[0], r->ev_fill[1]));
+  if (r->ev_done) HIP_TRY(hipEventSynchronize(r->ev_done));
+  if (r->ev_fill[1]) {
+    HIP_TRY(hipEventSynchronize(r->ev_fill[1]));
+    HIP_TRY(hipEventElapsedTime(&r->fill_ms, r->ev_fill[0], r->ev_fill[1]));
+  }
   return VS_OK;
 }
 
@@ -784,6 +809,7 @@ static int wait_posted(vs_index* idx, volatile uint64_t* word, uint64_t seq, int
     if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > deadline) break;
   }
   if (!posted) {
+    if (idx->plan_stream) HIP_TRY(hipStreamSynchronize(idx->plan_stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
     if (*word != seq) return fail(VS_ERR_INTERNAL, "a batch kernel finished without posting its sequence word");
   }
@@ -846,9 +872,19 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   VS_TRY(ralloc(r, n, &d.q_car_len));
-  if (regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
-  else HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
-  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  // async_submit: the PLAN of this batch runs on a stream of its own -- beside the expansion of the batch before it, which
+  // is still on the handle's stream when the caller submits back to back.  The plan reads the regions and the index and
+  // writes this batch's own arrays; nothing in the pool is referenced by work in flight (a batch that returned when it
+  // was enqueued keeps its temporaries until its completion event, vs_result::ev_done), so its buffers are its own.  The
+  // rest of the batch (rows, expansion) goes to the handle's stream behind an event.  Not for a handle that sorts first,
+  // not with async_fill (whose second stream plays the opposite game).
+  const bool async_submit = allow_async && idx->opts.async_submit && !idx->opts.async_fill && !idx->opts.lat_debug;
+  bool plan_aside = async_submit && !(idx->sort_hint && idx->sort_probe_in > 0);
+  if (plan_aside) VS_TRY(ensure_plan_stream(idx));
+  hipStream_t ps = plan_aside ? idx->plan_stream : idx->stream;
+  if (regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ps));
+  else HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, ps));
+  HIP_TRY(hipEventRecord(idx->ev[0], ps));
   ScratchBufs scratch(idx);
   const bool resident = idx->opts.resident_lists && idx->res_arena;
   // ---- plan ----
@@ -868,19 +904,19 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   VS_TRY(dev_alloc(idx, (n + 1) * sizeof(RunRec), (void**)&runs, &scratch.bufs));
   PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
   auto launch_bounds = [&](int src) {
-    if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
-    else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, site_records, items, tile_max);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
+    if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
+    else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, site_records, items, tile_max);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
   };
   // the plan over the regions as they stand in `d`; the totals arrive in mapped host memory
   auto plan = [&](int src) -> int {
-    HIP_TRY(hipMemsetAsync(status, 0, 4, idx->stream));
+    HIP_TRY(hipMemsetAsync(status, 0, 4, ps));
     launch_bounds(src);
-    hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
+    hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
-    if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+    if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                                      ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, idx->res_entries);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, idx->stream, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                             ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return wait_posted(idx, &pt->seq, seq, 200);
@@ -927,13 +963,21 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   } else {
     VS_TRY(plan(src));
     if (pt->not_sorted) {
+      if (plan_aside) {   // the sort and the second plan run on the handle's stream (behind the plan stream's work so far)
+        HIP_TRY(hipStreamSynchronize(ps));
+        plan_aside = false; ps = idx->stream;
+      }
       VS_TRY(sort_batch());
       VS_TRY(plan(2));
       idx->sort_hint = true; idx->sort_probe_in = 32;
     } else idx->sort_hint = false;
   }
   if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
-  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[1], ps));
+  if (plan_aside) {   // (the host has seen the totals block 0 posted; the handle's stream waits for the whole plan)
+    HIP_TRY(hipEventRecord(idx->plan_ev, ps));
+    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->plan_ev, 0));
+  }
   const uint64_t U = pt->shared_rows, n_slow = pt->n_slow, n_runs = pt->n_runs;
   d.A = pt->rows;
   d.S = pt->arena;
@@ -950,23 +994,28 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
     d.carriers = arena;
   }
-  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  // ---- shared rows + carrier lists: which form ----
+  const uint64_t n_fill = resident ? 0 : U;
+  const bool async_fill = allow_async && idx->opts.async_fill && n_fill > 0;
+  const bool fused = idx->opts.fill_fused && !resident && !async_fill;
+  // Every event on a stream is a packet the GPU works through (~3 us each): the default batch -- async_submit, rows and lists in one
+  // launch, no permutation -- records TWO on the handle's stream, the result's own pair around the expansion, and its phase
+  // times are read from those (round 3 recorded five per batch, and this round's completion event would have made it eight).
+  const bool lean = async_submit && fused && n_fill > 0 && !perm;
+  if (!lean) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   // ---- rows of the regions under the duplicate rule ----
   if (n_slow) {
     const uint64_t waves = std::min<uint64_t>(n_slow, 16384);
     hipLaunchKernelGGL(k_t6_slow, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)slow_list, n_slow);
   }
   // ---- shared rows + carrier lists ----
-  const uint64_t n_fill = resident ? 0 : U;
-  const bool async_fill = allow_async && idx->opts.async_fill && n_fill > 0;
   uint32_t* u_site = nullptr;
-  const bool fused = idx->opts.fill_fused && !resident && !async_fill;
   if (U && !fused) {
     if (!resident) VS_TRY(dev_alloc(idx, U * 4 + 8, (void**)&u_site, &scratch.bufs));
     hipLaunchKernelGGL(k_share_rows2, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, (const RunRec*)runs, (const uint32_t*)coarse, n_runs, U, u_site);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  if (!lean) HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   if (async_fill) {
     // the expansion goes to the handle's second stream behind an event and the call returns once the FIRST stream is done
     // (rows, per-region arrays); the next batch's plan and rows then run beside it.  The call's temporaries (the site
@@ -1033,13 +1082,16 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     hipLaunchKernelGGL(k_permute_out, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, idx->stream, ds, d, (const uint32_t*)perm);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  if (!lean) HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  else {   // plan: the handle's two events on the plan stream; the rest: the result's pair (no separate rows kernel: ms_emit = 0)
+    idx->tev[0] = idx->ev[0]; idx->tev[1] = idx->ev[1]; idx->tev[2] = r->ev_fill[0]; idx->tev[3] = r->ev_fill[0]; idx->tev[4] = r->ev_fill[1];
+    idx->timing_owner = r;
+  }
   idx->timing_pending = true;
   idx->timing_fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
   // async_submit: the batch is enqueued, its sizes are known (the plan's totals) and its buffers are the result's -- the call
   // returns here.  Whatever reads the result (copies, digests, packs, the next batch's kernels that reuse the temporaries
   // released below) is ordered behind the batch on the handle's stream; the timing events are read when asked for.
-  const bool async_submit = allow_async && idx->opts.async_submit && !async_fill && !idx->opts.lat_debug;
   if (!async_submit) {
     uint64_t* done = idx->pinned + vs_index::kPinDone;
     const uint64_t seq = ++idx->done_seq;
@@ -1048,9 +1100,19 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     VS_TRY(wait_posted(idx, done, seq, 2000));
     idx->batch_in_flight = false;
   }
-  if (async_fill) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
-  if (async_submit) { release_bufs(idx, scratch.bufs); idx->batch_in_flight = true; }   // (stream-ordered reuse: no wait)
-  else scratch.release();
+  if (async_submit) {
+    // the batch's completion event (a lean batch's last kernel is its expansion: the result's own event behind that is it);
+    // the call's temporaries stay with the result until it has happened (vs_result_free, result_ready): a buffer in the
+    // pool is never referenced by work in flight, whatever stream takes it next
+    if (!lean) {
+      VS_TRY(pooled_event(idx, &r->ev_done));
+      HIP_TRY(hipEventRecord(r->ev_done, idx->stream));
+    }
+    r->pending = true;
+    idx->batch_in_flight = true;
+  }
+  if (async_fill || async_submit) { r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end()); scratch.bufs.clear(); }
+  scratch.release();
   if (!async_submit) VS_TRY(collect_timing(idx));
   return VS_OK;
 }
@@ -1084,7 +1146,7 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
   vs_result* r = c.r;
   const uint64_t n = c.n;
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
-  idx->timing_pending = false;
+  idx->timing_pending = false; idx->timing_owner = nullptr;
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1241,6 +1303,11 @@ static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const 
 }
 template <int MODE, int PASS>
 static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) {
+  // the single walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
+  if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq_coop<MODE, 8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
+    return;
+  }
   if (idx->opts.sc_group > 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, q);
@@ -1456,7 +1523,7 @@ static int fetch_headers(vs_result* r) {
 static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r) {
   DevSeqResult& q = r->sq;
   if (idx->srv_alive) VS_TRY(server_stop(idx));
-  idx->timing_pending = false;
+  idx->timing_pending = false; idx->timing_owner = nullptr;
   q.Q = n;
   r->d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1640,7 +1707,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     HIP_TRY(hipStreamSynchronize(idx->stream));
   }
   const auto host_enter = std::chrono::steady_clock::now();
-  idx->timing_pending = false;
+  idx->timing_pending = false; idx->timing_owner = nullptr;
   DevResult& d = r->d;
   uint64_t capA = 0, capS = 0, ntasks = 0;
   for (uint64_t q = 0; q < n; ++q) {
@@ -1781,6 +1848,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
 // A failed call: kernels of the attempt may still be queued, so the stream is drained before the result's buffers
 // go back to the pool.
 static int drop_result(vs_result* r, int rc) {
+  if (r->idx && r->idx->plan_stream) (void)hipStreamSynchronize(r->idx->plan_stream);
   if (r->idx && r->idx->stream) (void)hipStreamSynchronize(r->idx->stream);
   vs_result_free(r);
   return rc;
@@ -1821,6 +1889,8 @@ void vs_index_close(vs_index* idx) {
     if (idx->res_mirror) (void)hipHostFree(idx->res_mirror);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->fill_stream) (void)hipStreamDestroy(idx->fill_stream);
+    if (idx->plan_stream) (void)hipStreamDestroy(idx->plan_stream);
+    if (idx->plan_ev) (void)hipEventDestroy(idx->plan_ev);
     for (auto& e : idx->fill_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev_pool) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
@@ -2016,7 +2086,9 @@ void vs_result_free(vs_result* r) {
   if (r->idx) {
     (void)hipSetDevice(r->idx->device);
     (void)result_ready(r);
+    if (r->idx->timing_owner == r) (void)collect_timing(r->idx);   // (its events go back to the pool below)
     for (auto& e : r->ev_fill) if (e) { r->idx->ev_pool.push_back(e); e = nullptr; }
+    if (r->ev_done) { r->idx->ev_pool.push_back(r->ev_done); r->ev_done = nullptr; }
     release_bufs(r->idx, r->bufs);
     pin_release(r->idx, r->raw_pin);
     for (auto& b : r->old_pins) pin_release(r->idx, b);

@@ -449,17 +449,11 @@ __device__ __forceinline__ int seq_window(const DevSeqResult& r, SeqSink& s, uin
   return 0;
 }
 
-// (SUB lanes per region running the same walk, lane 0 writing: see k_sample_walk_sc)
-template <int MODE, int PASS, uint32_t SUB = kScGroup>
-__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, DevSeqResult r) {
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
-  if (q >= r.Q) return;
-  if (PASS == 1 && r.q_flags[q]) return;
-  const uint32_t sid = r.sids[q];
-  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
-  const uint64_t seg0 = PASS ? r.seg_begin[q] : 0, byte0 = PASS == 1 ? r.byte_begin[q] : 0;
-  const uint64_t cap = PASS == 2 ? r.seg_begin[q + 1] - seg0 : 0;
-  SeqSink s{0, 0, (threadIdx.x % SUB) == 0};
+// One region's walk, start to end, by one lane (the reference's loop with jumps over uneventful runs when the sample has
+// event rows): returns the region's flag, the pieces go through `s`.
+template <int MODE, int PASS>
+__device__ __forceinline__ uint8_t seq_walk_region(const DevImage& im, const DevSeqResult& r, uint64_t x, uint64_t y, uint32_t sid,
+                                                   uint64_t seg0, uint64_t byte0, uint64_t cap, SeqSink& s) {
   uint8_t fl = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t cur = 0;
@@ -565,7 +559,228 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
       cur = nxt;
     }
   }
+  return fl;
+}
+
+// (SUB lanes per region running the same walk, lane 0 writing: see k_sample_walk_sc)
+template <int MODE, int PASS, uint32_t SUB = kScGroup>
+__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, DevSeqResult r) {
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  if (q >= r.Q) return;
+  if (PASS == 1 && r.q_flags[q]) return;
+  const uint32_t sid = r.sids[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  const uint64_t seg0 = PASS ? r.seg_begin[q] : 0, byte0 = PASS == 1 ? r.byte_begin[q] : 0;
+  const uint64_t cap = PASS == 2 ? r.seg_begin[q + 1] - seg0 : 0;
+  SeqSink s{0, 0, (threadIdx.x % SUB) == 0};
+  const uint8_t fl = seq_walk_region<MODE, PASS>(im, r, x, y, sid, seg0, byte0, cap, s);
   if (PASS != 1 && s.lead) {
+    r.q_flags[q] = fl;
+    r.q_nseg[q] = fl ? 0 : s.nseg;
+    r.q_nbytes[q] = fl ? 0 : s.nbytes;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Query types 2 and 3, cooperative (round 4): SUB lanes per region.
+// One lane per region walks a chain of ~90 dependent look-ups (a sample has ~11 events in a 10 kb region of the chr1
+// cohort, each costs the jump to it, the step off the path and the step back); a batch is 1,563 waves and the kernel's
+// time is the longest chain's.  Here the chain is cut: after the backward search and the head (redundant in the group,
+// same addresses) the group takes the region's EVENTS -- set bits of the sample's event row and of the break row -- SUB
+// at a time, one per lane, and every lane walks its own EPISODE: arrive at the event's slot as a jump would (in step),
+// step literally until the walk stands on the ref path again (type 2: in step with it).  An episode's pieces stay in
+// registers.  Then the hand-over, in order and in registers: the first episode at or after the slot the chain stands on
+// is the one the serial walk would run next; its lane puts the uneventful run up to its slot and its own pieces through
+// the reference's window logic (seq_window: the `record` flag, clipping at x and y, the stop) with the running position
+// and counts it receives, writes the pieces, and hands the end state on.  Episodes the chain jumps over are dropped.
+// When fewer than SUB events lie in the SUB words a round looks at, the next lane lands on the first slot behind them
+// (a jump to a slot without an event is a literal step like any other: the one-lane walk does the same at its
+// look-ahead limit), so every round advances.  Pieces differ from the one-lane walk's in where runs are cut, the bytes
+// do not.  Anything that does not fit -- an episode of more than kSeqEpSteps steps, a walk that never finds the path,
+// positions beyond 32 bits -- sends the region through the one-lane walk (seq_walk_region), in this kernel.
+// Not for coarse event rows (explicit-id cohorts: one to three events per region, bits that do not name slots).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSeqEpSteps = 6;
+struct SeqSt { uint32_t cur, rbeg, deg, ridx, off, len, slot1; };   // a vertex of the walk: first edge record, degree, ref index, sequence, ref-path slot + 1
+// the out-edges of one literal iteration (query.h:143-180 / :228-250): the FIRST ref neighbour's index; get_neighbor_vertex
+// (variant_graph.h:1402-1451) with the record of the vertex it names (n.off is not part of an edge record)
+__device__ __forceinline__ uint32_t seq_step_edges(const DevImage& im, BitRow& hold, const SeqSt& st, uint64_t& next_ref_pos, SeqSt& n) {
+  bool have_ref = false, by_sample = false;
+  uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+  for (uint32_t e = st.rbeg; e < st.rbeg + st.deg; ++e) {
+    const uint4 a = im.wblob[2 * (uint64_t)e];
+    if (a.y && !have_ref) { next_ref_pos = a.y; have_ref = true; }
+    if (!by_sample) {
+      const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+      const bool holds = hold.bit_n(a.x, b.w);
+      if (holds || (a.y && min_idx > a.y)) {
+        nxt = a.x; n.cur = a.x; n.rbeg = a.w; n.deg = b.x; n.ridx = a.y; n.len = b.z; n.slot1 = b.y;
+        if (holds) by_sample = true; else min_idx = a.y;
+      }
+    }
+  }
+  return nxt;
+}
+__device__ __forceinline__ SeqSt seq_slot_state(const DevImage& im, uint32_t k) {   // the node of ref-path slot k from its header record
+  const uint64_t h = im.blob_of_slot[k];
+  const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];
+  return SeqSt{rb.w, ra.x, ra.y, ra.z, ra.w, rb.x, k + 1};
+}
+
+template <int MODE, uint32_t SUB>
+__global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResult r) {
+  static_assert(MODE == 2 || MODE == 3, "query type");
+  static_assert(SUB == 8 || SUB == 16, "group width");
+  constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
+  const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  const bool live = q < r.Q;
+  uint32_t sid = 0;
+  uint64_t x = 0, y = 0, seg0 = 0, cap = 0;
+  if (live) { sid = r.sids[q]; x = r.regions[2 * q]; y = r.regions[2 * q + 1]; seg0 = r.seg_begin[q]; cap = r.seg_begin[q + 1] - seg0; }
+  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x && im.t4_ev_shift == 0;
+  // group-uniform state
+  bool serial = live && !fast, busy = false, record = false;
+  SeqSink s{0, 0, l == 0};
+  uint8_t fl = 0;
+  uint64_t pos = 0;                                   // type 2: ref_pos, type 3: sample_pos
+  uint32_t cur_slot = 0, off_cur = 0, ridx_cur = 0;   // the ref-path node the chain stands on: slot, sequence offset, ref index
+  BitRow ev = sample_event_row(im, sid, fast), hold = sample_hold_row(im, sid, fast);
+  const uint32_t last_slot = (uint32_t)im.P - 1;
+  if (fast) {
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t cur = 0;
+    bool ok = true;
+    if (MODE == 2) cur = prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos);
+    else ok = rewind_to_sample_pos_ev(im, x, sid, ev, hold, cur, ref_pos, sample_pos);
+    if (!ok) fl = kRegionEndless;
+    else {
+      // ---- head: literal iterations from the start vertex until the walk stands on the path (redundant in the group, lane 0 writes) ----
+      const uint4 v0 = im.w_vertex[2 * (uint64_t)cur], v1 = im.w_vertex[2 * (uint64_t)cur + 1];
+      SeqSt st{cur, im.blob_row[cur], v0.y, v0.z, v0.w, v1.x, v1.w};
+      uint32_t steps = 0;
+      while (true) {
+        if (st.slot1 && (MODE != 2 || ref_pos == st.ridx)) { busy = true; cur_slot = st.slot1 - 1; off_cur = st.off; ridx_cur = st.ridx; break; }
+        if (++steps > 64) { serial = true; break; }
+        uint64_t next_ref_pos = ref_pos + st.len;
+        SeqSt n{};
+        const uint32_t nxt = seq_step_edges(im, hold, st, next_ref_pos, n);
+        int w;
+        if (MODE == 2) { w = seq_window<2>(r, s, seg0, 0, cap, record, st.off, st.len, ref_pos, next_ref_pos, x, y); ref_pos = next_ref_pos; }
+        else { w = seq_window<2>(r, s, seg0, 0, cap, record, st.off, st.len, sample_pos, sample_pos + st.len, x, y); sample_pos += st.len; }
+        if (w == 2) { fl = kRegionInvalid; break; }
+        if (w == 1 || nxt == 0) break;
+        st = n;
+        st.off = im.v_off[st.cur];
+      }
+      pos = MODE == 2 ? ref_pos : sample_pos;
+    }
+  }
+  // ---- episodes, SUB events of a group at a time ----
+  while (__any(busy)) {
+    // the events at or after cur_slot and below the last slot in SUB words of the two rows, one word per lane
+    const uint32_t w0 = cur_slot >> 6, wi = w0 + l;
+    uint64_t word = 0;
+    if (busy && ((uint64_t)wi << 6) < last_slot) {
+      word = ev.row[wi] | im.seq_breaks[wi];
+      if (l == 0) word &= ~0ULL << (cur_slot & 63);
+      if (wi == (last_slot >> 6)) word &= (1ULL << (last_slot & 63)) - 1;
+    }
+    const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)gbase + (int)SUB - 1, 64);
+    uint32_t j = 0;                                   // the word holding this lane's event: #words whose inclusive count is <= l
+#pragma unroll
+    for (int t = 0; t < (int)SUB; ++t) j += (uint32_t)__shfl((int)incl, (int)gbase + t, 64) <= l ? 1u : 0u;
+    const int src = (int)gbase + (int)(j < SUB ? j : SUB - 1);
+    const uint64_t wj = shfl64(word, src);
+    const uint32_t excl_j = (uint32_t)__shfl((int)(incl - pc), src, 64);
+    const uint64_t chunk_end64 = ((uint64_t)(w0 + SUB)) << 6;
+    const uint32_t chunk_end = chunk_end64 < last_slot ? (uint32_t)chunk_end64 : last_slot;
+    bool have = busy && l < total;
+    uint32_t slot = 0;
+    if (have) slot = ((w0 + j) << 6) + select_bit(wj, l - excl_j);
+    else if (busy && l == total) { have = true; slot = chunk_end; }   // the landing slot behind the round's events
+    // ---- this lane's episode ----
+    uint32_t p_off[kSeqEpSteps], p_len[kSeqEpSteps], p_cur[kSeqEpSteps], p_next[kSeqEpSteps];
+    uint32_t n_p = 0, ep_end = 0, e_off = 0, e_ridx = 0, k_ridx = 0;
+    bool ep_term = false, ep_ovf = false;
+    if (have) {
+      SeqSt es = seq_slot_state(im, slot);
+      k_ridx = es.ridx;
+      uint64_t e_ref = es.ridx;
+      while (true) {
+        uint64_t next_ref_pos = e_ref + es.len;
+        SeqSt n{};
+        const uint32_t nxt = seq_step_edges(im, hold, es, next_ref_pos, n);
+        if (next_ref_pos >> 32) { ep_ovf = true; break; }
+#pragma unroll
+        for (uint32_t t = 0; t < kSeqEpSteps; ++t)
+          if (t == n_p) { p_off[t] = es.off; p_len[t] = es.len; p_cur[t] = (uint32_t)e_ref; p_next[t] = (uint32_t)next_ref_pos; }
+        ++n_p;
+        e_ref = next_ref_pos;
+        if (nxt == 0) { ep_term = true; break; }
+        es = n;
+        es.off = im.v_off[es.cur];
+        if (es.slot1 && (MODE != 2 || e_ref == es.ridx)) { ep_end = es.slot1 - 1; e_ridx = es.ridx; e_off = es.off; break; }
+        if (n_p >= kSeqEpSteps) { ep_ovf = true; break; }
+      }
+      if (!ep_term && !ep_ovf && ep_end <= slot) ep_ovf = true;   // (a walk that does not advance: one-lane walk)
+    }
+    // ---- the chain of hand-overs ----
+    bool gdone = !busy;
+#pragma unroll 1
+    for (int t = 0; t < (int)SUB; ++t) {
+      const bool cand = !gdone && have && slot >= cur_slot;
+      const uint32_t gb = (uint32_t)((__ballot(cand) >> gbase) & kGroupMask);
+      const int i = gb ? (int)gbase + __builtin_ctz(gb) : (int)gbase;
+      int stt = 0;                                    // 0 on, 1 the walk is over, 2 std::out_of_range, 3 one-lane walk
+      uint64_t pos_l = pos;
+      bool rec_l = record;
+      SeqSink s_l{s.nseg, s.nbytes, true};
+      if (gb && (int)lane == i) {
+        if (ep_ovf) stt = 3;
+        else {
+          if (slot > cur_slot) {                      // the uneventful run [cur_slot, slot): one piece
+            const uint64_t run = (uint64_t)k_ridx - ridx_cur;
+            if (MODE == 2) stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, off_cur, run, (uint64_t)ridx_cur, (uint64_t)k_ridx, x, y);
+            else { stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, off_cur, run, pos_l, pos_l + run, x, y); pos_l += run; }
+          }
+#pragma unroll
+          for (uint32_t t2 = 0; t2 < kSeqEpSteps; ++t2)
+            if (stt == 0 && t2 < n_p) {
+              if (MODE == 2) stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, p_off[t2], p_len[t2], (uint64_t)p_cur[t2], (uint64_t)p_next[t2], x, y);
+              else { stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, p_off[t2], p_len[t2], pos_l, pos_l + p_len[t2], x, y); pos_l += p_len[t2]; }
+            }
+          if (stt == 0 && ep_term) stt = 1;          // no next vertex: the path iterator is done
+        }
+      }
+      const int g_stt = __shfl(stt, i, 64);
+      const uint64_t g_nseg = shfl64(s_l.nseg, i), g_nbytes = shfl64(s_l.nbytes, i), g_pos = shfl64(pos_l, i);
+      const bool g_rec = __shfl((int)rec_l, i, 64) != 0;
+      const uint32_t g_end = (uint32_t)__shfl((int)ep_end, i, 64), g_off = (uint32_t)__shfl((int)e_off, i, 64), g_ridx = (uint32_t)__shfl((int)e_ridx, i, 64);
+      if (!gdone) {
+        if (!gb) gdone = true;                        // no event left in this round
+        else {
+          s.nseg = g_nseg; s.nbytes = g_nbytes; pos = g_pos; record = g_rec;
+          if (g_stt == 0) { cur_slot = g_end; off_cur = g_off; ridx_cur = g_ridx; }
+          else {
+            gdone = true; busy = false;
+            if (g_stt == 2) fl = kRegionInvalid;
+            if (g_stt == 3) serial = true;
+          }
+        }
+      }
+      if (!__any(!gdone)) break;
+    }
+  }
+  // ---- regions without event rows, and fallbacks: the one-lane walk (redundant in the group; lane 0 writes) ----
+  if (__any(serial)) {
+    if (serial) {
+      s = SeqSink{0, 0, l == 0};
+      fl = seq_walk_region<MODE, 2>(im, r, x, y, sid, seg0, 0, cap, s);
+    }
+  }
+  if (live && l == 0) {
     r.q_flags[q] = fl;
     r.q_nseg[q] = fl ? 0 : s.nseg;
     r.q_nbytes[q] = fl ? 0 : s.nbytes;
