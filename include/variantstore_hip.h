@@ -130,7 +130,11 @@ int vs_query_expand_site_ranges(vs_index* idx, const void* device_records, uint6
 /* type 4: get_sample_var_in_ref for one sample over n regions (query.h:618-729) */
 int vs_query_sample_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, uint32_t sample_id,
                                vs_result** out);
-/* type 4 with one sample id per region (a batch mixing samples, e.g. the cohort round-robin of the bench) */
+/* type 4 with one sample id per region (a batch mixing samples, e.g. the cohort round-robin of the bench).
+ * Here and in vs_query_sample_seq / vs_query_sample_var_in_sample, `regions` and `sample_ids` may each lie in host
+ * memory or in DEVICE memory of the handle's GPU (the engine asks the runtime which): device arrays are neither read
+ * on the host nor copied over the link, and an id out of range is found by the batch's first kernel instead of the
+ * host loop -- the call fails with VS_ERR_UNKNOWN_SAMPLE either way. */
 int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids,
                                 vs_result** out);
 /* Query type 1, closest_var (include/query.h:441-483; called from src/commands.cc:151-155): the variants of the
@@ -329,8 +333,9 @@ void vs_comm_destroy(vs_comm* c);
  *                     (default 0; VS_RESIDENT_LISTS=1 in the environment builds it when the handle is opened)
  *   "async_submit"    see vs_result_fill_ms (default 1)
  *   "async_fill"      see vs_result_fill_ms (default 0)
- *   "t4_walk"         the walk of query type 4: 2 cooperative (8 lanes per region; default), 1 one lane per region jumping
- *                     over uneventful ref-path runs, 0 literal (every vertex of the sample's path)
+ *   "t4_walk"         the walk of the query types that follow one sample's path: 2 cooperative (8 lanes per region, a region's
+ *                     events walked in parallel: types 4, 2 and 3; default), 1 one lane per region jumping over uneventful
+ *                     ref-path runs, 0 literal (type 4: every vertex of the sample's path; types 2 / 3 / 5 as 1)
  *   "force_fallbacks" 1 = query types 2 - 5 take the count-then-emit pair of walks they fall back to when a region outgrows
  *                     the capacity of its recording walk (tests of that path)
  * Tuning builds (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) add "lat_debug", "fill_fused", "fill_chunk",

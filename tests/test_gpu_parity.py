@@ -622,6 +622,47 @@ def test_sample_sequence_batch_with_one_sample_per_region(tmp_path):
         assert res.totals()[3] == sum(len(s) for s in seqs)
 
 
+def test_walking_queries_take_regions_and_sample_ids_in_device_memory(tmp_path):
+    """Query types 4 (one sample per region), 2, 3 and 5 with their inputs already on the GPU (variantstore_hip.h:
+    vs_query_samples_var_in_ref): the same answers as from host arrays, in both walk forms; an id out of range in a device
+    array is refused by the batch itself."""
+    import torch
+    from variantstore_amd import DeviceArray, VariantStoreError
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 415, n_samples=70, n_rows=300, ref_len=5000, p_near=0.5)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(415)
+    regions = np.array(random_regions(rng, vs.info().ref_length, 200, max_len=900), dtype=np.uint64)
+    ids = rng.integers(1, vs.info().num_samples, size=len(regions)).astype(np.uint32)
+    reg_t = torch.from_numpy(regions.view(np.int64)).cuda()
+    ids_t = torch.from_numpy(ids.view(np.int32)).cuda()
+    dreg, dids = DeviceArray(reg_t.data_ptr(), len(regions)), DeviceArray(ids_t.data_ptr(), len(ids))
+    for form in (2, 1):
+        vs.set_option("t4_walk", form)
+        for call in (lambda r, i: vs.get_sample_var_in_ref(r, i), lambda r, i: vs.get_sample_var_in_sample(r, i)):
+            a, b, c = call(regions, ids), call(dreg, dids), call(dreg, ids)
+            assert a.totals() == b.totals() == c.totals() and a.digest() == b.digest() == c.digest()
+            assert [a.region_text(q) for q in range(0, 200, 7)] == [b.region_text(q) for q in range(0, 200, 7)]
+            a.close(); b.close(); c.close()
+        for coords in (False, True):
+            a, b = vs.query_sample_seq(regions, ids, sample_coordinates=coords), vs.query_sample_seq(dreg, dids, sample_coordinates=coords)
+            (fa, sa), (fb, sb) = a.sequences(), b.sequences()
+            assert np.array_equal(fa, fb) and sa == sb and a.totals() == b.totals()
+            a.close(); b.close()
+    vs.set_option("t4_walk", 2)
+    bad = ids.copy()
+    bad[137] = vs.info().num_samples
+    bad_t = torch.from_numpy(bad.view(np.int32)).cuda()
+    dbad = DeviceArray(bad_t.data_ptr(), len(bad))
+    for call in (lambda: vs.get_sample_var_in_ref(dreg, dbad), lambda: vs.get_sample_var_in_sample(dreg, dbad),
+                 lambda: vs.query_sample_seq(dreg, dbad), lambda: vs.get_sample_var_in_ref(regions, bad)):
+        with pytest.raises(VariantStoreError) as e:
+            call()
+        assert e.value.code == -6, e.value   # VS_ERR_UNKNOWN_SAMPLE
+    r = vs.get_sample_var_in_ref(dreg, dids)     # the handle is fine afterwards
+    assert r.region_text(3) == orc.get_sample_var_in_ref(int(regions[3, 0]), int(regions[3, 1]), vs.sample_name(int(ids[3])))[2]
+    r.close()
+
+
 def test_sample_coordinate_queries_synthetic_midsize(tmp_path):
     """20k variants x 200 samples (bit-vector classes), 300 regions of 5 kb, three samples: types 2, 3 and 5."""
     vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=23,

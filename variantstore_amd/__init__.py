@@ -4,4 +4,4 @@ Only the position-indexed variation-graph lookup path is here (query types 6
 and 4 of `variantstore query`), as HIP kernels behind a C ABI
 (include/variantstore_hip.h).  See DESIGN.md.
 """
-from .api import Comm, QueryResult, Variant, VariantStore, VariantStoreError  # noqa: F401
+from .api import Comm, DeviceArray, QueryResult, Variant, VariantStore, VariantStoreError  # noqa: F401

@@ -43,9 +43,28 @@ class Variant:  # reference include/query.h:30-36
     samples: List[Tuple[str, str]]
 
 
+class DeviceArray:
+    """An array that already lies in device memory: `ptr` (an integer address, e.g. a torch tensor's data_ptr()) and its
+    number of elements -- regions ({u64 beg, u64 end} pairs) or sample ids (u32).  The walking query types
+    (get_sample_var_in_ref with one sample per region, query_sample_seq, get_sample_var_in_sample) take it wherever they
+    take a host array; the engine then neither reads the array on the host nor copies it over the link."""
+
+    def __init__(self, ptr, n):
+        self.ptr = int(ptr)
+        self.n = int(n)
+
+
 def _regions_array(regions):
+    if isinstance(regions, DeviceArray):
+        return regions, C.cast(C.c_void_p(regions.ptr), C.POINTER(Region)), regions.n
     arr = np.ascontiguousarray(np.asarray(regions, dtype=np.uint64).reshape(-1, 2))
     return arr, arr.ctypes.data_as(C.POINTER(Region)), arr.shape[0]
+
+
+def _u32_ptr(ids):
+    if isinstance(ids, DeviceArray):
+        return C.cast(C.c_void_p(ids.ptr), C.POINTER(C.c_uint32))
+    return ids.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
 class QueryResult:
@@ -393,9 +412,9 @@ class VariantStore:
         """Query type 4 for one sample over a batch of regions (query.h:618-729)."""
         arr, ptr, n = _regions_array(regions)
         h = C.c_void_p()
-        if isinstance(sample, (list, tuple, np.ndarray)):  # one sample per region
+        if isinstance(sample, (list, tuple, np.ndarray, DeviceArray)):  # one sample per region
             sids = self._sample_ids(sample, n)
-            _check(self._lib.vs_query_samples_var_in_ref(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+            _check(self._lib.vs_query_samples_var_in_ref(self._h, ptr, n, _u32_ptr(sids),
                                                          C.byref(h)), "vs_query_samples_var_in_ref")
             return QueryResult(self, h)
         sid = self.sample_id(sample) if isinstance(sample, str) else int(sample)
@@ -426,6 +445,10 @@ class VariantStore:
         return QueryResult(self, h)
 
     def _sample_ids(self, sample, n):
+        if isinstance(sample, DeviceArray):
+            if sample.n != n:
+                raise ValueError("one sample per region expected")
+            return sample
         if isinstance(sample, np.ndarray) and sample.dtype.kind in "ui":   # ids already: no per-element Python
             sids = np.ascontiguousarray(sample, dtype=np.uint32)
             if sids.shape[0] != n:
@@ -445,7 +468,7 @@ class VariantStore:
         arr, ptr, n = _regions_array(regions)
         sids = self._sample_ids(sample, n)
         h = C.c_void_p()
-        _check(self._lib.vs_query_sample_seq(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+        _check(self._lib.vs_query_sample_seq(self._h, ptr, n, _u32_ptr(sids),
                                              1 if sample_coordinates else 0, C.byref(h)), "vs_query_sample_seq")
         return QueryResult(self, h)
 
@@ -454,7 +477,7 @@ class VariantStore:
         arr, ptr, n = _regions_array(regions)
         sids = self._sample_ids(sample, n)
         h = C.c_void_p()
-        _check(self._lib.vs_query_sample_var_in_sample(self._h, ptr, n, sids.ctypes.data_as(C.POINTER(C.c_uint32)),
+        _check(self._lib.vs_query_sample_var_in_sample(self._h, ptr, n, _u32_ptr(sids),
                                                        C.byref(h)), "vs_query_sample_var_in_sample")
         return QueryResult(self, h)
 

@@ -233,7 +233,7 @@ template <typename T>
 static int upload_image(vs_index* idx, const std::vector<T>& v, const T** dptr) {
   size_t bytes = v.size() * sizeof(T);
   void* p = nullptr;
-  HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
+  HIP_TRY(hipMalloc(&p, bytes + 64));   // (slack: k_copy_segments reads 16 bytes at a time, up to 15 beyond a piece)
   idx->image_allocs.push_back(p);
   idx->device_bytes += bytes;
   if (bytes) HIP_TRY(hipMemcpyAsync(p, v.data(), bytes, hipMemcpyHostToDevice, idx->stream));
@@ -642,6 +642,14 @@ static int ensure_plan_stream(vs_index* idx) {
   HIP_TRY(hipStreamCreateWithFlags(&idx->plan_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&idx->plan_ev, hipEventDisableTiming));
   return VS_OK;
+}
+// Regions and sample ids of the walking query types may be handed over in device memory (the copies below are
+// hipMemcpyDefault: the runtime reads the direction off the pointers).
+static bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain host memory: not known to the runtime)
+  return a.type == hipMemoryTypeDevice;
 }
 // The phase times of a batch from the handle's events (the batch's last event has completed or is waited for here).
 static int collect_timing(vs_index* idx) {
@@ -1136,10 +1144,22 @@ struct BatchCtx {
   uint64_t n;
   ScratchBufs scratch;
   uint32_t* dsids = nullptr;     // one sample per region (types 4 / 5), on the device
+  uint64_t* bad_ids = nullptr;   // ids that arrived in device memory: set by k_check_sample_ids, read with the batch's first sizes
   bool resident = false;         // rows point into the index's resident arena: nothing is expanded
   bool async_fill = false;
   BatchCtx(vs_index* i, vs_result* res, uint64_t nn) : idx(i), r(res), n(nn), scratch(i) {}
 };
+
+static int check_device_ids(vs_index* idx, vs_result* r, const uint32_t* dsids, uint64_t n, uint64_t** bad) {
+  VS_TRY(ralloc(r, 1, bad));
+  HIP_TRY(hipMemsetAsync(*bad, 0, 8, idx->stream));
+  hipLaunchKernelGGL(k_check_sample_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, dsids, n, idx->g.num_samples, *bad);
+  HIP_TRY(hipGetLastError());
+  return VS_OK;
+}
+static int bad_ids_error(vs_index* idx) {
+  return fail(VS_ERR_UNKNOWN_SAMPLE, "a sample id of the batch is out of range (%u samples)", idx->g.num_samples);
+}
 
 static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_device, const uint32_t* sample_ids) {
   vs_index* idx = c.idx;
@@ -1160,11 +1180,12 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
-  if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, idx->stream));
+  if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDefault, idx->stream));
   else if (n) HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
   if (sample_ids && n) {
     VS_TRY(ralloc(r, n, &c.dsids));
-    HIP_TRY(hipMemcpyAsync(c.dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
+    HIP_TRY(hipMemcpyAsync(c.dsids, sample_ids, n * 4, hipMemcpyDefault, idx->stream));
+    if (is_device_ptr(sample_ids)) VS_TRY(check_device_ids(idx, r, c.dsids, n, &c.bad_ids));
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
   return VS_OK;
@@ -1334,14 +1355,20 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     if (walk_mode == 5) launch_walk_sc<0>(idx, d, n, dsids, WalkScratch{});
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
   };
+  if (c.bad_ids && idx->opts.force_fallbacks) {   // (otherwise read with the capacities' total below: nothing before that looks at an id)
+    uint64_t bad = 0;
+    VS_TRY(read_device_words(idx, c.bad_ids, &bad));
+    if (bad) return bad_ids_error(idx);
+  }
   if (n && !idx->opts.force_fallbacks) {
     if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
     uint64_t* cap_begin = nullptr;
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch.bufs));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch.bufs));
-    uint64_t cap_total = 0;
-    VS_TRY(read_device_words(idx, cap_begin + n, &cap_total));
+    uint64_t cap_total = 0, bad = 0;
+    VS_TRY(read_device_words(idx, cap_begin + n, &cap_total, c.bad_ids, &bad));
+    if (bad) return bad_ids_error(idx);
     ws_capacity = cap_total;
     ws.cap_begin = cap_begin;
     VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch.bufs));
@@ -1536,14 +1563,20 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
   VS_TRY(ralloc(r, n, &q.q_nbytes));
   VS_TRY(ralloc(r, n + 1, &q.seg_begin));
   VS_TRY(ralloc(r, n + 1, &q.byte_begin));
+  uint64_t* bad_ids = nullptr;
   if (n) {
-    HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyHostToDevice, idx->stream));
-    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyHostToDevice, idx->stream));
+    HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyDefault, idx->stream));
+    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyDefault, idx->stream));
+    if (is_device_ptr(sample_ids)) VS_TRY(check_device_ids(idx, r, dsids, n, &bad_ids));
   }
   HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
-  
   ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
+  if (bad_ids && idx->opts.force_fallbacks) {
+    uint64_t bad = 0;
+    VS_TRY(read_device_words(idx, bad_ids, &bad));
+    if (bad) return bad_ids_error(idx);
+  }
   // Single walk: piece capacities from the reference range of each region, one recording walk, then the byte
   // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
   bool single_walk = n > 0 && !idx->opts.force_fallbacks;
@@ -1552,7 +1585,9 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
     hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
-    VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0]));
+    uint64_t bad = 0;
+    VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0], bad_ids, &bad));
+    if (bad) return bad_ids_error(idx);
     VS_TRY(ralloc(r, totals[0], &q.seg_src));
     VS_TRY(ralloc(r, totals[0], &q.seg_len));
     VS_TRY(ralloc(r, totals[0], &q.seg_dst));
@@ -2098,6 +2133,17 @@ void vs_result_free(vs_result* r) {
   delete r;
 }
 
+// ids in host memory are checked before anything is launched (ids in device memory: k_check_sample_ids, inside the batch)
+static int check_host_ids(vs_index* idx, const uint32_t* sample_ids, uint64_t n) {
+  if (!n || is_device_ptr(sample_ids)) return VS_OK;
+  uint32_t top = 0;
+  for (uint64_t i = 0; i < n; ++i) top = sample_ids[i] > top ? sample_ids[i] : top;
+  if (top < idx->g.num_samples) return VS_OK;
+  for (uint64_t i = 0; i < n; ++i)
+    if (sample_ids[i] >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_ids[i], idx->g.num_samples);
+  return VS_OK;
+}
+
 int vs_query_var_in_ref(vs_index* idx, const vs_region* regions, uint64_t n, vs_result** out) {
   if (!idx || !out || (n && !regions)) return fail(VS_ERR_ARG, "null argument");
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
@@ -2163,9 +2209,8 @@ int vs_query_samples_var_in_ref(vs_index* idx, const vs_region* regions, uint64_
                                 vs_result** out) {
   if (!idx || !out || (n && (!regions || !sample_ids))) return fail(VS_ERR_ARG, "null argument");
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
-  for (uint64_t i = 0; i < n; ++i)
-    if (sample_ids[i] >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_ids[i], idx->g.num_samples);
   HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(check_host_ids(idx, sample_ids, n));
   vs_result* r = new vs_result();
   r->idx = idx;
   idx->live_results++;
@@ -2217,8 +2262,8 @@ static int check_sample_batch(vs_index* idx, const vs_region* regions, uint64_t 
                               bool need_index) {
   if (!idx || !out || (n && (!regions || !sample_ids))) return fail(VS_ERR_ARG, "null argument");
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device; queries run on the GPU only");
-  for (uint64_t i = 0; i < n; ++i)
-    if (sample_ids[i] >= idx->g.num_samples) return fail(VS_ERR_UNKNOWN_SAMPLE, "sample id %u out of range (%u samples)", sample_ids[i], idx->g.num_samples);
+  HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(check_host_ids(idx, sample_ids, n));
   if (need_index && !idx->d.has_car_index)
     return fail(VS_ERR_ARG, "this index holds no sample coordinates (built without them); query types 2, 3 and 5 need them");
   return VS_OK;

@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
     if (have) slot = ((w0 + j) << 6) + select_bit(wj, l - excl_j);
     else if (busy && l == total) { have = true; slot = chunk_end; }   // the landing slot behind the round's events
     // ---- this lane's episode ----
-    uint32_t p_off[kSeqEpSteps], p_len[kSeqEpSteps], p_cur[kSeqEpSteps], p_next[kSeqEpSteps];
+    uint32_t p_off[kSeqEpSteps], p_len[kSeqEpSteps], p_next[kSeqEpSteps];   // (type 2: a piece's own position is the one before it's next, the first one's the slot's index)
     uint32_t n_p = 0, ep_end = 0, e_off = 0, e_ridx = 0, k_ridx = 0;
     bool ep_term = false, ep_ovf = false;
     if (have) {
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
         if (next_ref_pos >> 32) { ep_ovf = true; break; }
 #pragma unroll
         for (uint32_t t = 0; t < kSeqEpSteps; ++t)
-          if (t == n_p) { p_off[t] = es.off; p_len[t] = es.len; p_cur[t] = (uint32_t)e_ref; p_next[t] = (uint32_t)next_ref_pos; }
+          if (t == n_p) { p_off[t] = es.off; p_len[t] = es.len; if (MODE == 2) p_next[t] = (uint32_t)next_ref_pos; }
         ++n_p;
         e_ref = next_ref_pos;
         if (nxt == 0) { ep_term = true; break; }
@@ -745,10 +745,11 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
             if (MODE == 2) stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, off_cur, run, (uint64_t)ridx_cur, (uint64_t)k_ridx, x, y);
             else { stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, off_cur, run, pos_l, pos_l + run, x, y); pos_l += run; }
           }
+          uint32_t p_at = k_ridx;
 #pragma unroll
           for (uint32_t t2 = 0; t2 < kSeqEpSteps; ++t2)
             if (stt == 0 && t2 < n_p) {
-              if (MODE == 2) stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, p_off[t2], p_len[t2], (uint64_t)p_cur[t2], (uint64_t)p_next[t2], x, y);
+              if (MODE == 2) { stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, p_off[t2], p_len[t2], (uint64_t)p_at, (uint64_t)p_next[t2], x, y); p_at = p_next[t2]; }
               else { stt = seq_window<2>(r, s_l, seg0, 0, cap, rec_l, p_off[t2], p_len[t2], pos_l, pos_l + p_len[t2], x, y); pos_l += p_len[t2]; }
             }
           if (stt == 0 && ep_term) stt = 1;          // no next vertex: the path iterator is done
@@ -898,6 +899,12 @@ __global__ void __launch_bounds__(256) k_result_totals(DevResult r, unsigned lon
     const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
     if (t) atomicAdd(out + threadIdx.x, t);
   }
+}
+
+// sample ids handed over in device memory are checked here (a host array is checked by the host before anything is launched)
+__global__ void __launch_bounds__(256) k_check_sample_ids(const uint32_t* sids, uint64_t n, uint32_t num_samples, uint64_t* bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && sids[i] >= num_samples) *bad = 1;
 }
 
 // Index::find batched (index.h:119-133)
