@@ -1318,6 +1318,11 @@ static int run_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_res
 // lanes per region of the one-chain walks of query types 2, 3 and 5 (k_sample_walk_sc, k_sample_seq): 1, or kScGroup running the same chain
 template <int MODE>
 static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const uint32_t* dsids, const WalkScratch& ws) {
+  // the recording walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
+  if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc_coop<8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
+    return;
+  }
   if (idx->opts.sc_group > 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, ws);

@@ -214,16 +214,12 @@ __global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) 
 // divergence).  With SUB = 8 the lanes of a group issue the same addresses (one request), a wave diverges 8 ways, and
 // the batch is 12,500 waves: every SIMD holds eight.  Lane 0 of a group writes.
 constexpr uint32_t kScGroup = 8;
-template <int MODE, uint32_t SUB = kScGroup>
-__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+// One region's walk, start to end, by one lane.  MODE as in k_sample_walk (0 count, 1 emit, 2 record once); `lead`: this lane writes.
+template <int MODE>
+__device__ __forceinline__ void sc_walk_region(const DevImage& im, const DevResult& r, const WalkScratch& ws, uint64_t q, uint32_t sid, uint64_t x, uint64_t y,
+                                               bool lead, uint8_t& fl, uint64_t& nvar, uint64_t& ncar, uint64_t& ncar_kept) {
   constexpr bool EMIT = MODE == 1;
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
-  const bool lead = (threadIdx.x % SUB) == 0;
-  if (q >= r.Q) return;
-  const uint32_t sid = sid_per_region[q];
-  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
-  uint8_t fl = 0;
-  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
+  fl = 0; nvar = 0; ncar = 0; ncar_kept = 0;
   uint64_t ref_pos = 0, sample_pos = 0;
   uint32_t closest_v = 0;
   // With the per-sample event and hold rows of query type 4 (+ the break bits of the sequence queries): the backward
@@ -386,6 +382,19 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
       cur = nxt;
     }
   }
+}
+
+template <int MODE, uint32_t SUB = kScGroup>
+__global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+  constexpr bool EMIT = MODE == 1;
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  const bool lead = (threadIdx.x % SUB) == 0;
+  if (q >= r.Q) return;
+  const uint32_t sid = sid_per_region[q];
+  const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
+  uint8_t fl;
+  uint64_t nvar, ncar, ncar_kept;
+  sc_walk_region<MODE>(im, r, ws, q, sid, x, y, lead, fl, nvar, ncar, ncar_kept);
   if (!lead) return;
   if (!EMIT) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
   else { r.var_count[q] = nvar; r.q_ncar[q] = ncar_kept; }
@@ -786,6 +795,230 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
     r.q_nseg[q] = fl ? 0 : s.nseg;
     r.q_nbytes[q] = fl ? 0 : s.nbytes;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Query type 5, cooperative (round 4): the recording walk of get_sample_var_in_sample with SUB lanes per region, built
+// like k_sample_seq_coop -- search and head redundant in the group, the region's events (sample's event row | break row)
+// taken SUB at a time, one episode per lane, hand-over in order.  An episode notes, per literal step, the bases walked
+// before it, and resolves the rows of the vertices that hold the sample (position, REF, ALT: what the one-lane walk
+// writes) without knowing where in the sample's coordinates it is; the hand-over, which knows (the running sample_pos),
+// applies the reference's two tests to each step -- stop at sample_pos >= y, report only beyond x (query.h:520-575) --
+// and writes the rows that pass.  Episodes of more than kScEpSteps steps or kScEpRows rows: one-lane walk (sc_walk_region).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScEpSteps = 6, kScEpRows = 2;
+struct ScSt { uint32_t cur, rbeg, deg, ridx, len, cls, ncar, slot1; };
+struct ScRow { uint32_t pos, cur, ro, rl, ao, al, c, step; };
+// the out-edges of one literal iteration (query.h:530-545): the LAST ref neighbour; get_neighbor_vertex with its record
+__device__ __forceinline__ uint32_t sc_step_edges(const DevImage& im, BitRow& hold, const ScSt& st, uint64_t& next_ref_pos, uint32_t& next_ref_v, ScSt& n) {
+  uint32_t nxt = 0, min_idx = 0xFFFFFFFFu;
+  bool by_sample = false;
+  for (uint32_t e = st.rbeg; e < st.rbeg + st.deg; ++e) {
+    const uint4 a = im.wblob[2 * (uint64_t)e];
+    if (a.y) { next_ref_pos = a.y; next_ref_v = a.x; }
+    if (!by_sample) {
+      const uint4 b = im.wblob[2 * (uint64_t)e + 1];
+      const bool holds = hold.bit_n(a.x, b.w);
+      if (holds || (a.y && min_idx > a.y)) {
+        nxt = a.x; n.cur = a.x; n.rbeg = a.w; n.deg = b.x; n.ridx = a.y; n.len = b.z; n.cls = a.z; n.ncar = b.w; n.slot1 = b.y;
+        if (holds) by_sample = true; else min_idx = a.y;
+      }
+    }
+  }
+  return nxt;
+}
+// the row of a vertex that holds the sample (query.h:547-575), wherever the walk is in the sample's coordinates
+__device__ __forceinline__ bool sc_resolve_row(const DevImage& im, const ScSt& st, uint32_t sid, uint64_t ref_pos, uint64_t next_ref_pos, uint32_t cur_ref_v, ScRow& row) {
+  uint32_t sidx = 0;
+  if (!sample_entry_rec(im, st.cur, st.ridx, im.use_bv ? st.cls : 0u, sid, sidx)) return false;
+  row.cur = st.cur; row.c = st.ncar;
+  if (ref_pos == next_ref_pos) {        // insertion
+    row.pos = (uint32_t)ref_pos; row.ro = 0; row.rl = 0; row.ao = im.v_off[st.cur]; row.al = st.len;
+  } else if (st.ridx) {                 // deletion: ref = sequence of find(ref_pos - 1)
+    const uint32_t fv = im.rp_vid[slot_of_find(im, ref_pos - 1)];
+    row.pos = sidx; row.ro = im.v_off[fv]; row.rl = im.v_len[fv]; row.ao = 0; row.al = 0;
+  } else {                              // substitution: ref = sequence of the previous step's last ref neighbour
+    row.pos = sidx; row.ro = 0; row.rl = 0; row.ao = im.v_off[st.cur]; row.al = st.len;
+    if (cur_ref_v != kNone) { row.ro = im.v_off[cur_ref_v]; row.rl = im.v_len[cur_ref_v]; }
+  }
+  return true;
+}
+
+template <uint32_t SUB>
+__global__ void __launch_bounds__(256) k_sample_walk_sc_coop(DevImage im, DevResult r, const uint32_t* sid_per_region, WalkScratch ws) {
+  static_assert(SUB == 8 || SUB == 16, "group width");
+  constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
+  const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  const bool live = q < r.Q;
+  uint32_t sid = 0;
+  uint64_t x = 0, y = 0, s0 = 0, scap = 0;
+  if (live) { sid = sid_per_region[q]; x = r.regions[2 * q]; y = r.regions[2 * q + 1]; s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0; }
+  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && im.t4_ev_shift == 0;
+  // group-uniform state
+  bool serial = live && !fast, busy = false;
+  uint8_t fl = 0;
+  uint64_t nvar = 0, ncar = 0, ncar_kept = 0;
+  uint64_t pos = 0;                               // sample_pos where the chain stands
+  uint32_t cur_slot = 0, ridx_cur = 0;            // the ref-path node the chain stands on, in step: slot, ref index
+  BitRow ev = sample_event_row(im, sid, fast), hold = sample_hold_row(im, sid, fast);
+  const uint32_t last_slot = (uint32_t)im.P - 1;
+  auto put_row = [&](const ScRow& row, uint64_t& nv, uint64_t& nc) {   // (the lane that calls it writes)
+    if (nv < scap) {
+      const uint64_t s = s0 + nv;
+      ws.pos[s] = row.pos; ws.cur[s] = row.cur; ws.ro[s] = row.ro; ws.rl[s] = row.rl; ws.ao[s] = row.ao; ws.al[s] = row.al;
+    } else *ws.overflow = 1;
+    nv++; nc += pad_car(row.c);
+  };
+  if (fast) {
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t closest_v = 0;
+    if (!rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
+    else {
+      closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
+      if (im.v_ridx[closest_v]) {
+        const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
+        ref_pos = im.v_ridx[closest_v];
+        sample_pos -= seq_len;
+      }
+      // ---- head: literal iterations until the walk is in step with the path (redundant in the group, lane 0 writes) ----
+      const uint4 v0 = im.w_vertex[2 * (uint64_t)closest_v], v1 = im.w_vertex[2 * (uint64_t)closest_v + 1];
+      ScSt st{closest_v, im.blob_row[closest_v], v0.y, v0.z, v1.x, v1.y, v1.z, v1.w};
+      uint32_t cur_ref_v = kNone, steps = 0;
+      while (true) {
+        if (sample_pos >= y) break;
+        if (st.slot1 && ref_pos == st.ridx) { busy = true; cur_slot = st.slot1 - 1; ridx_cur = st.ridx; break; }
+        if (++steps > 64 || (ref_pos >> 32)) { serial = true; break; }
+        uint64_t next_ref_pos = ref_pos + st.len;
+        uint32_t next_ref_v = kNone;
+        ScSt n{};
+        const uint32_t nxt = sc_step_edges(im, hold, st, next_ref_pos, next_ref_v, n);
+        ScRow row{};
+        if (sample_pos > x && hold.bit_n(st.cur, st.ncar) && sc_resolve_row(im, st, sid, ref_pos, next_ref_pos, cur_ref_v, row)) {
+          uint64_t nv = nvar, nc = ncar;
+          if (l == 0) put_row(row, nv, nc);
+          nvar++; ncar += pad_car(row.c);
+        }
+        cur_ref_v = next_ref_v; ref_pos = next_ref_pos; sample_pos += st.len;
+        if (nxt == 0) break;
+        st = n;
+      }
+      pos = sample_pos;
+    }
+  }
+  // ---- episodes, SUB events of a group at a time ----
+  while (__any(busy)) {
+    const uint32_t w0 = cur_slot >> 6, wi = w0 + l;
+    uint64_t word = 0;
+    if (busy && ((uint64_t)wi << 6) < last_slot) {
+      word = ev.row[wi] | im.seq_breaks[wi];
+      if (l == 0) word &= ~0ULL << (cur_slot & 63);
+      if (wi == (last_slot >> 6)) word &= (1ULL << (last_slot & 63)) - 1;
+    }
+    const uint32_t pc = (uint32_t)__popcll(word), incl = group_inclusive_scan<SUB>(l, pc);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)gbase + (int)SUB - 1, 64);
+    uint32_t j = 0;
+#pragma unroll
+    for (int t = 0; t < (int)SUB; ++t) j += (uint32_t)__shfl((int)incl, (int)gbase + t, 64) <= l ? 1u : 0u;
+    const int src = (int)gbase + (int)(j < SUB ? j : SUB - 1);
+    const uint64_t wj = shfl64(word, src);
+    const uint32_t excl_j = (uint32_t)__shfl((int)(incl - pc), src, 64);
+    const uint64_t chunk_end64 = ((uint64_t)(w0 + SUB)) << 6;
+    const uint32_t chunk_end = chunk_end64 < last_slot ? (uint32_t)chunk_end64 : last_slot;
+    bool have = busy && l < total;
+    uint32_t slot = 0;
+    if (have) slot = ((w0 + j) << 6) + select_bit(wj, l - excl_j);
+    else if (busy && l == total) { have = true; slot = chunk_end; }   // the landing slot behind the round's events
+    // ---- this lane's episode ----
+    uint32_t p_cum[kScEpSteps];                     // bases walked before each step
+    ScRow rows[kScEpRows];
+    uint32_t n_s = 0, n_rows = 0, ep_cum = 0, ep_end = 0, e_ridx = 0, k_ridx = 0;
+    bool ep_term = false, ep_ovf = false;
+    if (have) {
+      const uint64_t h = im.blob_of_slot[slot];
+      const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header of the slot
+      ScSt es{rb.w, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, slot + 1};
+      k_ridx = es.ridx;
+      uint64_t e_ref = es.ridx;
+      uint32_t cur_ref_v = es.cur;
+      while (true) {
+        uint64_t next_ref_pos = e_ref + es.len;
+        uint32_t next_ref_v = kNone;
+        ScSt n{};
+        const uint32_t nxt = sc_step_edges(im, hold, es, next_ref_pos, next_ref_v, n);
+        if ((next_ref_pos >> 32) || ((uint64_t)ep_cum + es.len) >> 31) { ep_ovf = true; break; }
+        ScRow row{};
+        if (hold.bit_n(es.cur, es.ncar) && sc_resolve_row(im, es, sid, e_ref, next_ref_pos, cur_ref_v, row)) {
+          row.step = n_s;
+#pragma unroll
+          for (uint32_t t = 0; t < kScEpRows; ++t) if (t == n_rows) rows[t] = row;
+          if (n_rows >= kScEpRows) { ep_ovf = true; break; }
+          ++n_rows;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < kScEpSteps; ++t) if (t == n_s) p_cum[t] = ep_cum;
+        ++n_s;
+        ep_cum += es.len;
+        cur_ref_v = next_ref_v; e_ref = next_ref_pos;
+        if (nxt == 0) { ep_term = true; break; }
+        es = n;
+        if (es.slot1 && e_ref == es.ridx) { ep_end = es.slot1 - 1; e_ridx = es.ridx; break; }
+        if (n_s >= kScEpSteps) { ep_ovf = true; break; }
+      }
+      if (!ep_term && !ep_ovf && ep_end <= slot) ep_ovf = true;   // (a walk that does not advance: one-lane walk)
+    }
+    // ---- the chain of hand-overs ----
+    bool gdone = !busy;
+#pragma unroll 1
+    for (int t = 0; t < (int)SUB; ++t) {
+      const bool cand = !gdone && have && slot >= cur_slot;
+      const uint32_t gb = (uint32_t)((__ballot(cand) >> gbase) & kGroupMask);
+      const int i = gb ? (int)gbase + __builtin_ctz(gb) : (int)gbase;
+      int stt = 0;                                  // 0 on, 1 the walk is over, 3 one-lane walk
+      uint64_t pos_l = pos, nv_l = nvar, nc_l = ncar;
+      if (gb && (int)lane == i) {
+        if (ep_ovf) stt = 3;
+        else {
+          if (slot > cur_slot) {                    // the jump over the uneventful run [cur_slot, slot): the loop's test, then the bases
+            if (pos_l >= y) stt = 1;
+            else pos_l += (uint64_t)k_ridx - ridx_cur;
+          }
+#pragma unroll
+          for (uint32_t t2 = 0; t2 < kScEpSteps; ++t2)
+            if (stt == 0 && t2 < n_s) {
+              const uint64_t sp = pos_l + p_cum[t2];
+              if (sp >= y) stt = 1;
+              else if (sp > x) {
+#pragma unroll
+                for (uint32_t t3 = 0; t3 < kScEpRows; ++t3)
+                  if (t3 < n_rows && rows[t3].step == t2) put_row(rows[t3], nv_l, nc_l);
+              }
+            }
+          if (stt == 0) { pos_l += ep_cum; if (ep_term) stt = 1; }
+        }
+      }
+      const int g_stt = __shfl(stt, i, 64);
+      const uint64_t g_pos = shfl64(pos_l, i), g_nv = shfl64(nv_l, i), g_nc = shfl64(nc_l, i);
+      const uint32_t g_end = (uint32_t)__shfl((int)ep_end, i, 64), g_ridx = (uint32_t)__shfl((int)e_ridx, i, 64);
+      if (!gdone) {
+        if (!gb) gdone = true;
+        else {
+          pos = g_pos; nvar = g_nv; ncar = g_nc;
+          if (g_stt == 0) { cur_slot = g_end; ridx_cur = g_ridx; }
+          else {
+            gdone = true; busy = false;
+            if (g_stt == 3) serial = true;
+          }
+        }
+      }
+      if (!__any(!gdone)) break;
+    }
+  }
+  // ---- regions without event rows, and fallbacks: the one-lane walk (redundant in the group; lane 0 writes) ----
+  if (__any(serial)) {
+    if (serial) sc_walk_region<2>(im, r, ws, q, sid, x, y, l == 0, fl, nvar, ncar, ncar_kept);
+  }
+  if (live && l == 0) { r.q_flags[q] = fl; r.q_g0[q] = 0; r.q_nvar[q] = nvar; r.q_ncar[q] = ncar; }
 }
 
 // Piece capacity of a region for the single walk: twice the ref-path slots plus branch sites of the (for sample
