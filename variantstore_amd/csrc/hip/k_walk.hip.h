@@ -600,56 +600,34 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t word, uint32_t rank) {  
   return (uint32_t)__builtin_ctzll(word);
 }
 
+// ---- get_prev_vertex_with_sample by a group of SUB lanes, kSearchWindow (32) ranks at a time ----
+// The search visits rank, rank - deg(previous(rank)), ... (one count per neighbour of each visited node): a static
+// chain.  The group reads the records of the 32 ranks below the current one together, decides which of them the
+// chain visits (ancestor labels, rk_anc), tests the visited nodes' event bits, and checks the candidates literally in
+// parallel; the first visited node with a neighbour holding the sample is the answer.  Its ref_pos is the node's own
+// last ref neighbour; a node without one (the end of the path) would need the history: `no_ref`, the caller walks serially.
+// (Shared by the cooperative kernels of query types 4, 2, 3 and 5.)
+struct GroupFound {
+  uint32_t v, slot1;     // the vertex found (query.h:57-113) and its ref-path slot + 1
+  WalkVertex wc;         // its record as the edge that names it carries it (off not included)
+  uint64_t ref_pos;      // the found node's last ref neighbour's index; 1 at the head of the path
+  bool head;             // the chain ran out: v is the first node of the path, wc / slot1 are not set
+  bool no_ref;           // found at a node without a ref neighbour: ref_pos would be an earlier iteration's
+};
 template <uint32_t SUB>
-__global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
-                                                          WalkScratch ws) {
-  static_assert(SUB == 8 || SUB == 16, "group width");
+__device__ __forceinline__ GroupFound group_search_prev(const DevImage& im, BitRow& ev, BitRow& hold, bool searching, uint64_t rank0,
+                                                        uint32_t l, uint32_t gbase, uint32_t& n_search) {
   constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
-  const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
-  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
-  const bool live = q < r.Q;
-  WalkCtx cx{0, 0, 0, false, 0, 0};
-  if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
-  cx.use_ev = live && im.t4_events && cx.sid != 0;
-  // group-uniform state: every lane of a group computes / receives the same values
-  uint64_t nvar = 0, ncar = 0, rank0 = 0;
-  uint8_t fl = 0;
-  bool busy = false;         // the group still has episodes to run
-  bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
-  uint32_t cur_slot = 0;     // slot at which the chain is in step
-  uint64_t s0 = 0, scap = 0;
-  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0}, irr{nullptr, kNone, 0};   // the sample's own events; "does v hold the sample"; the global irregular row
-  const uint32_t sh = im.t4_ev_shift;   // > 0: coarse event rows (explicit-id cohorts): the search below, then the one-lane walk from where it ends
-  WalkSt st{};
-  const uint64_t t_c0 = VS_WALK_CLOCK();
-  uint64_t t_c1 = t_c0, t_c2 = t_c0;
-  uint32_t n_chunks = 0, n_search = 0;
-  if (live) {
-    fl = walk_prologue(im, cx, rank0);
-    s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
-    if (!fl) {
-      ev = sample_event_row(im, cx.sid, cx.use_ev);
-      irr = irregular_row(im, cx.use_ev);
-      hold = sample_hold_row(im, cx.sid, cx.use_ev);
-      if (!cx.use_ev) serial = true;
-    }
-  }
-  // ---- get_prev_vertex_with_sample, kSearchWindow (32) ranks at a time ----
-  // The search visits rank, rank - deg(previous(rank)), ... (one count per neighbour of each visited node): a static
-  // chain.  The group reads the records of the 32 ranks below the current one together, decides which of them the
-  // chain visits (ancestor labels, rk_anc), tests the visited nodes' event bits, and checks the candidates literally in
-  // parallel; the first visited node with a neighbour holding the sample is the answer.  Its ref_pos is the node's own
-  // last ref neighbour; a node without one (the end of the path) would need the history: serial loop.
-  bool searching = live && !fl && cx.use_ev;
+  const uint32_t sh = im.t4_ev_shift;
+  GroupFound g{};
   uint64_t rank = rank0;
   const uint32_t tin0 = (searching && rank0 >= 2) ? im.rk_anc[rank0 - 1].x : 0u;   // label of the chain's first rank
   bool hop = false;            // group-uniform: the search has gone over to the event row's set bits
   uint32_t windows = 0, s_top = 0;
   while (__any(searching)) {
     if (searching && rank <= 1) {   // the head of the path (redundant in the group)
-      const uint32_t v = im.rp_vid[im.rk_back[rank == 0 ? 0 : rank - 1].x];
-      st.cur = v; st.wc = blob_vertex(im, v); st.ref_pos = 1; st.cur_ref_v = kNone;
-      st.cur_slot1 = im.w_vertex[2 * (uint64_t)v + 1].w;
+      g.v = im.rp_vid[im.rk_back[rank == 0 ? 0 : rank - 1].x];
+      g.head = true; g.ref_pos = 1;
       searching = false;
     }
     ++n_search;
@@ -733,14 +711,65 @@ __global__ void __launch_bounds__(256) k_sample_walk_coop(DevImage im, DevResult
     g_wc.ncar = (uint32_t)__shfl((int)f_wc.ncar, fl_lane, 64);
     if (searching) {
       if (fb) {
-        if (!g_had_ref) serial = true;   // (ref_pos would be an earlier iteration's: the serial loop knows)
-        st.cur = g_v; st.wc = g_wc; st.ref_pos = g_ref_pos; st.cur_ref_v = kNone; st.cur_slot1 = g_slot1;
+        g.no_ref = !g_had_ref;
+        g.v = g_v; g.wc = g_wc; g.ref_pos = g_ref_pos; g.slot1 = g_slot1;
         searching = false;
       } else if (!hop) {
         rank = rank > kSearchWindow ? rank - kSearchWindow : 0;   // the next window starts right below this one
         if (++windows >= kHopAfter && rank > 1 && im.slot_rank) { hop = true; s_top = im.rk_back[rank - 1].x; }
       } else if (((s_top >> sh) >> 6) >= SUB) s_top = ((((((s_top >> sh) >> 6) - SUB) << 6) | 63u) << sh) | ((1u << sh) - 1u);   // the last slot of the word SUB words down
       else rank = 0;   // nothing left below: the head of the path
+    }
+  }
+  return g;
+}
+
+template <uint32_t SUB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
+                                                          WalkScratch ws) {
+  static_assert(SUB == 8 || SUB == 16, "group width");
+  constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
+  const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
+  const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  const bool live = q < r.Q;
+  WalkCtx cx{0, 0, 0, false, 0, 0};
+  if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
+  cx.use_ev = live && im.t4_events && cx.sid != 0;
+  // group-uniform state: every lane of a group computes / receives the same values
+  uint64_t nvar = 0, ncar = 0, rank0 = 0;
+  uint8_t fl = 0;
+  bool busy = false;         // the group still has episodes to run
+  bool serial = false;       // the group walks its region with the serial loop (no event rows, or a fallback)
+  uint32_t cur_slot = 0;     // slot at which the chain is in step
+  uint64_t s0 = 0, scap = 0;
+  BitRow ev{nullptr, kNone, 0}, hold{nullptr, kNone, 0}, irr{nullptr, kNone, 0};   // the sample's own events; "does v hold the sample"; the global irregular row
+  const uint32_t sh = im.t4_ev_shift;   // > 0: coarse event rows (explicit-id cohorts): the search below, then the one-lane walk from where it ends
+  WalkSt st{};
+  const uint64_t t_c0 = VS_WALK_CLOCK();
+  uint64_t t_c1 = t_c0, t_c2 = t_c0;
+  uint32_t n_chunks = 0, n_search = 0;
+  if (live) {
+    fl = walk_prologue(im, cx, rank0);
+    s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0;
+    if (!fl) {
+      ev = sample_event_row(im, cx.sid, cx.use_ev);
+      irr = irregular_row(im, cx.use_ev);
+      hold = sample_hold_row(im, cx.sid, cx.use_ev);
+      if (!cx.use_ev) serial = true;
+    }
+  }
+  // ---- get_prev_vertex_with_sample, kSearchWindow (32) ranks at a time (group_search_prev) ----
+  {
+    const bool searching = live && !fl && cx.use_ev;
+    const GroupFound g = group_search_prev<SUB>(im, ev, hold, searching, rank0, l, gbase, n_search);
+    if (searching) {
+      if (g.head) {
+        st.cur = g.v; st.wc = blob_vertex(im, g.v); st.ref_pos = 1; st.cur_ref_v = kNone;
+        st.cur_slot1 = im.w_vertex[2 * (uint64_t)g.v + 1].w;
+      } else {
+        if (g.no_ref) serial = true;   // (ref_pos would be an earlier iteration's: the serial loop knows)
+        st.cur = g.v; st.wc = g.wc; st.ref_pos = g.ref_pos; st.cur_ref_v = kNone; st.cur_slot1 = g.slot1;
+      }
     }
   }
   t_c1 = VS_WALK_CLOCK();

@@ -28,10 +28,12 @@
 //                       as used by closest_var (query.h:441-483, type 1) and
 //                       samples_has_var (query.h:792-823, type 7)
 // k_has_var_filter      the (pos, ref, alt) match of samples_has_var (query.h:802-803)
-// k_sample_walk_sc      get_sample_var_in_sample (query.h:490-612, type 5)
+// k_sample_walk_sc      get_sample_var_in_sample (query.h:490-612, type 5), one lane per region;
+// k_sample_walk_sc_coop  eight lanes per region, the sample's events walked as episodes in parallel
 // k_sample_seq          query_sample_from_ref / query_sample_from_sample
 //                       (query.h:118-261, types 2 and 3): the walk emits (offset, length)
-//                       pieces of the sequence pool; k_copy_segments decodes them
+//                       pieces of the sequence pool; k_copy_segments decodes them;
+// k_sample_seq_coop      the cooperative form (window logic of query.h:160-177 / :236-247 at the hand-over)
 // k_find                Index::find batched
 #pragma once
 #include "k_image.hip.h"
