@@ -590,46 +590,6 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, 
   }
 }
 
-// The backward searches of the sample-coordinate queries by a group of SUB lanes (group_search_prev, k_walk.hip.h): one
-// search from x (type 2, query.h:139), or the loop of query.h:213-218 / :507-512 that searches again from the found
-// node's ref_pos while the sample's position there is not yet before x (`REWIND`; the found vertex then pays the
-// look-up of its sample-coordinate index).  `gf`: the last search's answer; `serial`: the group cannot say (a node
-// without a ref neighbour, a search that keeps going) -- the one-lane walk knows; fl: the reference would never return.
-template <uint32_t SUB, bool REWIND>
-__device__ __forceinline__ void group_rewind(const DevImage& im, BitRow& ev, BitRow& hold, bool active, uint64_t x, uint32_t sid, uint32_t l, uint32_t gbase,
-                                             GroupFound& gf, uint64_t& ref_pos, uint64_t& sample_pos, bool& serial, uint8_t& fl) {
-  bool need = active;
-  uint64_t from = x;
-  uint32_t iter = 0, n_search = 0;
-  while (__any(need)) {
-    uint64_t rank0 = 0;
-    if (need) {   // find(pos, rank), index.h:135-148
-      if (from >= im.ref_length) rank0 = im.R - 1;
-      else { const uint32_t k = rank1(im, from); rank0 = k == 0 ? 0 : k - 1; }
-    }
-    const GroupFound g = group_search_prev<SUB>(im, ev, hold, need, rank0, l, gbase, n_search);
-    if (need) {
-      if (g.no_ref) { serial = true; need = false; }
-      else {
-        uint64_t sp = 0;
-        if (g.head) sp = im.v_ridx[g.v];
-        else if (REWIND) {
-          uint32_t idx = 0;
-          (void)sample_entry_rec(im, g.v, g.wc.ridx, im.use_bv ? g.wc.cls : 0u, sid, idx);
-          sp = idx;
-        }
-        if (iter > 0 && g.ref_pos == ref_pos && sp == sample_pos && g.v == gf.v) { fl = kRegionEndless; need = false; }   // (query.h:213-218 would loop forever)
-        else {
-          gf = g; ref_pos = g.ref_pos; sample_pos = sp;
-          if (!REWIND || !(sample_pos >= x && g.v > 0)) need = false;
-          else if (++iter > 32) { serial = true; need = false; }
-          else from = ref_pos;
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Query types 2 and 3, cooperative (round 4): SUB lanes per region.
 // One lane per region walks a chain of ~90 dependent look-ups (a sample has ~11 events in a 10 kb region of the chr1
@@ -696,18 +656,19 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
   uint32_t cur_slot = 0, off_cur = 0, ridx_cur = 0;   // the ref-path node the chain stands on: slot, sequence offset, ref index
   BitRow ev = sample_event_row(im, sid, fast), hold = sample_hold_row(im, sid, fast);
   const uint32_t last_slot = (uint32_t)im.P - 1;
-  // ---- the backward search(es), by the group ----
-  uint64_t ref_pos = 0, sample_pos = 0;
-  GroupFound gf{};
-  group_rewind<SUB, MODE != 2>(im, ev, hold, fast, x, sid, l, gbase, gf, ref_pos, sample_pos, serial, fl);
-  if (fast && !serial && !fl) {
-    {
+  // (the backward searches run redundantly in the group -- one-lane code, same addresses.  The group-parallel window search
+  //  of the type-4 kernel, group_search_prev, was tried here: the same kernel times.)
+  if (fast) {
+    uint64_t ref_pos = 0, sample_pos = 0;
+    uint32_t cur = 0;
+    bool ok = true;
+    if (MODE == 2) cur = prev_vertex_with_sample_ev<false>(im, x, sid, ev, hold, ref_pos, sample_pos);
+    else ok = rewind_to_sample_pos_ev(im, x, sid, ev, hold, cur, ref_pos, sample_pos);
+    if (!ok) fl = kRegionEndless;
+    else {
       // ---- head: literal iterations from the start vertex until the walk stands on the path (redundant in the group, lane 0 writes) ----
-      SeqSt st{gf.v, gf.wc.row_begin, gf.wc.deg, gf.wc.ridx, 0u, gf.wc.len, gf.slot1};
-      if (gf.head) {   // the first node of the path: its record from the vertex table
-        const uint4 v0 = im.w_vertex[2 * (uint64_t)gf.v], v1 = im.w_vertex[2 * (uint64_t)gf.v + 1];
-        st = SeqSt{gf.v, im.blob_row[gf.v], v0.y, v0.z, v0.w, v1.x, v1.w};
-      } else st.off = im.v_off[gf.v];
+      const uint4 v0 = im.w_vertex[2 * (uint64_t)cur], v1 = im.w_vertex[2 * (uint64_t)cur + 1];
+      SeqSt st{cur, im.blob_row[cur], v0.y, v0.z, v0.w, v1.x, v1.w};
       uint32_t steps = 0;
       while (true) {
         if (st.slot1 && (MODE != 2 || ref_pos == st.ridx)) { busy = true; cur_slot = st.slot1 - 1; off_cur = st.off; ridx_cur = st.ridx; break; }
@@ -911,13 +872,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     } else *ws.overflow = 1;
     nv++; nc += pad_car(row.c);
   };
-  // ---- the backward searches of query.h:507-512, by the group ----
-  uint64_t ref_pos = 0, sample_pos = 0;
-  GroupFound gf{};
-  group_rewind<SUB, true>(im, ev, hold, fast, x, sid, l, gbase, gf, ref_pos, sample_pos, serial, fl);
-  if (fast && !serial && !fl) {
+  if (fast) {
+    uint64_t ref_pos = 0, sample_pos = 0;
     uint32_t closest_v = 0;
-    {
+    if (!rewind_to_sample_pos_ev(im, x, sid, ev, hold, closest_v, ref_pos, sample_pos)) fl = kRegionEndless;
+    else {
       closest_v = im.rp_vid[slot_of_find(im, ref_pos)];
       if (im.v_ridx[closest_v]) {
         const uint64_t seq_len = ref_pos - im.v_ridx[closest_v];
