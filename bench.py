@@ -470,11 +470,13 @@ def main():
     else:
         fill_ms *= args.steps / fill_steps
     # phase times of the pipeline (plan, rows, expansion) by the handle's events, from three batches outside the timed region
+    alone_ms = 0.0
     for _i in range(3):
         r3, _g = step()
-        t = vs.last_timing()
+        t = vs.last_timing()      # (waits for the batch: these three run one at a time, nothing beside their kernels)
         tot_ms += t.ms_total * args.steps / 3
         emit_ms += t.ms_emit * args.steps / 3
+        alone_ms += t.ms_fill / 3
         r3.close()
     fence()
     vs.set_option("async_fill", 0)
@@ -865,6 +867,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": fill_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                          "avg_launch_ms": fill_ms / args.steps,
+                         # In the timed loop the expansion of batch k runs beside the plan of batch k + 1 (its own stream: DESIGN.md 5e)
+                         # and shares the memory system with the plan's ~0.14 GB of scattered lines: `frac` is the figure of the
+                         # timed region, as the contract asks.  The same kernel with nothing beside it (three batches after the
+                         # timed region, each waited for): its duration and the fraction that gives.
+                         "avg_launch_ms_alone": alone_ms if alone_ms > 0 else None,
+                         "frac_alone": (achieved * (fill_ms / args.steps) / alone_ms / HBM_PEAK_GBPS) if alone_ms > 0 else None,
                          # the counters as they come (FETCH_SIZE + WRITE_SIZE) beside the corrected figure (2 x FETCH_SIZE + WRITE_SIZE).
                          # profiles/r04_fetch_calibration.txt: FETCH_SIZE counts 64 B per request on gfx950 for every access width
                          # tried (16 B ... 320 B segments, coalesced streams) while the request RATE tops out at the same ~45 G/s

