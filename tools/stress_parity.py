@@ -179,7 +179,8 @@ for c in range(n_cohorts):
         r1.close()
         # ---- types 2, 3 and 5 (sample coordinates) ----
         sc_regions = regions[:50]
-        for smp in ("ref", sample):
+        for form, smp in ((2, "ref"), (2, sample), (1, sample)):   # cooperative kernels (default), then the one-lane walks
+            vs.set_option("t4_walk", form)
             for coords in (False, True):
                 rs = vs.query_sample_seq(sc_regions, smp, sample_coordinates=coords)
                 fl, seqs = rs.sequences()
@@ -200,6 +201,29 @@ for c in range(n_cohorts):
                     bad += 1
                     print(f"MISMATCH t5 cohort {seed} sample {smp} region {x}:{y}")
             r5.close()
+        vs.set_option("t4_walk", 2)
+        # one sample per region through the cooperative kernels (the groups of a wave then run different samples' rows)
+        per_sc = [names[int(i)] for i in rng.integers(0, len(names), size=len(sc_regions))]
+        for coords in (False, True):
+            rs = vs.query_sample_seq(sc_regions, per_sc, sample_coordinates=coords)
+            fl, seqs = rs.sequences()
+            for q, (x, y) in enumerate(sc_regions):
+                n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(x, y, per_sc[q])
+                checked += 1
+                okq = (bool(fl[q] & 8) if n == -1 else bool(fl[q] & 2) if n == -3 else (not fl[q] and seqs[q] == seq))
+                if not okq:
+                    bad += 1
+                    print(f"MISMATCH t{3 if coords else 2} (per-region samples) cohort {seed} sample {per_sc[q]} region {x}:{y} code {n} flags {fl[q]}")
+            rs.close()
+        r5 = vs.get_sample_var_in_sample(sc_regions, per_sc)
+        f5 = r5.view(False)["region_flags"]
+        for q, (x, y) in enumerate(sc_regions):
+            n, text = orc.get_sample_var_in_sample(x, y, per_sc[q])
+            checked += 1
+            if (n == -1) != bool(f5[q] & 8) or (n >= 0 and r5.region_text(q) != text):
+                bad += 1
+                print(f"MISMATCH t5 (per-region samples) cohort {seed} sample {per_sc[q]} region {x}:{y}")
+        r5.close()
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
