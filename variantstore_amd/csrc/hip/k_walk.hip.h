@@ -682,20 +682,39 @@ __device__ __forceinline__ GroupFound group_search_prev(const DevImage& im, BitR
       const int64_t wi = (int64_t)(c_top >> 6) - (int64_t)l;
       uint64_t word = wi >= 0 ? ev.row[wi] : 0ULL;
       if (l == 0 && (c_top & 63) != 63) word &= (1ULL << ((c_top & 63) + 1)) - 1;   // nothing above s_top's block
-      while (word && !found) {
-        const uint32_t b = 63u - (uint32_t)__builtin_clzll(word);
-        word &= ~(1ULL << b);
-        const uint32_t c = (uint32_t)wi * 64u + b;
-        for (uint32_t j = 1u << sh; j-- > 0 && !found;) {
-          const uint32_t k = (c << sh) + j;
-          if (k > s_top || k >= im.P) continue;
-          const uint32_t r = im.slot_rank[k];               // chain rank r + 1 looks at the first slot of rank r
-          if (r < 1) continue;                              // (the chain stops at rank <= 1 before it would look there)
-          const uint2 bk = im.rk_back[r];
-          if (bk.x != k) continue;
-          const uint2 an = im.rk_anc[r];
-          if (!(an.x <= tin0 && tin0 - an.x < an.y)) continue;
-          check_node(k, bk.y);
+      // is slot k a node the chain looks at (first slot of its rank, rank on the chain)?  Then its literal test.
+      auto try_slot = [&](uint32_t k) {
+        if (k > s_top || k >= im.P) return;
+        const uint32_t r = im.slot_rank[k];                 // chain rank r + 1 looks at the first slot of rank r
+        if (r < 1) return;                                  // (the chain stops at rank <= 1 before it would look there)
+        const uint2 bk = im.rk_back[r];
+        if (bk.x != k) return;
+        const uint2 an = im.rk_anc[r];
+        if (!(an.x <= tin0 && tin0 - an.x < an.y)) return;
+        check_node(k, bk.y);
+      };
+      if (sh > 0 && (1u << sh) <= SUB) {
+        // Coarse rows: the group takes the set bits of its SUB words one at a time, highest block first, and tests the
+        // block's 2^sh slots TOGETHER, a slot per lane (lane 0 the highest: the first lane that finds is the answer).
+        // (One lane per word working through its blocks slot by slot was up to 2^sh serial tests of ~5 dependent look-ups
+        //  per set bit: on the 10,000-sample cohort that was most of the search.)
+        while (true) {
+          const uint32_t wb = (uint32_t)((__ballot(word != 0) >> gbase) & kGroupMask);
+          if (!wb) break;
+          const int i0 = (int)gbase + __builtin_ctz(wb);
+          const uint64_t w0 = shfl64(word, i0);
+          const uint32_t b = 63u - (uint32_t)__builtin_clzll(w0);
+          if ((int)(threadIdx.x & 63) == i0) word &= ~(1ULL << b);
+          const uint32_t c = (uint32_t)((int64_t)(c_top >> 6) - (int64_t)(i0 - (int)gbase)) * 64u + b;
+          if (l < (1u << sh)) try_slot((c << sh) + ((1u << sh) - 1u - l));
+          if ((__ballot(found) >> gbase) & kGroupMask) break;
+        }
+      } else {
+        while (word && !found) {
+          const uint32_t b = 63u - (uint32_t)__builtin_clzll(word);
+          word &= ~(1ULL << b);
+          const uint32_t c = (uint32_t)wi * 64u + b;
+          for (uint32_t j = 1u << sh; j-- > 0 && !found;) try_slot((c << sh) + j);
         }
       }
     }
