@@ -312,7 +312,7 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
   }
 }
 template <bool RESIDENT>
-__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+__global__ void __launch_bounds__(kPlanBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
                                                          RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                                          PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
   plan_apply<RESIDENT>(im, r, e_prev, tile_sums, ntiles, items, runs, coarse, slow_list, totals_host, status, seq, resident_entries);
