@@ -101,6 +101,8 @@ typedef struct {
   uint64_t t4_rows_bytes;    /* of device_bytes: the per-sample event and hold rows of query type 4 (O(samples x ref-path slots):
                               * taken when they fit half of the free HBM and 176 GB -- VS_T4_ROWS_MAX_GB in the environment
                               * lowers the cap; 0: not built, the walks then visit every vertex) */
+  uint64_t pool_mallocs;     /* hipMalloc / hipFree calls the handle's pool of batch buffers has made since it was opened: a loop */
+  uint64_t pool_frees;       /* of like batches makes none once it is warm (hipFree waits for the whole device)                  */
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);
 /* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */

@@ -92,6 +92,7 @@ struct vs_index {
   std::vector<void*> image_allocs;
   uint64_t device_bytes = 0;
   uint64_t t4_rows_bytes = 0;   // of which: the per-sample event and hold rows of query type 4
+  uint64_t pool_mallocs = 0, pool_frees = 0;   // hipMalloc / hipFree calls of the batch-buffer pool (vs_index_info)
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
   std::vector<DevBuf> pool;
@@ -216,10 +217,11 @@ static int dev_alloc(vs_index* idx, size_t bytes, void** out, std::vector<DevBuf
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
+  idx->pool_mallocs++;
   if (e != hipSuccess) {
     // release the pool and retry once
     (void)server_stop(idx);
-    for (auto& b : idx->pool) (void)hipFree(b.p);
+    for (auto& b : idx->pool) { (void)hipFree(b.p); idx->pool_frees++; }
     idx->pool.clear();
     e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(VS_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -296,6 +298,7 @@ static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs) {
     for (size_t i = 1; i < idx->pool.size(); ++i)
       if (idx->pool[i].cap < idx->pool[k].cap) k = i;
     (void)hipFree(idx->pool[k].p);
+    idx->pool_frees++;
     idx->pool.erase(idx->pool.begin() + k);
   }
 }
@@ -2036,6 +2039,8 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   info->list_max = idx->im.use_bit_vector ? idx->im.list_max : 0;
   info->reserved_ = 0;
   info->t4_rows_bytes = idx->t4_rows_bytes;
+  info->pool_mallocs = idx->pool_mallocs;
+  info->pool_frees = idx->pool_frees;
   return VS_OK;
 }
 
