@@ -32,9 +32,19 @@ __device__ __forceinline__ bool sample_entry_rec(const DevImage& im, uint32_t v,
     index = im.car_index[im.v_car_begin[v] + rank];
     return true;
   }
+  // (explicit ids: the FIRST record with the sample's id, eight records per round trip -- see BitRow::holds_explicit)
   const uint64_t b = im.v_car_begin[v];
-  for (uint32_t i = 0; i < im.v_ncar[v]; ++i)
-    if (im.car_sid[b + i] == sid) { index = im.car_index[b + i]; return true; }
+  const uint32_t n = im.v_ncar[v];
+  for (uint32_t k = 0; k < n; k += 8) {
+    uint4 p, q;
+    __builtin_memcpy(&p, im.car_sid + b + k, 16);
+    __builtin_memcpy(&q, im.car_sid + b + k + 4, 16);
+    const uint32_t m = n - k;
+    const uint32_t hits = (uint32_t)(p.x == sid) | ((uint32_t)(p.y == sid && m > 1) << 1) | ((uint32_t)(p.z == sid && m > 2) << 2) |
+                          ((uint32_t)(p.w == sid && m > 3) << 3) | ((uint32_t)(q.x == sid && m > 4) << 4) | ((uint32_t)(q.y == sid && m > 5) << 5) |
+                          ((uint32_t)(q.z == sid && m > 6) << 6) | ((uint32_t)(q.w == sid && m > 7) << 7);
+    if (hits) { index = im.car_index[b + k + (uint32_t)__builtin_ctz(hits)]; return true; }
+  }
   return false;
 }
 __device__ __forceinline__ bool sample_entry(const DevImage& im, uint32_t v, uint32_t sid, uint32_t& index) {

@@ -218,12 +218,22 @@ struct BitRow {
     if (x_sid) return holds_explicit(i, ncar);
     return (at(i >> 6) >> (i & 63)) & 1;
   }
+  // (eight ids per round trip, two 16-byte loads -- a list holds ~8: an id at a time with an early exit was up to nine
+  //  DEPENDENT look-ups per neighbour, most of a walk's chain on the 10,000-sample cohort.  Ids behind the list's end are the
+  //  next vertex's or the pool's slack, as in the expansion's group loads: masked by the count.)
   __device__ __forceinline__ bool holds_explicit(uint32_t i, uint32_t n) const {
     if (!n) return false;
     const uint64_t b0 = x_begin[i];
-    for (uint32_t k = 0; k < n; ++k)
-      if (x_sid[b0 + k] == x_id) return true;
-    return false;
+    bool hit = false;
+    for (uint32_t k = 0; k < n && !hit; k += 8) {
+      uint4 a, b;
+      __builtin_memcpy(&a, x_sid + b0 + k, 16);
+      __builtin_memcpy(&b, x_sid + b0 + k + 4, 16);
+      const uint32_t m = n - k;
+      hit = (a.x == x_id) | (a.y == x_id && m > 1) | (a.z == x_id && m > 2) | (a.w == x_id && m > 3) |
+            (b.x == x_id && m > 4) | (b.y == x_id && m > 5) | (b.z == x_id && m > 6) | (b.w == x_id && m > 7);
+    }
+    return hit;
   }
   // first index >= m whose bit is set, or `limit` when there is none below it (m < limit); a coarse row answers with m
   // itself when m's block is set, else with the first index of the next set block
