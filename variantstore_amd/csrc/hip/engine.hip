@@ -1402,7 +1402,10 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
 #endif
     if (walk_mode == 5) launch_walk_sc<2>(idx, d, n, dsids, ws);
     else if (dwalk.t4_events && idx->opts.t4_walk == 2)   // 8 lanes per region: the episodes of a region run in parallel
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
+    {
+      if (dwalk.t4_hold) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, false>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, true>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);   // explicit ids
+    }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;

@@ -267,7 +267,7 @@ __device__ __forceinline__ void sc_walk_region(const DevImage& im, const DevResu
         //  advances by lengths alone.  What else could break a run -- the smallest-index ref neighbour is not the successor, ref
         //  indexes that do not continue -- is in the break bits.)
         uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
-        if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
+        if (k > s0) { const uint32_t kb = brk.next_wide(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];
           const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header of slot k
@@ -503,7 +503,7 @@ __device__ __forceinline__ uint8_t seq_walk_region(const DevImage& im, const Dev
         // (the sample's OWN events: an irregular slot -- its LAST ref neighbour is not its successor -- is nothing to a sequence
         //  walk, which follows the FIRST ref neighbour and the smallest-index one; what could break a run here is in the break bits)
         uint32_t k = s0 < lim ? ev.next(s0, lim) : s0;
-        if (k > s0) { const uint32_t kb = brk.next(s0, lim); k = kb < k ? kb : k; }
+        if (k > s0) { const uint32_t kb = brk.next_wide(s0, lim); k = kb < k ? kb : k; }
         if (k > s0) {
           const uint64_t h = im.blob_of_slot[k];
           const uint4 ra = im.wblob[2 * h], rb = im.wblob[2 * h + 1];   // header of slot k

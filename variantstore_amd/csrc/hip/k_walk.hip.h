@@ -251,6 +251,34 @@ struct BitRow {
     const uint32_t k = c == cm ? m : c << sh;
     return k < limit ? k : limit;
   }
+  // The same for rows that are mostly clear over long ranges -- the break row over the 1024 slots a sequence walk looks
+  // ahead, on a cohort whose samples have an event every few thousand slots: eight words per round trip instead of one
+  // DEPENDENT load per 64 slots (16 in a row per jump: a third of such a walk's chain).  Costs sixteen registers: not for
+  // the kernels that are short of them.
+  __device__ __forceinline__ uint32_t next_wide(uint32_t m, uint32_t limit) {
+    const uint32_t cm = m >> sh, c_end = ((limit - 1) >> sh) + 1;
+    uint32_t wi = cm >> 6;
+    const uint32_t w_end = (c_end + 63) >> 6;
+    uint64_t x = at(wi) & (~0ULL << (cm & 63));
+    while (!x) {
+      if (++wi >= w_end) return limit;
+      uint64_t q[8];
+#pragma unroll
+      for (uint32_t t = 0; t < 8; ++t) q[t] = wi + t < w_end ? row[wi + t] : 0ULL;
+      uint32_t hit = 8;
+#pragma unroll
+      for (uint32_t t = 8; t-- > 0;) if (q[t]) hit = t;
+      if (hit == 8) { wi += 7; continue; }
+#pragma unroll
+      for (uint32_t t = 0; t < 8; ++t) if (t == hit) x = q[t];
+      wi += hit;
+      w = wi; word = x;
+    }
+    const uint32_t c = (wi << 6) + (uint32_t)__builtin_ctzll(x);
+    if (c >= c_end) return limit;
+    const uint32_t k = c == cm ? m : c << sh;
+    return k < limit ? k : limit;
+  }
 };
 // the rows of one sample (NULL rows: the index has none, or the walk does not use them)
 __device__ __forceinline__ BitRow sample_event_row(const DevImage& im, uint32_t sid, bool use) {
@@ -279,10 +307,11 @@ typedef BitRow EventRow;
 struct WalkCtx { uint32_t sid; uint64_t x, y; bool use_ev; uint32_t limit; uint32_t irr_from; };   // irr_from: irregular slots count as events from here on (walk_prologue)
 // The next slot >= m (m < cx.limit) at which the type-4 walk must step literally: the sample's next event, or an irregular slot
 // once the stop slot is within reach (walk_prologue: irr_from); cx.limit when neither comes first.
+template <bool WIDE = false>   // WIDE: rows that are clear over long ranges (explicit-id cohorts): BitRow::next_wide
 __device__ __forceinline__ uint32_t next_walk_event(BitRow& ev, BitRow& irr, const WalkCtx& cx, uint32_t m) {
-  uint32_t k = ev.next(m, cx.limit);
+  uint32_t k = WIDE ? ev.next_wide(m, cx.limit) : ev.next(m, cx.limit);
   const uint32_t m2 = m > cx.irr_from ? m : cx.irr_from;
-  if (m2 < k) k = irr.next(m2, k);     // (k itself when no irregular slot lies before it)
+  if (m2 < k) k = WIDE ? irr.next_wide(m2, k) : irr.next(m2, k);     // (k itself when no irregular slot lies before it)
   return k;
 }
 struct WalkSt { uint32_t cur; WalkVertex wc; uint64_t ref_pos; uint32_t cur_ref_v, cur_slot1; };   // cur_slot1: ref-path slot + 1 of cur, 0 = off the path
@@ -487,7 +516,7 @@ __device__ __forceinline__ uint8_t walk_prologue(const DevImage& im, WalkCtx& cx
 
 // The serial walk of one region: the reference's loop, with jumps over uneventful runs in BLOB mode.  `sink(em)` takes
 // each reported vertex.
-template <bool BLOB, typename Sink>
+template <bool BLOB, bool WIDE = false, typename Sink>
 __device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& cx, BitRow& ev, BitRow& irr, BitRow& hold, WalkSt& st, Sink&& sink,
                                             uint32_t& st_jumps, uint32_t& st_steps) {
   bool done = false;
@@ -498,7 +527,7 @@ __device__ __forceinline__ void walk_serial(const DevImage& im, const WalkCtx& c
       // would take the default step node by node -- no neighbour holds the sample (next = path successor), the
       // node itself does not (nothing emitted), every node is regular (ref_pos and cur_ref follow the path) -- and
       // stop at `limit` if that comes first.
-      const uint32_t k = next_walk_event(ev, irr, cx, st.cur_slot1 - 1);
+      const uint32_t k = next_walk_event<WIDE>(ev, irr, cx, st.cur_slot1 - 1);
       if (k != st.cur_slot1 - 1) {
         if (k >= cx.limit) break;
         walk_arrive_at_slot(im, st, k);
@@ -753,7 +782,10 @@ __device__ __forceinline__ GroupFound group_search_prev(const DevImage& im, BitR
   return g;
 }
 
-template <uint32_t SUB>
+// EXPL: the cohort keeps explicit sample ids (coarse event rows, hold tests from the carrier lists).  The class-row
+// instantiation carries none of that code -- at the 128 registers this kernel is held to, the eight ids a hold test reads
+// at a time cost it 40 bytes of scratch per lane and 12 % of its time on the chr1 cohort, which never runs them.
+template <uint32_t SUB, bool EXPL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                           WalkScratch ws) {
   static_assert(SUB == 8 || SUB == 16, "group width");
@@ -784,6 +816,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
       ev = sample_event_row(im, cx.sid, cx.use_ev);
       irr = irregular_row(im, cx.use_ev);
       hold = sample_hold_row(im, cx.sid, cx.use_ev);
+      if (!EXPL) hold.x_sid = nullptr;     // (class-row cohorts: the hold row answers)
       if (!cx.use_ev) serial = true;
     }
   }
@@ -815,7 +848,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
       } else if (l == 0) *ws.overflow = 1;
       nvar++; ncar += pad_car(e1.c);
     };
-    walk_serial<true>(im, cx, ev, irr, hold, st, sink, jm, sp);
+    walk_serial<true, EXPL>(im, cx, ev, irr, hold, st, sink, jm, sp);
     walked = true;
   }
   if (live && !fl && cx.use_ev && !serial && !walked) {
@@ -935,7 +968,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         } else if (l == 0) *ws.overflow = 1;
         nvar++; ncar += pad_car(e1.c);
       };
-      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true>(im, cx, ev, irr, hold, st, sink, jm, sp); }
+      if (cx.use_ev) { walk_start_search<true>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<true, EXPL>(im, cx, ev, irr, hold, st, sink, jm, sp); }
       else { walk_start_search<false>(im, cx, ev, hold, rank0, st, it, lit); walk_serial<false>(im, cx, ev, irr, hold, st, sink, jm, sp); }
     }
   }
