@@ -140,6 +140,23 @@ def test_handle_options_are_checked():
     vs.close()
 
 
+def test_device_arrays_are_checked_on_the_host_side():
+    """DeviceArray (regions / sample ids already in HBM): one id per region is asked for before anything reaches the
+    library, and a handle without a device refuses the query like any other."""
+    from variantstore_amd import DeviceArray, VariantStore
+    from variantstore_amd.api import VariantStoreError
+    vs = VariantStore.synthetic(device=-1, ref_length=20_000, num_variants=50, num_samples=4, seed=3, first_pos=10)
+    regions, ids = DeviceArray(0x1000, 5), DeviceArray(0x2000, 3)
+    for call in (lambda: vs.get_sample_var_in_ref(regions, ids), lambda: vs.query_sample_seq(regions, ids),
+                 lambda: vs.get_sample_var_in_sample(regions, ids)):
+        with pytest.raises(ValueError):
+            call()
+    with pytest.raises(VariantStoreError) as e:       # (the addresses are never touched: no device, no query)
+        vs.get_sample_var_in_ref(regions, DeviceArray(0x2000, 5))
+    assert e.value.code == -3                          # VS_ERR_NO_DEVICE
+    vs.close()
+
+
 def test_image_labels_against_brute_force(golden_dir, tmp_path):
     """device_image.hpp's static structures for the walking query types -- ancestor labels of the backward search's
     chains (rk_anc), slot -> rank table, break bits of the sequence queries -- against brute force, on a synthetic cohort
