@@ -74,6 +74,9 @@ struct EngineOpts {
   bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
   bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
   uint32_t fill_chunk = 0;      // rows per task of the expansion: 0 = by the batch's shape, else 8 / 16 / 32 / 64
+  int fill_mode = 0;            // shared expansion: 0 one task per wave, 1 resident waves pulling tasks, 2 split (lists + rows, then the dense sites)
+  uint32_t fill_dense_k = 16;   // dense sites per wave of k_fill_dense: 8 / 16 / 32 / 64
+  uint32_t fill_waves = 8;      // fill_mode 1: resident waves per SIMD the grid is sized for
   bool fill_stats = false;      // device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
   int sc_group = 1;             // lanes per region of the walks of query types 2 / 3 / 5: 1, or 8 lanes running the same chain
   bool walk_stats = false;      // iteration counts and device-clock ticks of k_sample_walk
@@ -468,15 +471,24 @@ static int build_device_image(vs_index* idx) {
     idx->h_carpre.resize(G + 1);
     HIP_TRY(hipMemcpyAsync(idx->h_carpre.data(), d.s_carpre, (G + 1) * 8, hipMemcpyDeviceToHost, idx->stream));
   }
-  std::vector<uint32_t> h_dup(G), h_fl(G);
+  std::vector<uint32_t> h_dup(G), h_fl(G), h_ncar(G);
   if (G) {
     hipLaunchKernelGGL(k_mark_dups, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, idx->stream, d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_dup.data(), d.s_dup_prev, G * 4, hipMemcpyDeviceToHost, idx->stream));
     HIP_TRY(hipMemcpyAsync(h_fl.data(), d.s_flags, G * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipMemcpyAsync(h_ncar.data(), d.s_ncar, G * 4, hipMemcpyDeviceToHost, idx->stream));
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   scratch.release();
+  {  // the dense sites (k_fill_dense)
+    std::vector<uint32_t> dense;
+    if (d.use_bv)
+      for (uint64_t g = 0; g < G; ++g)
+        if (h_ncar[g] > d.list_max) dense.push_back((uint32_t)g);
+    d.n_dense = dense.size();
+    VS_TRY(upload_image(idx, dense, &d.dense_site));
+  }
   std::vector<uint32_t> sus_g, sus_prev;
   for (uint64_t g = 0; g < G; ++g) {
     if (h_fl[g] & kSiteAlwaysDrop) { sus_g.push_back((uint32_t)g); sus_prev.push_back(kNone); }
@@ -561,6 +573,7 @@ static void read_env_opts(vs_index* idx) {
   if (getenv("VS_SYNC_SUBMIT")) o.async_submit = false;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
+  if (const char* fm = getenv("VS_FILL_MODE")) o.fill_mode = std::max(0, std::min(2, atoi(fm)));
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 #ifdef VS_TUNING
   o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
@@ -852,11 +865,41 @@ static int read_device_words(vs_index* idx, const uint64_t* a, uint64_t* va, con
   return VS_OK;
 }
 
-// The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).
+// The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).  mode 0: one task per wave; 1: resident
+// waves pulling tasks from `counters` (zeroed by the caller); 2: split -- rows + listed variants here, the dense sites of the
+// index the batch covers in k_fill_dense behind it.
 template <bool WIDE, bool TUNE>
 static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, const uint32_t* coarse, uint64_t n_runs, uint64_t U, uint32_t chunk,
-                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
+                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, int mode, uint32_t* counters) {
   const unsigned blocks = (unsigned)(((U + chunk - 1) / chunk + 3) / 4);
+  if (mode == 1) {
+    const unsigned rb = std::min<unsigned>(blocks, 256u * idx->opts.fill_waves);
+    switch (chunk) {
+      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 16, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
+      case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 64, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 32, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
+    }
+    return;
+  }
+  if (mode == 2) {
+    switch (chunk) {
+      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+      case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+    }
+    const uint64_t nd = idx->d.n_dense;
+    if (nd) {
+      const uint32_t k = idx->opts.fill_dense_k;
+      const unsigned db = (unsigned)(((nd + k - 1) / k + 3) / 4);
+      switch (k) {
+        case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_dense<WIDE, 8>), dim3(db), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, n_runs, U, gt_words); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_dense<WIDE, 32>), dim3(db), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, n_runs, U, gt_words); break;
+        case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_dense<WIDE, 64>), dim3(db), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, n_runs, U, gt_words); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_dense<WIDE, 16>), dim3(db), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, n_runs, U, gt_words); break;
+      }
+    }
+    return;
+  }
   switch (chunk) {
     case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
     case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
@@ -1070,10 +1113,16 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
       HIP_TRY(hipMemsetAsync(tstat, 0, ((U + chunk - 1) / chunk + 4) * 16, idx->stream));
     }
 #endif
+    const int mode = idx->opts.fill_mode;
+    uint32_t* counters = nullptr;
+    if (mode == 1) {
+      VS_TRY(dev_alloc(idx, kTaskShards * kTaskShardStride * 4, (void**)&counters, &scratch.bufs));
+      HIP_TRY(hipMemsetAsync(counters, 0, kTaskShards * kTaskShardStride * 4, idx->stream));
+    }
     VS_TRY(result_events(r));   // the kernel's own duration, whenever the result is asked for it (vs_result_fill_ms)
     HIP_TRY(hipEventRecord(r->ev_fill[0], idx->stream));
-    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
-    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat);
+    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, counters);
+    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(r->ev_fill[1], idx->stream));
     r->pending = true;
@@ -2102,17 +2151,20 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value < 0 || value > 2) return fail(VS_ERR_ARG, "t4_walk takes 0 (literal), 1 (one lane per region, jumping) or 2 (cooperative, default)");
     o.t4_walk = (int)value;
   } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
-  else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
+  else if (k == "fill_mode") { if (value < 0 || value > 2) return fail(VS_ERR_ARG, "fill_mode takes 0, 1 or 2"); o.fill_mode = (int)value; }
+  else if (k == "fill_dense_k") { if (value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_dense_k takes 8, 16, 32 or 64"); o.fill_dense_k = (uint32_t)value; }
+  else if (k == "fill_waves") { if (value < 1 || value > 8) return fail(VS_ERR_ARG, "fill_waves takes 1..8"); o.fill_waves = (uint32_t)value; }
+  else if (k == "fill_chunk") {
+    if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
+    o.fill_chunk = (uint32_t)value;
+  }
+  else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
     if (k == "lat_debug") o.lat_debug = value != 0;
     else if (k == "fill_fused") o.fill_fused = value != 0;
     else if (k == "sc_group") o.sc_group = value > 1 ? 8 : 1;
-    else if (k == "fill_chunk") {
-      if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
-      o.fill_chunk = (uint32_t)value;
-    }
     else if (k == "fill_stats") o.fill_stats = value != 0;
     else if (k == "walk_stats") o.walk_stats = value != 0;
     else if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;

@@ -126,7 +126,9 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
 // one wave of occupancy -- is compiled out.
 // EARLY_NIB: request the first dense variant's genotype nibbles before the list phase too (latency launches: one task
 // per wave and nothing to overlap with; throughput launches request them afterwards to stay within 64 registers).
-template <bool WIDE, bool EARLY_NIB, bool TUNE = false>
+// LISTED / DENSE: instantiations that take only one of the two regimes (the split form: k_fill_sites2 without the dense
+// variants, k_fill_dense with nothing else) compile the other one out.
+template <bool WIDE, bool EARLY_NIB, bool TUNE = false, bool LISTED = true, bool DENSE = true>
 __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uint32_t* lds_wave, uint32_t lane, uint32_t cnt, uint32_t cls,
                                             uint64_t gt0, uint64_t cb, uint32_t ablate_arg, uint32_t gt_words, unsigned long long* tstat = nullptr) {
   const uint32_t ablate = TUNE ? ablate_arg : 0u;   // production instantiations carry no ablation tests
@@ -201,7 +203,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
 
   // ---------------- denser variants (wave per variant, below): their first loads are requested NOW, so that the
   //                  list phase runs in the shadow of that memory latency ----------------
-  uint64_t dmask = __ballot(cnt > list_max && !explicit_ids);
+  uint64_t dmask = DENSE ? __ballot(cnt > list_max && !explicit_ids) : 0ull;
   uint64_t word_cur = 0, word_n1 = 0, word_n2 = 0;   // bit rows of the current dense variant and of the next two
   uint4 nq0 = {0, 0, 0, 0}, nq1 = {0, 0, 0, 0};      // raw genotype nibbles of the current one (then of the next)
   if (dmask) {
@@ -233,10 +235,10 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   if constexpr (WIDE) {
     // the same with 32-bit list entries and 32-bit carrier words (id | gt << 29): a group is two loads and two stores
     uint32_t* s_off = lds_wave;
-    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const bool sp = LISTED && cnt > 0 && cnt <= list_max && !(ablate & 1);
     const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
-    const uint32_t incl = wave_inclusive_scan(c);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    const uint32_t incl = LISTED ? wave_inclusive_scan(c) : 0u;
+    const uint32_t total = LISTED ? __builtin_amdgcn_readlane(incl, 63) : 0u;
     if (total) {
       uint32_t* s_idb = s_off + 64;
       uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
@@ -270,10 +272,10 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     }
   } else {
     uint32_t* s_off = lds_wave;   // aliases the genotype staging area
-    const bool sp = cnt > 0 && cnt <= list_max && !(ablate & 1);
+    const bool sp = LISTED && cnt > 0 && cnt <= list_max && !(ablate & 1);
     const uint32_t c = sp ? (cnt + kCarAlign - 1) / kCarAlign : 0u;
-    const uint32_t incl = wave_inclusive_scan(c);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    const uint32_t incl = LISTED ? wave_inclusive_scan(c) : 0u;
+    const uint32_t total = LISTED ? __builtin_amdgcn_readlane(incl, 63) : 0u;
     if (total) {
       uint32_t* s_idb = s_off + 64;
       uint64_t* s_gt0 = reinterpret_cast<uint64_t*>(s_off + 128);
@@ -592,7 +594,39 @@ __global__ void __launch_bounds__(256) k_fill_sites(DevImage im, DevResult r, co
 // number into a site with that run's record, copies the static site row with the list offset rebased, and takes
 // count / source handle / genotype offset of the same site for the expansion.  No row kernel, no site index written
 // and read back, no second read of the rows.
-template <bool WIDE, uint32_t CH, bool TUNE>
+// One task of the shared expansion: rows [u_first, u_first + CH) of the shared table -- their rows and their lists.
+template <bool WIDE, uint32_t CH, bool TUNE, bool DENSE>
+__device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevResult& r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
+                                                uint64_t U, uint64_t u_first, uint32_t lane, uint32_t* lds_wave, uint32_t ablate, uint32_t gt_words,
+                                                unsigned long long* tstat, uint64_t task, uint64_t t_start) {
+  const RowDelta d = shared_row_run(runs, coarse, n_runs, u_first, lane, lane < CH ? lane : 0u);
+  const uint64_t u = u_first + lane;
+  uint32_t cnt = 0, cls = 0;
+  uint64_t gt0 = 0, cb = 0;
+  if (u < U && lane < CH) {
+    const uint32_t g = (uint32_t)(u + d.dg);
+    const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
+    const uint4 x = src[0];
+    uint4 y = src[1];
+    cls = im.s_class[g];
+    gt0 = im.s_gt0[g];
+    cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
+    y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
+    uint4* dst = reinterpret_cast<uint4*>(r.rows + u);
+    dst[0] = x; dst[1] = y;
+    cnt = y.y & ~kRowDropped;
+  }
+  unsigned long long ph[3] = {0, 0, 0}, t_params = 0;
+  if (TUNE && tstat) {
+    __builtin_amdgcn_s_waitcnt(0);   // the task's parameters are in registers, its rows are on their way
+    t_params = wall_clock64() - t_start;
+  }
+  expand_task<WIDE, false, TUNE, true, DENSE>(im, r.carriers, lds_wave, lane, cnt, cls, gt0, cb, ablate, gt_words, (TUNE && tstat) ? ph : nullptr);
+  if (TUNE && tstat && lane == 0)   // one 16-byte record per task, written once at the end: {parameters + rows, list phase, dense phase, whole task | dense variants << 24}
+    reinterpret_cast<uint4*>(tstat)[task] = uint4{(uint32_t)t_params, (uint32_t)ph[0], (uint32_t)ph[1], (uint32_t)(wall_clock64() - t_start) | ((uint32_t)ph[2] << 24)};
+}
+
+template <bool WIDE, uint32_t CH, bool TUNE, bool DENSE = true>
 __global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
                                                      uint64_t U, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
   const uint64_t t_start = (TUNE && tstat) ? wall_clock64() : 0;
@@ -601,33 +635,69 @@ __global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, c
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
   const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
   const uint64_t u_first = wave * CH;
-  if (u_first < U) {
-    const RowDelta d = shared_row_run(runs, coarse, n_runs, u_first, lane, lane < CH ? lane : 0u);
-    const uint64_t u = u_first + lane;
-    uint32_t cnt = 0, cls = 0;
-    uint64_t gt0 = 0, cb = 0;
-    if (u < U && lane < CH) {
-      const uint32_t g = (uint32_t)(u + d.dg);
-      const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
-      const uint4 x = src[0];
-      uint4 y = src[1];
+  if (u_first < U)
+    fill_sites_task<WIDE, CH, TUNE, DENSE>(im, r, runs, coarse, n_runs, U, u_first, lane, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], ablate, gt_words, tstat, wave, t_start);
+}
+
+// The same tasks pulled by RESIDENT waves (experiment, option fill_mode = 1): the grid is what the machine holds, a wave takes
+// task after task from one of eight counters (a block's counter: blockIdx & 7 -- one word saturates near 90 dequeues per
+// microsecond, the launch needs ~300); shard s owns the tasks congruent to s modulo 8.
+constexpr uint32_t kTaskShards = 8, kTaskShardStride = 16;   // counters 64 bytes apart
+template <bool WIDE, uint32_t CH, bool DENSE>
+__global__ void __launch_bounds__(256) k_fill_sites2_resident(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
+                                                              uint64_t U, uint32_t gt_words, uint32_t* __restrict__ counters) {
+  const uint32_t lane = threadIdx.x & 63;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  uint32_t* lds_wave = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];
+  const uint64_t ntasks = (U + CH - 1) / CH;
+  const uint32_t shard = blockIdx.x & (kTaskShards - 1);
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&counters[shard * kTaskShardStride], 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const uint64_t task = (uint64_t)t * kTaskShards + shard;
+    if (task >= ntasks) break;
+    fill_sites_task<WIDE, CH, false, DENSE>(im, r, runs, coarse, n_runs, U, task * CH, lane, lds_wave, 0u, gt_words, nullptr, task, 0);
+  }
+}
+
+// The DENSE variants of a shared batch in a launch of their own (experiment, option fill_mode = 2): the index keeps the list
+// of its dense sites (more than list_max carriers: DevImage::dense_site); a wave owns K consecutive entries of that list,
+// its lanes look their sites up in the batch's runs -- covered or not, which row, which arena offset -- and the wave expands
+// the covered ones one after the other, rows requested two variants ahead and nibbles one, K deep instead of the two or
+// three a mixed task holds.  k_fill_sites2<..., DENSE = false> writes the rows and everything else.
+template <bool WIDE, uint32_t K>
+__global__ void __launch_bounds__(256) k_fill_dense(DevImage im, DevResult r, const RunRec* __restrict__ runs, uint64_t n_runs, uint64_t U, uint32_t gt_words) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
+  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
+  const uint64_t d_first = wave * K;
+  if (d_first >= im.n_dense) return;
+  uint32_t cnt = 0, cls = 0;
+  uint64_t gt0 = 0, cb = 0;
+  if (lane < K && d_first + lane < im.n_dense) {
+    const uint32_t g = im.dense_site[d_first + lane];
+    uint64_t lo = 0, hi = n_runs;                // the last run that starts at or before site g (runs are in site order as well as in row order)
+    while (hi - lo > 1) {
+      const uint64_t m = (lo + hi) >> 1;
+      if (runs[m].u_start + runs[m].dg <= g) lo = m; else hi = m;
+    }
+    const uint4* rp = reinterpret_cast<const uint4*>(runs + lo);
+    const uint4 a = rp[0], b = rp[1];
+    const uint64_t u_start = ((uint64_t)a.y << 32) | a.x, dg = ((uint64_t)a.w << 32) | a.z, dc = ((uint64_t)b.y << 32) | b.x;
+    const uint64_t u_end = lo + 1 < n_runs ? runs[lo + 1].u_start : U;
+    if (n_runs && g >= u_start + dg && g - dg < u_end) {
+      const uint4 y = reinterpret_cast<const uint4*>(im.s_row + g)[1];
+      cnt = y.y & ~kRowDropped;
+      cb = (((uint64_t)y.w << 32) | y.z) + dc;
       cls = im.s_class[g];
       gt0 = im.s_gt0[g];
-      cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
-      y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
-      uint4* dst = reinterpret_cast<uint4*>(r.rows + u);
-      dst[0] = x; dst[1] = y;
-      cnt = y.y & ~kRowDropped;
     }
-    unsigned long long ph[3] = {0, 0, 0}, t_params = 0;
-    if (TUNE && tstat) {
-      __builtin_amdgcn_s_waitcnt(0);   // the task's parameters are in registers, its rows are on their way
-      t_params = wall_clock64() - t_start;
-    }
-    expand_task<WIDE, false, TUNE>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, ablate, gt_words, (TUNE && tstat) ? ph : nullptr);
-    if (TUNE && tstat && lane == 0)   // one 16-byte record per task, written once at the end: {parameters + rows, list phase, dense phase, whole task | dense variants << 24}
-      reinterpret_cast<uint4*>(tstat)[wave] = uint4{(uint32_t)t_params, (uint32_t)ph[0], (uint32_t)ph[1], (uint32_t)(wall_clock64() - t_start) | ((uint32_t)ph[2] << 24)};
   }
+  if (__ballot(cnt != 0) == 0) return;
+  expand_task<WIDE, true, false, false, true>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, 0u, gt_words);
 }
 
 }  // namespace vsamd

@@ -95,6 +95,10 @@ struct DevImage {
   // (so a region's lists are ONE arena range, [s_carpre[g0], s_carpre[g1])), then the lists of the vertices only the
   // walking query types report.  A result then holds rows that point into this arena and no arena of its own.
   const uint64_t* v_abegin;   // [V] arena offset of each vertex's list (~0: the vertex has no carriers); NULL: not built
+  // The DENSE sites of the index (class-row cohorts: more than list_max carriers, expanded from the class's bit row), ascending:
+  // the split form of the shared expansion gives them a launch of their own (k_fill_dense).
+  const uint32_t* dense_site;
+  uint64_t n_dense;
 };
 
 // One row of a result's VARIANT TABLE (what the reference's `Variant` holds, query.h:30-36, with the strings and the
