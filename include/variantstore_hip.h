@@ -319,6 +319,9 @@ int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, ui
 /* the same into HOST memory (world x max_count records; synchronous) for callers that hold no device memory of their own */
 int vs_comm_allgather_regions_host(vs_comm* c, vs_result* r, uint64_t region_base, uint64_t max_count, void* host_dst);
 int vs_comm_wait(vs_comm* c);
+/* what the communicator is: the rank and world size it was made with and the number of ranks RCCL itself reports for it
+ * (ncclCommCount) -- a self-check for launchers: the three agree or the ranks did not all join the same communicator */
+int vs_comm_info(vs_comm* c, int* rank, int* world, int* rccl_ranks);
 void vs_comm_destroy(vs_comm* c);
 
 /* ---- switches of one handle ----

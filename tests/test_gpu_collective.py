@@ -87,8 +87,19 @@ def test_c_abi_collective_round_trip(tmp_path):
     orc = Oracle(plain)
     regions = sorted(random_regions(np.random.default_rng(6), vs.info().ref_length, 400))
     dev = torch.device("cuda", 0)
-    comm = make_comm(vs, 0, 1, id_file=os.path.join(tmp_path, "uid"))
+    comm = make_comm(vs, 0, 1, id_file=os.path.join(tmp_path, "uid"), nonce="test")   # (the file branch of the rendezvous, world 1)
+    assert comm.info() == (0, 1, 1), "rank, world and ncclCommCount of the communicator"
     local = vs.get_var_in_ref(regions)
+    # a result freed while its gather is in flight: the pack kernel reads the result's arrays, so its completion moves behind
+    # the kernel -- the records are those of the result all the same
+    early = vs.get_var_in_ref(regions)
+    g_early, c_early = allgather_region_records(comm, early, 0, dev, [len(regions)], async_op=True)
+    early.close()
+    for _k in range(3):   # (batches that would take the freed arrays from the pool)
+        vs.get_var_in_ref(regions[: len(regions) // 2]).close()
+    comm.wait()
+    rec = unpack_region_records(g_early, c_early)[0]
+    assert int(rec["variants"].sum()) == local.totals()[1] and int(rec["carriers"].sum()) == local.totals()[2]
     for async_op in (False, True):
         gathered, cnt = allgather_region_records(comm, local, 0, dev, [len(regions)], async_op=async_op)
         if async_op:
@@ -109,6 +120,7 @@ def test_c_abi_collective_round_trip(tmp_path):
     assert int(out[0, 0]) == 1000 and int(out[len(regions) - 1, 0]) == 1000 + len(regions) - 1
     with pytest.raises(Exception):
         comm.allgather_regions(local, 0, len(regions) - 1, out.data_ptr())     # max_count below this rank's count
-    comm.close()
+    # the handle's close is deferred while a communicator lives on it (vs_index::live_comms): closing in the "wrong" order is safe
     local.close()
     vs.close()
+    comm.close()

@@ -97,3 +97,28 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_id_file_rendezvous_ignores_a_stale_file(tmp_path):
+    """make_comm's file rendezvous (parallel.exchange_id_file): a rank other than 0 never takes the file an EARLIER launch
+    left at the same path -- nor a torn one -- for this launch's unique id (ranks used to accept any file)."""
+    import threading
+    import time
+    from variantstore_amd.parallel import exchange_id_file
+    path = str(tmp_path / "uid")
+    old = exchange_id_file(0, 2, path, lambda: b"O" * 128, nonce="launch-1")
+    assert old == b"O" * 128 and os.path.exists(path)
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("uid", exchange_id_file(1, 2, path, None, nonce="launch-2", timeout=20)))
+    t.start()
+    time.sleep(0.3)
+    assert "uid" not in got, "rank 1 accepted the stale id file of another launch"
+    with open(path, "wb") as f:   # a torn write of this launch's header alone is not an id either
+        f.write(b"\0" * 8)
+    time.sleep(0.1)
+    assert "uid" not in got
+    new = exchange_id_file(0, 2, path, lambda: b"N" * 128, nonce="launch-2")
+    t.join(20)
+    assert got.get("uid") == new == b"N" * 128
+    with pytest.raises(TimeoutError):
+        exchange_id_file(1, 2, path, None, nonce="launch-3", timeout=0.2)

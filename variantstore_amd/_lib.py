@@ -117,6 +117,7 @@ SYMBOLS = {
     "vs_comm_allgather_regions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int]),
     "vs_comm_allgather_regions_host": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
     "vs_comm_wait": (C.c_int, [_P]),
+    "vs_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vs_comm_destroy": (None, [_P]),
     "vs_index_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "vs_index_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),

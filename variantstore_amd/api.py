@@ -250,6 +250,12 @@ class Comm:
     def wait(self):
         _check(self._lib.vs_comm_wait(self._h), "vs_comm_wait")
 
+    def info(self):
+        """(rank, world, ranks RCCL reports for the communicator: ncclCommCount)."""
+        r, w, n = C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib.vs_comm_info(self._h, C.byref(r), C.byref(w), C.byref(n)), "vs_comm_info")
+        return r.value, w.value, n.value
+
     def close(self):
         if self._h:
             self._lib.vs_comm_destroy(self._h)

@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <sys/wait.h>
+#include <signal.h>
 #include <unistd.h>
 #include <algorithm>
 #include <cstdint>
@@ -431,11 +432,23 @@ int query_multiproc_main(const Args& a) {
     vs_index_close(idx);
     _exit(status);
   }
+  // Whichever rank ends first is reaped first; a rank that fails (no such device, an RCCL error) leaves the others inside
+  // ncclCommInitRank or the all-gather for good, so the first abnormal exit ends them all (fresh forks: nothing to save).
   int failed = 0;
-  for (pid_t pid : kids) {
+  for (size_t left = kids.size(); left > 0; --left) {
     int st = 0;
-    waitpid(pid, &st, 0);
-    if (!WIFEXITED(st) || WEXITSTATUS(st) != EXIT_SUCCESS) failed = 1;
+    const pid_t pid = waitpid(-1, &st, 0);
+    if (pid < 0) { failed = 1; break; }
+    auto it = std::find(kids.begin(), kids.end(), pid);
+    if (it == kids.end()) { ++left; continue; }   // (not one of the ranks)
+    *it = -1;
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != EXIT_SUCCESS) {
+      if (!failed) {
+        error("a rank of --nprocs failed; stopping the others");
+        for (pid_t other : kids) if (other > 0) kill(other, SIGKILL);
+      }
+      failed = 1;
+    }
   }
   if (!failed && !a.batch_out.empty()) {
     std::ofstream out(a.batch_out, std::ios::binary);

@@ -19,9 +19,11 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string path, error;
 };
+static std::string& rccl_error() { static std::string e; return e; }
 static RcclApi* rccl_api() {
   static RcclApi api;
   static bool tried = false;
@@ -37,18 +39,28 @@ static RcclApi* rccl_api() {
     for (auto& n : names)
       if (void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)) { api.lib = h; api.path = n; break; }
   }
-  if (!api.lib) { api.error = std::string("cannot load RCCL (librccl.so): ") + (dlerror() ? dlerror() : "not found"); return nullptr; }
+  if (!api.lib) {
+    const char* de = dlerror();
+    api.error = std::string("cannot load RCCL (librccl.so): ") + (de ? de : "not found");
+    rccl_error() = api.error;
+    return nullptr;
+  }
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
   api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+  api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.CommCount || !api.GetErrorString) {
     api.error = "RCCL at " + api.path + " lacks a symbol the collective needs";
+    rccl_error() = api.error;
     api.lib = nullptr;
     return nullptr;
   }
   return &api;
+}
+static int rccl_missing() {   // (rccl_api() has been tried: its error says why)
+  return fail(VS_ERR_UNSUPPORTED, "RCCL is not available in this process: %s", rccl_error().c_str());
 }
 #define RCCL_TRY(api, expr)                                                                                   \
   do {                                                                                                        \
@@ -67,6 +79,7 @@ struct vs_comm {
   void* recv = nullptr;             // receive buffer of the host-destination form
   size_t recv_cap = 0;
   bool pending = false;
+  bool counted = false;             // in vs_index::live_comms (the handle's close is deferred until the communicator is gone)
 };
 
 extern "C" {
@@ -75,7 +88,7 @@ int vs_comm_unique_id(void* id_out) {
   if (!id_out) return fail(VS_ERR_ARG, "null argument");
   static_assert(sizeof(ncclUniqueId) == VS_COMM_ID_BYTES, "unique id size of the ABI");
   RcclApi* api = rccl_api();
-  if (!api) return fail(VS_ERR_UNSUPPORTED, "%s", api ? "" : "RCCL is not available in this process");
+  if (!api) return rccl_missing();
   ncclUniqueId id;
   RCCL_TRY(api, api->GetUniqueId(&id));
   memcpy(id_out, &id, sizeof(id));
@@ -87,7 +100,7 @@ int vs_comm_init(vs_index* idx, int rank, int world, const void* id, vs_comm** o
   if (world < 1 || rank < 0 || rank >= world) return fail(VS_ERR_ARG, "rank %d of %d", rank, world);
   if (idx->device < 0) return fail(VS_ERR_NO_DEVICE, "index handle was opened without a device");
   RcclApi* api = rccl_api();
-  if (!api) return fail(VS_ERR_UNSUPPORTED, "RCCL is not available in this process");
+  if (!api) return rccl_missing();
   HIP_TRY(hipSetDevice(idx->device));
   vs_comm* c = new vs_comm();
   c->idx = idx; c->rank = rank; c->world = world;
@@ -100,6 +113,8 @@ int vs_comm_init(vs_index* idx, int rank, int world, const void* id, vs_comm** o
     vs_comm_destroy(c);
     return fail(VS_ERR_HIP, "stream / event creation for the collective failed");
   }
+  idx->live_comms++;
+  c->counted = true;
   *out = c;
   return VS_OK;
 }
@@ -113,13 +128,27 @@ int vs_comm_wait(vs_comm* c) {
   return VS_OK;
 }
 
+int vs_comm_info(vs_comm* c, int* rank, int* world, int* rccl_ranks) {
+  if (!c) return fail(VS_ERR_ARG, "null argument");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (rccl_ranks) {
+    RcclApi* api = rccl_api();
+    if (!api) return rccl_missing();
+    int n = 0;
+    RCCL_TRY(api, api->CommCount(c->comm, &n));
+    *rccl_ranks = n;
+  }
+  return VS_OK;
+}
+
 int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, uint64_t max_count, void* device_dst, int async_op) {
   if (!c || !r || !device_dst) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
   if (r->idx != c->idx) return fail(VS_ERR_ARG, "the result belongs to another index handle than the communicator");
   if (r->d.Q > max_count) return fail(VS_ERR_ARG, "this rank holds %llu regions, max_count is %llu", (unsigned long long)r->d.Q, (unsigned long long)max_count);
   RcclApi* api = rccl_api();
-  if (!api) return fail(VS_ERR_UNSUPPORTED, "RCCL is not available in this process");
+  if (!api) return rccl_missing();
   vs_index* idx = c->idx;
   HIP_TRY(hipSetDevice(idx->device));
   VS_TRY(vs_comm_wait(c));   // (the send buffer is reused)
@@ -134,6 +163,11 @@ int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, ui
   if (r->d.Q) {
     hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((r->d.Q + 255) / 256)), dim3(256), 0, idx->stream, r->d, (uint64_t*)c->send, region_base);
     HIP_TRY(hipGetLastError());
+    // the pack kernel reads the result's per-region arrays: the result's completion event moves behind it, so that a
+    // vs_result_free before vs_comm_wait does not hand those arrays back to the pool under the kernel
+    VS_TRY(pooled_event(idx, &r->ev_done));
+    HIP_TRY(hipEventRecord(r->ev_done, idx->stream));
+    r->pending = true;
   }
   HIP_TRY(hipEventRecord(c->packed, idx->stream));
   // ... and ONE all-gather of the padded records on the communicator's stream behind them
@@ -172,7 +206,12 @@ void vs_comm_destroy(vs_comm* c) {
   if (c->packed) (void)hipEventDestroy(c->packed);
   if (c->done) (void)hipEventDestroy(c->done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  vs_index* idx = c->counted ? c->idx : nullptr;
   delete c;
+  if (idx) {
+    idx->live_comms--;
+    if (idx->close_pending && idx->live_results == 0 && idx->live_comms == 0) vs_index_close(idx);
+  }
 }
 
 }  // extern "C"

@@ -126,7 +126,8 @@ struct vs_index {
   vs_timing timing{};
   vs_construct_stats cstats{};
   uint64_t live_results = 0;
-  bool close_pending = false;  // vs_index_close was called while results were alive
+  uint64_t live_comms = 0;     // communicators (vs_comm) made on this handle: they keep its device and stream in use
+  bool close_pending = false;  // vs_index_close was called while results or communicators were alive
   unsigned long long* done_counter = nullptr;   // device word of the latency path's completion mailbox
   uint64_t lat_seq = 0;
   // resident query server of the latency path (kernels.hip.h: k_query_server)
@@ -533,7 +534,7 @@ static int build_device_image(vs_index* idx) {
     // Budget: half of the free memory, at most 176 GB -- or VS_T4_ROWS_MAX_GB from the environment; vs_index_get_info
     // reports what was taken (t4_rows_bytes).
     uint64_t cap = 176ull << 30;
-    if (const char* gb = getenv("VS_T4_ROWS_MAX_GB")) cap = (uint64_t)std::max(0.0, atof(gb)) << 30;
+    if (const char* gb = getenv("VS_T4_ROWS_MAX_GB")) cap = (uint64_t)(std::max(0.0, atof(gb)) * (double)(1ull << 30));
     if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
       idx->t4_rows_bytes = bytes + hbytes;
       uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
@@ -920,6 +921,7 @@ static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, 
 static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
                             bool allow_async) {
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
+  idx->timing_pending = false; idx->timing_owner = nullptr;   // (an earlier lean batch's event pair is not this batch's)
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1976,7 +1978,7 @@ const char* vs_last_error(void) { return g_last_error.c_str(); }
 
 void vs_index_close(vs_index* idx) {
   if (!idx) return;
-  if (idx->live_results > 0) {  // results still hold buffers of this handle: the last vs_result_free closes it
+  if (idx->live_results > 0 || idx->live_comms > 0) {  // results / communicators still use this handle: the last vs_result_free / vs_comm_destroy closes it
     idx->close_pending = true;
     return;
   }
@@ -2200,7 +2202,7 @@ void vs_result_free(vs_result* r) {
     pin_release(r->idx, r->raw_pin);
     for (auto& b : r->old_pins) pin_release(r->idx, b);
     r->idx->live_results--;
-    if (r->idx->close_pending && r->idx->live_results == 0) vs_index_close(r->idx);
+    if (r->idx->close_pending && r->idx->live_results == 0 && r->idx->live_comms == 0) vs_index_close(r->idx);
   }
   delete r;
 }

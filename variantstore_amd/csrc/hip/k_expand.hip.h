@@ -435,6 +435,10 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         asm volatile("" : "+v"(incl));   // keeps the six fused DPP adds (the compiler otherwise re-associates them into ~20)
         const uint32_t end = pos + __builtin_amdgcn_readlane(incl, 63);
         uint32_t j = pos + incl - pc;                     // list index of this lane's first carrier of the round
+        // (Tried in round 5 and removed: peeling by NIBBLE through a 16-entry table -- four 16-bit positions per 8-byte store at
+        //  the lane's cursor, ceil(sb / 4) steps whatever the popcount.  A store that is only 2-byte aligned is legal on
+        //  gfx950 but the LDS takes it one LANE at a time: 64 cycles per wave-instruction against 5.6 for ds_write_b16 and
+        //  7.2 for an aligned ds_write_b64 (tools/microbench/lds_store.hip); the kernel went from 0.51 to 0.59 ms.)
         while (bits) {
           ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
           bits &= bits - 1;

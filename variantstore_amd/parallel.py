@@ -66,35 +66,60 @@ def allgather_hit_lists(result, region_base, device, compact=False, counts=None,
     return out.view(world, max_n, 4), counts
 
 
-def make_comm(store, rank, world, id_file=None):
-    """A `Comm` (the engine's own RCCL communicator, vs_comm_*) for this rank.  The 128-byte unique id is made on rank 0
-    and reaches the other ranks through torch.distributed when a process group exists (any backend), else through
-    `id_file` (rank 0 writes it, the others wait for it)."""
+def _launch_nonce():
+    """What tells one launch's id file from another's: VS_COMM_NONCE, else what torchrun gives every rank of a launch."""
+    import os
+    n = os.environ.get("VS_COMM_NONCE")
+    if n is None:
+        n = ":".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    return n
+
+
+def exchange_id_file(rank, world, id_file, make_id, nonce=None, timeout=120.0):
+    """The file rendezvous of `make_comm`: rank 0 writes `sha256(nonce)[:16] + make_id()` to `id_file` (atomically, over
+    whatever an earlier launch left there), the other ranks wait for a file that carries THIS launch's nonce -- a stale
+    file (another nonce, or a torn write) is never taken for the id.  Returns the id bytes."""
+    import hashlib
     import os
     import time
+    tag = hashlib.sha256((_launch_nonce() if nonce is None else nonce).encode()).digest()[:16]
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{id_file}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(tag + uid)
+        os.replace(tmp, id_file)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(id_file, "rb") as f:
+                blob = f.read()
+        except OSError:
+            blob = b""
+        if len(blob) > 16 and blob[:16] == tag:
+            return blob[16:]
+        if time.time() - t0 > timeout:
+            raise TimeoutError(f"no unique id of this launch at {id_file}")
+        time.sleep(0.01)
+
+
+def make_comm(store, rank, world, id_file=None, nonce=None):
+    """A `Comm` (the engine's own RCCL communicator, vs_comm_*) for this rank.  The 128-byte unique id is made on rank 0
+    and reaches the other ranks through torch.distributed when a process group exists (any backend), else through
+    `id_file` (`exchange_id_file`: rank 0 writes it, the others wait for the file of THIS launch -- give every rank the
+    same `nonce`, or VS_COMM_NONCE, when the path is reused between launches outside torchrun)."""
     from .api import Comm
     if dist.is_available() and dist.is_initialized():
         box = [Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
-    elif world == 1:
+    elif world == 1 and id_file is None:
         uid = Comm.unique_id()
     else:
         if id_file is None:
             raise ValueError("make_comm needs a process group or an id_file")
-        if rank == 0:
-            uid = Comm.unique_id()
-            with open(id_file + ".tmp", "wb") as f:
-                f.write(uid)
-            os.replace(id_file + ".tmp", id_file)
-        else:
-            t0 = time.time()
-            while not os.path.exists(id_file):
-                if time.time() - t0 > 120:
-                    raise TimeoutError(f"no unique id at {id_file}")
-                time.sleep(0.01)
-            with open(id_file, "rb") as f:
-                uid = f.read()
+        uid = exchange_id_file(rank, world, id_file, Comm.unique_id, nonce)
     return Comm(store, rank, world, uid)
 
 
