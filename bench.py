@@ -274,6 +274,221 @@ def spawn_ranks(ngpus):
     print(lines[-1], flush=True)
 
 
+def back_to_back(call, reps):
+    """Seconds per batch of `call` submitted back to back: a result is closed one step late (closing waits for its batch), the
+    clock stops when the device is idle."""
+    import torch
+    prev = call()      # warm-up (also: the handle's pool holds what two batches alive at a time need)
+    nxt = call()
+    prev.close()
+    prev = nxt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _k in range(reps):
+        nxt = call()
+        prev.close()
+        prev = nxt
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prev.close()
+    return dt
+
+
+def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nreg, region_base, counts, strong, torch_collective, step, fence,
+                     in_flight):
+    """What the N > 1 line says about the collective itself, outside the headline's timed region:
+      rccl_ranks    ncclCommCount of the engine's communicator (vs_comm_info) -- or the process group's size on the torch path
+      gathered_ok   one synchronous gather of this step's records, checked on rank 0: rank k's records lie at k x max_count, carry
+                    the region numbers [lo_k, hi_k) in order and add up to the variants / carriers rank k itself counted; any
+                    mismatch is an error on every rank (non-zero exit), not a number
+      strong        BASELINE configs[3] -- ONE sorted batch of 1,000,000 regions cut into `world` contiguous shards, every step
+                    ending in the gather -- timed like the headline (barrier, K steps, max over ranks), with the N = 1 time of the
+                    whole batch measured on rank 0 of the same node, the collective's own time, and what rebuilding rows and
+                    lists of the WHOLE batch from the gathered records costs the receiving rank (vs_query_expand_site_ranges)
+      headers       SURVEY 8e's default form timed once: per-variant 32-byte records (vs_result_pack_headers) instead of
+                    per-region site ranges"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from variantstore_amd.parallel import allgather_hit_lists, allgather_region_records, shard_bounds, unpack_region_records
+    dev = torch.device("cuda", local_rank)
+    out = {"world": world, "collective": "torch.distributed" if comm is None else "vs_comm_allgather_regions (C ABI, RCCL by dlopen)"}
+    out["rccl_ranks"] = comm.info()[2] if comm is not None else dist.get_world_size()
+
+    def gather_sync(res, base, cnts):
+        if comm is not None:
+            recs, c = allgather_region_records(comm, res, base, dev, cnts, async_op=False)
+        else:
+            recs, c = allgather_hit_lists(res, base, dev, compact=True, counts=cnts)
+        return recs, c
+
+    def check(res, base, cnts, bases, label):
+        """rank 0: the gathered records against what every rank says about its own shard"""
+        recs, c = gather_sync(res, base, cnts)
+        tot = res.totals()
+        mine = torch.tensor([int(tot[1]), int(tot[2])], dtype=torch.int64, device=dev)
+        allt = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        ok = 1
+        if rank == 0:
+            per = unpack_region_records(recs, c)
+            allt_h = allt.cpu().numpy()
+            for k in range(world):
+                n_k = int(cnts[k])
+                want_ids = np.arange(bases[k], bases[k] + n_k, dtype=np.uint64)
+                if len(per[k]["region"]) != n_k or not np.array_equal(per[k]["region"], want_ids):
+                    sys.stderr.write(f"gathered_ok[{label}]: rank {k}'s records do not carry regions [{bases[k]}, {bases[k] + n_k}) at record {k} x max_count\n")
+                    ok = 0
+                elif int(per[k]["variants"].sum()) != int(allt_h[k, 0]) or int(per[k]["carriers"].sum()) != int(allt_h[k, 1]):
+                    sys.stderr.write(f"gathered_ok[{label}]: rank {k}'s records add up to {int(per[k]['variants'].sum())} variants / "
+                                     f"{int(per[k]['carriers'].sum())} carriers, the rank itself counted {int(allt_h[k, 0])} / {int(allt_h[k, 1])}\n")
+                    ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, src=0)
+        return bool(int(flag.item())), recs, c
+
+    # ---- the headline's own gather, checked ----
+    bases = [0] * world
+    if strong:
+        total = sum(int(c) for c in counts)
+        bases = [shard_bounds(total, k, world)[0] for k in range(world)]
+    else:
+        bases = [k * nreg for k in range(world)]
+    res = vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg)
+    ok, recs, c = check(res, region_base, counts, bases, "headline")
+    out["gathered_ok"] = ok
+    out["records_bytes_per_rank"] = int(max(int(x) for x in counts)) * 32
+    # the collective alone (records already packed is not separable from the call: pack kernel + all-gather, synchronous)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _i in range(5):
+        gather_sync(res, region_base, counts)
+    torch.cuda.synchronize()
+    out["gather_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+    # SURVEY 8e's default: one 32-byte record per reported VARIANT (self-contained rows), through torch.distributed
+    try:
+        torch.cuda.synchronize(); dist.barrier()
+        hr, hc = allgather_hit_lists(res, region_base, dev, compact=False)     # warm-up (buffers)
+        del hr
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        hr, hc = allgather_hit_lists(res, region_base, dev, compact=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nrec = int(hc.sum().item())
+        out["headers"] = {"ms": dt * 1e3, "records": nrec, "bytes_received_per_rank": int(hc.max().item()) * 32 * world,
+                          "GBps_received": int(hc.max().item()) * 32 * world / dt / 1e9,
+                          "note": "per-variant header records (vs_result_pack_headers): count all-gather + one padded all_gather_into_tensor"}
+        del hr
+    except Exception as e:   # (memory: world x 650 MB on the bench cohort)
+        out["headers"] = {"error": str(e)[:200]}
+    # the receiving side: rows and carrier lists of the WHOLE gathered batch rebuilt from the records of all ranks
+    flat = torch.cat([recs[k, : int(counts[k])] for k in range(world)], dim=0).contiguous()
+    nall = int(flat.shape[0])
+    back = vs.expand_site_ranges(flat.data_ptr(), nall)
+    back.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _i in range(3):
+        back = vs.expand_site_ranges(flat.data_ptr(), nall)
+        back.close()
+    torch.cuda.synchronize()
+    out["expand_site_ranges_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    out["expand_site_ranges_regions"] = nall
+    res.close()
+    del flat, recs
+
+    # ---- config #4: one sorted batch of 1 M regions cut `world` ways (the target form), when the headline is the weak one ----
+    if not strong and not args.emulate_shard:
+        total = 1_000_000
+        whole = make_regions(dict(w, region_seed=3), 0, total)
+        lo, hi = shard_bounds(total, rank, world)
+        s_counts = [shard_bounds(total, k, world)[1] - shard_bounds(total, k, world)[0] for k in range(world)]
+        s_bases = [shard_bounds(total, k, world)[0] for k in range(world)]
+        shard_dev = torch.from_numpy(np.ascontiguousarray(whole[lo:hi]).astype(np.int64)).to(dev).contiguous()
+        n_s = hi - lo
+        flight = []
+
+        class _W:
+            def wait(self):
+                comm.wait()
+
+        def s_step():
+            r = vs.get_var_in_ref_device(shard_dev.data_ptr(), n_s)
+            if comm is not None:
+                while flight:
+                    flight.pop(0)[0].wait()
+                g, _c = allgather_region_records(comm, r, lo, dev, s_counts, async_op=True)
+                flight.append((_W(), g))
+            else:
+                g, _c, work = allgather_hit_lists(r, lo, dev, compact=True, counts=s_counts, async_op=True)
+                flight.append((work[0], g))
+            while len(flight) > 1:
+                flight.pop(0)[0].wait()
+            return r
+
+        def s_fence():
+            while flight:
+                flight.pop(0)[0].wait()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+        prev = None
+        for _i in range(max(args.warmup, 2)):
+            r = s_step()
+            if prev is not None:
+                prev.close()
+            prev = r
+        prev.close(); prev = None
+        s_fence()
+        t0 = time.perf_counter()
+        for _i in range(args.steps):
+            r = s_step()
+            if prev is not None:
+                prev.close()
+            prev = r
+        s_fence()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = float(el.item())
+        ok_s, _r, _c = check(prev, lo, s_counts, s_bases, "strong")
+        prev.close()
+        out["gathered_ok"] = out["gathered_ok"] and ok_s
+        # the same batch whole, on rank 0 alone (the others wait): what one GPU of this node takes
+        n1_ms = None
+        s_fence()
+        if rank == 0:
+            whole_dev = torch.from_numpy(whole.astype(np.int64)).to(dev).contiguous()
+            pr = None
+            for _i in range(3):
+                r = vs.get_var_in_ref_device(whole_dev.data_ptr(), total)
+                if pr is not None:
+                    pr.close()
+                pr = r
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _i in range(args.steps):
+                r = vs.get_var_in_ref_device(whole_dev.data_ptr(), total)
+                pr.close()
+                pr = r
+            torch.cuda.synchronize()
+            n1_ms = (time.perf_counter() - t0) / args.steps * 1e3
+            pr.close()
+            del whole_dev
+        s_fence()
+        ms = el / args.steps * 1e3
+        out["strong"] = {"config": "BASELINE configs[3]: one sorted batch of 1,000,000 regions, contiguous shards, gather of per-region records every step",
+                         "regions_total": total, "n_gpus": world, "value": total * args.steps / el, "unit": "queries/s", "ms_per_step": ms,
+                         "steps": args.steps, "gathered_ok": ok_s,
+                         "n1_ms_per_step_same_node": n1_ms, "speedup_vs_n1": (n1_ms / ms) if n1_ms else None,
+                         "note": "ms_per_step is the slowest rank's (max over ranks); speedup_vs_n1 = rank 0 running the whole batch alone / that"}
+        del shard_dev
+    ok_all = torch.tensor([1 if out["gathered_ok"] else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    if int(ok_all.item()) == 0:
+        raise SystemExit("bench.py: the gathered records do not match what the ranks computed (see stderr)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -485,6 +700,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
+    # ---- the collective, judged (N > 1, or VS_BENCH_FORCE_DIST=1 on one GPU: the same code paths) ----
+    dist_info = None
+    if use_dist:
+        dist_info = distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nreg, region_base, counts, strong,
+                                     torch_collective, step, fence, in_flight)
+
     # ---- result-derived figures of one batch (last step's result is still alive) ----
     nq, nvar, ncar, nbases = res.totals()
     digest = res.digest()
@@ -638,20 +859,20 @@ def main():
         r4 = vs.get_sample_var_in_ref(regions4, per_region)  # warm-up
         nv4, nc4 = r4.totals()[1:3]
         r4.close()
-        torch.cuda.synchronize()
-        a4 = time.perf_counter()
+        # (as the headline loop: a batch call returns when the batch is enqueued -- one host wait inside it, for the sizes -- and a
+        #  result is closed one step late, so the host is not between the batches)
+        dt4 = back_to_back(lambda: vs.get_sample_var_in_ref(regions4, per_region), 6)
         walk_ms = 0.0
-        for _k in range(5):
+        for _k in range(3):   # the walk phase by the handle's events (reading them waits for the batch: outside the timed loop)
             r4 = vs.get_sample_var_in_ref(regions4, per_region)
             walk_ms += vs.last_timing().ms_bounds
             r4.close()
-        torch.cuda.synchronize()
-        t4 = {"queries_per_s": 5 * nreg / (time.perf_counter() - a4), "regions_per_batch": nreg, "samples": 16, "inputs": "device memory",
-              "variants_per_region": nv4 / nreg, "carriers_per_variant": nc4 / max(nv4, 1), "walk_phase_ms": walk_ms / 5}
+        t4 = {"queries_per_s": nreg / dt4, "ms_per_batch": dt4 * 1e3, "regions_per_batch": nreg, "samples": 16, "inputs": "device memory",
+              "variants_per_region": nv4 / nreg, "carriers_per_variant": nc4 / max(nv4, 1), "walk_phase_ms": walk_ms / 3}
         tw = (tj["kernels"].get("k_sample_walk_coop") or tj["kernels"].get("k_sample_walk")) if tj else None
         if tw and walk_ms > 0:   # the walk kernel's own pin traffic (PMC) over the walk phase (capacity bounds + scan + walk) timed here
             t4["walk_traffic_bytes"] = tw["traffic_bytes_per_launch"]
-            t4["walk_traffic_GBps"] = tw["traffic_bytes_per_launch"] / (walk_ms / 5 * 1e-3) / 1e9
+            t4["walk_traffic_GBps"] = tw["traffic_bytes_per_launch"] / (walk_ms / 3 * 1e-3) / 1e9
 
     # ---- point queries (types 1 and 7) on the same index, outside the timed region:
     #      1M random positions; type 7 asks for an A>C substitution everywhere (nearly always "no such variant",
@@ -707,12 +928,7 @@ def main():
             rr = call()
             tot = rr.totals()      # (a reduction kernel over the rows for type 5: outside the timed calls, as in the headline loop)
             rr.close()
-            torch.cuda.synchronize()
-            b0 = time.perf_counter()
-            for _k in range(3):
-                call().close()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - b0) / 3
+            dt = back_to_back(call, 4)
             tsc[name + "_queries_per_s"] = nsc / dt
             if name != "type5":
                 tsc[name + "_bases_per_s"] = tot[3] / dt
@@ -900,6 +1116,11 @@ def main():
             "overlap_factor": n_slots / max(table_rows, 1),                      # rows reported over all regions / rows of the variant table
             "unique_sites_per_s": lists_expanded * world * args.steps / elapsed,   # carrier lists expanded per second, whole job
             "delivered_queries_per_s": (delivery or {}).get("batch_then_copy_queries_per_s"),   # batch + raw copy of rows AND carriers into page-locked host memory
+            # N > 1 (or VS_BENCH_FORCE_DIST=1): ranks RCCL reports, the gathered records checked on rank 0, config #4's strong
+            # form beside the weak headline, the per-variant-header gather (SURVEY 8e's default) and the receiving side's cost
+            "rccl_ranks": (dist_info or {}).get("rccl_ranks"), "gathered_ok": (dist_info or {}).get("gathered_ok"),
+            "strong": (dist_info or {}).pop("strong", None) if dist_info else None,
+            "distributed": dist_info,
             "emulated_shard": ({"shard": emu[0], "of": emu[1], "regions_in_shard": nreg, "batch_regions": (args.regions or 1_000_000),
                                 "ms_per_step": elapsed / args.steps * 1e3,
                                 "predicted_value_at_n_gpus": (args.regions or 1_000_000) * args.steps / elapsed,

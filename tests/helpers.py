@@ -133,3 +133,46 @@ def read_plain(path):
     g["idx_pos"] = vec("<u4")
     g["node_list"] = vec("<u4")
     return g
+
+
+# ---- windows of a synthetic cohort (tests/native/synth_windows.cpp): how the oracle gets to see the full-size indexes ----
+_SYNTH_WINDOWS_EXE = None
+
+
+def synth_windows(kw, wins, outdir):
+    """Write FASTA + VCF of the windows [(lo, hi), ...] (1-based, inclusive) of the synthetic cohort `kw` (the keyword
+    arguments of VariantStore.synthetic) into outdir/w<k>.fa / .vcf; returns the records written per window."""
+    import subprocess
+    import tempfile
+    global _SYNTH_WINDOWS_EXE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if _SYNTH_WINDOWS_EXE is None:
+        exe = os.path.join(tempfile.mkdtemp(prefix="vs_native_"), "synth_windows")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "native", "synth_windows.cpp")])
+        _SYNTH_WINDOWS_EXE = exe
+    args = [str(kw[k]) for k in ("ref_length", "num_variants", "num_samples", "seed", "first_pos", "frac_ins", "frac_del", "frac_multi",
+                                 "max_indel", "af_exponent")] + [str(kw.get("max_af", 0.5)), str(outdir)]
+    out = subprocess.run([_SYNTH_WINDOWS_EXE] + args, input="".join(f"{a} {b}\n" for a, b in wins), text=True, capture_output=True, check=True)
+    return [int(line.split()[3]) for line in out.stdout.strip().split("\n")]
+
+
+def parse_rows(text, shift=0):
+    """Rows of a region's print_var text as (pos + shift, ref, alt, samples)."""
+    rows = []
+    for line in text.split("\n")[1:]:
+        if line:
+            p, ref, alt, s = line.split("\t")
+            rows.append((int(p) + shift, ref, alt, s))
+    return rows
+
+
+def window_oracle(outdir, k):
+    """The small index of window k built through the product's VCF path on the host, and the oracle over it."""
+    from oracle.oracle import Oracle
+    from variantstore_amd import VariantStore
+    w = VariantStore.from_vcf(os.path.join(outdir, f"w{k}.fa"), os.path.join(outdir, f"w{k}.vcf"), device=-1)
+    plain = os.path.join(outdir, f"w{k}.bin")
+    w.export_plain(plain)
+    w.close()
+    orc = Oracle(plain)
+    return orc

@@ -265,3 +265,72 @@ def test_a_loop_of_batches_in_flight_neither_allocates_nor_frees_device_memory(b
     assert len(loop(25)) == 1
     after = vs.info()
     assert (after.pool_mallocs, after.pool_frees) == (before.pool_mallocs, before.pool_frees)
+
+
+def test_oracle_spot_checks_through_windows(big, tmp_path):
+    """The CPU oracle on the FULL-size index, through windows (exactness at full size used to rest on properties
+    alone).  The generator's records inside a window are written as FASTA + VCF relative to the window
+    (tests/native/synth_windows.cpp), built into a small index through the product's VCF path on the host, and the oracle's
+    rows over that index -- shifted back by the window's origin -- are compared with what the GPU answers on the whole
+    5 M-site index: query type 6 on 90 + 12 regions, type 4 on 24 (region, sample) pairs whose walk back to the sample's
+    previous vertex stays inside a 150 kb margin.  tests/test_windows.py checks the windowing itself against the oracle on
+    a cohort it can hold whole."""
+    from helpers import parse_rows, synth_windows, window_oracle
+    vs, _regions = big
+    rng = np.random.default_rng(77)
+    m6, m4 = 20_000, 150_000
+    wins, plan = [], []   # plan: (window, kind, [(x, y), ...])
+    for c in np.sort(rng.integers(1_000_000, KW["ref_length"] - 1_000_000, size=30)):
+        c = int(c)
+        wins.append((c - m6, c + 30_000 + m6))
+        plan.append((len(wins) - 1, 6, [(c + j * 10_000, c + (j + 1) * 10_000) for j in range(3)]))
+    for c in np.sort(rng.integers(1_000_000, KW["ref_length"] - 1_000_000, size=6)):
+        c = int(c)
+        wins.append((c - m4, c + 20_000 + m4))
+        plan.append((len(wins) - 1, 4, [(c, c + 10_000), (c + 10_000, c + 20_000)]))
+    counts = synth_windows(KW, wins, tmp_path)
+    assert min(counts) > 500
+    # the full-size answers, one batch per query type (sorted by start: shared rows and lists, the bench's own path)
+    q6 = sorted(r for _w, _k, rs in plan for r in rs)
+    res6 = vs.get_var_in_ref(np.array(q6, dtype=np.uint64))
+    assert res6.layout()[4]
+    text6 = {r: res6.region_text(i) for i, r in enumerate(q6)}
+    # type 4: two samples per region that carry something within 100 kb before it
+    q4 = []
+    for _w, kind, rs in plan:
+        if kind != 4:
+            continue
+        for (x, y) in rs:
+            before = vs.get_var_in_ref(np.array([[x - 100_000, x]], dtype=np.uint64))
+            names = []
+            for row in reversed(parse_rows(before.region_text(0))):
+                for s in row[3].split():
+                    nm = s.split("(")[0]
+                    if nm not in names:
+                        names.append(nm)
+                if len(names) >= 2:
+                    break
+            before.close()
+            assert len(names) >= 2
+            q4 += [((x, y), names[0]), ((x, y), names[1])]
+    res4 = vs.get_sample_var_in_ref(np.array([r for r, _s in q4], dtype=np.uint64), [s for _r, s in q4])
+    text4 = {(r, s): res4.region_text(i) for i, (r, s) in enumerate(q4)}
+    n6 = n4 = rows6 = rows4 = 0
+    for w, kind, rs in plan:
+        lo, _hi = wins[w]
+        orc = window_oracle(tmp_path, w)
+        for (x, y) in rs:
+            n, _, t = orc.get_var_in_ref(x - lo + 1, y - lo + 1)
+            assert n >= 0 and parse_rows(text6[(x, y)]) == parse_rows(t, lo - 1), ("type 6", x, y)
+            n6 += 1
+            rows6 += n
+            if kind == 4:
+                for (r, s) in [k for k in text4 if k[0] == (x, y)]:
+                    n, _, t = orc.get_sample_var_in_ref(x - lo + 1, y - lo + 1, s)
+                    assert n >= 0 and parse_rows(text4[(r, s)]) == parse_rows(t, lo - 1), ("type 4", x, y, s)
+                    n4 += 1
+                    rows4 += n
+        orc.close()
+    res6.close()
+    res4.close()
+    assert n6 == 102 and n4 == 24 and rows6 > 15_000 and rows4 > 0

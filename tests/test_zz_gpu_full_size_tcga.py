@@ -164,6 +164,49 @@ def test_types_3_and_7_at_full_size(tcga):
     whole.close()
 
 
+def test_oracle_spot_checks_through_windows(tcga, tmp_path):
+    """The CPU oracle on the FULL 20 M-site, 10,000-sample index, through windows (tests/native/synth_windows.cpp; the
+    method: tests/test_windows.py): query types 6 and 7 -- type 7's point walk and type 6's region walk are local to the
+    window; type 3 answers in SAMPLE coordinates, which depend on every indel of the sample upstream, and stays with the
+    1/50 slice below."""
+    from helpers import parse_rows, synth_windows, window_oracle
+    vs, _regions = tcga
+    kw = bench.synth_kwargs(W)
+    rng = np.random.default_rng(78)
+    margin = 6_000
+    centres = [int(c) for c in np.sort(rng.integers(1_000_000, W["ref_length"] - 1_000_000, size=5))]
+    wins = [(c - margin, c + 20_000 + margin) for c in centres]
+    counts = synth_windows(kw, wins, tmp_path)
+    assert min(counts) > 1000
+    q6 = [(c + j * 10_000, c + (j + 1) * 10_000) for c in centres for j in range(2)]
+    res6 = vs.get_var_in_ref(np.array(q6, dtype=np.uint64))
+    n6 = n7 = rows = 0
+    for k, c in enumerate(centres):
+        lo = wins[k][0]
+        orc = window_oracle(tmp_path, k)
+        for j in range(2):
+            x, y = q6[2 * k + j]
+            n, _, t = orc.get_var_in_ref(x - lo + 1, y - lo + 1)
+            full_rows = parse_rows(res6.region_text(2 * k + j))
+            assert n >= 0 and full_rows == parse_rows(t, lo - 1), ("type 6", x, y)
+            n6 += 1
+            rows += n
+            # type 7 at the rows' own (pos, ref, alt) -- found -- and one base further -- mostly not
+            probe = [(p, r, a) for p, r, a, _s in full_rows[:40] if r and a] + [(p + 1, r, a) for p, r, a, _s in full_rows[:20] if r and a]
+            r7 = vs.samples_has_var([q[0] for q in probe], [q[1] for q in probe], [q[2] for q in probe])
+            fl = r7.view(False)["region_flags"]
+            for i, (p, r, a) in enumerate(probe):
+                want = orc.samples_has_var(p - lo + 1, r, a)
+                assert (want is None) == bool(fl[i] & 4), ("type 7", p, r, a)
+                if want is not None:
+                    assert r7.region_text(i) == want, ("type 7", p, r, a)
+                n7 += 1
+            r7.close()
+        orc.close()
+    res6.close()
+    assert n6 == 10 and rows > 5_000 and n7 > 300
+
+
 def test_one_fiftieth_slice_against_the_oracle_mixed_types(tmp_path):
     """The same generator at 1/50 of the length (400,000 variants, 10,000 samples), types 3 / 6 / 7 mixed in one run,
     against the CPU oracle as text."""

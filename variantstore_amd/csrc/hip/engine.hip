@@ -74,9 +74,8 @@ struct EngineOpts {
   bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
   bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
   uint32_t fill_chunk = 0;      // rows per task of the expansion: 0 = by the batch's shape, else 8 / 16 / 32 / 64
-  int fill_mode = 0;            // shared expansion: 0 one task per wave, 1 resident waves pulling tasks, 2 split (lists + rows, then the dense sites)
+  int fill_mode = 0;            // shared expansion: 0 one launch, 2 split (lists + rows, then the dense sites: what a profiler wants to see apart)
   uint32_t fill_dense_k = 16;   // dense sites per wave of k_fill_dense: 8 / 16 / 32 / 64
-  uint32_t fill_waves = 8;      // fill_mode 1: resident waves per SIMD the grid is sized for
   bool fill_stats = false;      // device-clock ticks per phase of the expansion's tasks (k_fill_sites2)
   int sc_group = 1;             // lanes per region of the walks of query types 2 / 3 / 5: 1, or 8 lanes running the same chain
   bool walk_stats = false;      // iteration counts and device-clock ticks of k_sample_walk
@@ -107,12 +106,15 @@ struct vs_index {
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
   bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
   uint32_t sort_probe_in = 0;
+  uint64_t seq_cap_hint[2] = {0, 0};        // the same for the piece lists of query types 2 / 3
+  uint64_t walk_cap_hint[2] = {0, 0};       // scratch entries the last type-4 / type-5 batch's recording walk needed (+ 1/8): the next batch's allocation
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
   bool batch_in_flight = false;             // a batch returned when it was enqueued (async_submit) and nothing has synchronised the stream since
   hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the events collect_timing reads: the handle's own (ev[]) or, for a
                                             // lean batch, the result's pair around its expansion (timing_owner)
   vs_result* timing_owner = nullptr;
+  bool timing_total_only = false;           // ... and recorded only its first and last event (query types 2 / 3)
   bool timing_pending = false;              // the last batch returned before its kernels had finished: vs_index_last_timing reads the events then
   uint64_t timing_fill_launches = 0;
   std::vector<hipEvent_t> ev_pool;          // timing events of results (two per shared batch), reused between results
@@ -574,7 +576,6 @@ static void read_env_opts(vs_index* idx) {
   if (getenv("VS_SYNC_SUBMIT")) o.async_submit = false;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
-  if (const char* fm = getenv("VS_FILL_MODE")) o.fill_mode = std::max(0, std::min(2, atoi(fm)));
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 #ifdef VS_TUNING
   o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
@@ -684,6 +685,12 @@ static int collect_timing(vs_index* idx) {
   idx->timing_owner = nullptr;
   HIP_TRY(hipEventSynchronize(e[4]));
   HIP_TRY(hipEventElapsedTime(&t.ms_total, e[0], e[4]));
+  if (idx->timing_total_only) {   // (a sequence batch records its first and last event only)
+    idx->timing_total_only = false;
+    t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
+    t.fill_launches = 0;
+    return VS_OK;
+  }
   HIP_TRY(hipEventElapsedTime(&t.ms_bounds, e[0], e[1]));
   HIP_TRY(hipEventElapsedTime(&t.ms_scan, e[1], e[2]));
   HIP_TRY(hipEventElapsedTime(&t.ms_emit, e[2], e[3]));
@@ -866,22 +873,13 @@ static int read_device_words(vs_index* idx, const uint64_t* a, uint64_t* va, con
   return VS_OK;
 }
 
-// The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).  mode 0: one task per wave; 1: resident
-// waves pulling tasks from `counters` (zeroed by the caller); 2: split -- rows + listed variants here, the dense sites of the
-// index the batch covers in k_fill_dense behind it.
+// The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).  mode 2 (tuning builds): split -- rows +
+// listed variants here, the dense sites of the index the batch covers in k_fill_dense behind it.
 template <bool WIDE, bool TUNE>
 static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, const uint32_t* coarse, uint64_t n_runs, uint64_t U, uint32_t chunk,
-                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, int mode, uint32_t* counters) {
+                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, int mode) {
   const unsigned blocks = (unsigned)(((U + chunk - 1) / chunk + 3) / 4);
-  if (mode == 1) {
-    const unsigned rb = std::min<unsigned>(blocks, 256u * idx->opts.fill_waves);
-    switch (chunk) {
-      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 16, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
-      case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 64, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
-      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2_resident<WIDE, 32, true>), dim3(rb), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, gt_words, counters); break;
-    }
-    return;
-  }
+#ifdef VS_TUNING
   if (mode == 2) {
     switch (chunk) {
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
@@ -901,6 +899,7 @@ static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, 
     }
     return;
   }
+#endif
   switch (chunk) {
     case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
     case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
@@ -921,7 +920,7 @@ static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, 
 static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
                             bool allow_async) {
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
-  idx->timing_pending = false; idx->timing_owner = nullptr;   // (an earlier lean batch's event pair is not this batch's)
+  idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;   // (an earlier lean batch's event pair is not this batch's)
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1116,15 +1115,10 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     }
 #endif
     const int mode = idx->opts.fill_mode;
-    uint32_t* counters = nullptr;
-    if (mode == 1) {
-      VS_TRY(dev_alloc(idx, kTaskShards * kTaskShardStride * 4, (void**)&counters, &scratch.bufs));
-      HIP_TRY(hipMemsetAsync(counters, 0, kTaskShards * kTaskShardStride * 4, idx->stream));
-    }
     VS_TRY(result_events(r));   // the kernel's own duration, whenever the result is asked for it (vs_result_fill_ms)
     HIP_TRY(hipEventRecord(r->ev_fill[0], idx->stream));
-    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, counters);
-    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, counters);
+    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode);
+    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(r->ev_fill[1], idx->stream));
     r->pending = true;
@@ -1227,7 +1221,7 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
   vs_result* r = c.r;
   const uint64_t n = c.n;
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
-  idx->timing_pending = false; idx->timing_owner = nullptr;
+  idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1313,9 +1307,23 @@ static int batch_fill(BatchCtx& c, bool allow_async) {
   return VS_OK;
 }
 
-static int batch_finish(BatchCtx& c) {
+// enqueued: the batch returns when its last kernel is launched (the walking query types under async_submit): its temporaries stay
+// with the result until the completion event recorded here, everything that reads the result is ordered behind it on the
+// handle's stream, and the phase times are read from the handle's events when somebody asks (vs_index_last_timing)
+static int batch_finish(BatchCtx& c, bool enqueued = false) {
   vs_index* idx = c.idx;
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  if (enqueued) {
+    vs_result* r = c.r;
+    VS_TRY(pooled_event(idx, &r->ev_done));
+    HIP_TRY(hipEventRecord(r->ev_done, idx->stream));
+    r->pending = true;
+    idx->batch_in_flight = true;
+    r->bufs.insert(r->bufs.end(), c.scratch.bufs.begin(), c.scratch.bufs.end());
+    c.scratch.bufs.clear();
+    idx->timing_pending = true;
+    return VS_OK;
+  }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   idx->batch_in_flight = false;
   if (c.async_fill) { c.r->bufs.insert(c.r->bufs.end(), c.scratch.bufs.begin(), c.scratch.bufs.end()); c.scratch.bufs.clear(); }
@@ -1406,7 +1414,19 @@ static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) 
 //          (cooperative, serial with jumps, or literal: option t4_walk); a region that outgrows its capacity -- not seen
 //          in practice; option force_fallbacks -- sends the batch down the count-then-emit pair of walks
 //   claims one carrier list per reported VERTEX, shared by the rows that report it (k_t4_claim)
+static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode,
+                               bool speculate, bool* refused);
+// ONE host wait per batch (round 5): the recording walk's scratch is sized from the handle's previous batch of the kind; a batch
+// that does not fit is refused on the device (k_walk_admit) and redone here with the exact size -- the first batch of a handle
+// and a batch 12 % bigger than any before it pay the second wait, a steady stream of batches never does.
 static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode) {
+  bool refused = false;
+  VS_TRY(run_walk_batch_once(idx, regions, n, r, sample_id, sample_ids, walk_mode, true, &refused));
+  if (!refused) return VS_OK;
+  return run_walk_batch_once(idx, regions, n, r, sample_id, sample_ids, walk_mode, false, &refused);
+}
+static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode,
+                               bool speculate, bool* refused) {
   BatchCtx c(idx, r, n);
   VS_TRY(batch_setup(c, regions, false, sample_ids));
   DevResult& d = r->d;
@@ -1414,7 +1434,8 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
   const uint32_t* dsids = c.dsids;
   WalkScratch ws{};
   uint64_t ws_capacity = 0;
-  bool single_walk = false;
+  bool single_walk = false, speculative = false;
+  const uint64_t* cap_total_dev = nullptr;
   DevImage dwalk = idx->d;   // what the type-4 walk sees: with or without the event bitmaps
   if (idx->opts.t4_walk == 0) dwalk.t4_events = nullptr;
   auto counting_walk = [&]() {
@@ -1433,8 +1454,15 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch.bufs));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch.bufs));
     uint64_t cap_total = 0, bad = 0;
-    VS_TRY(read_device_words(idx, cap_begin + n, &cap_total, c.bad_ids, &bad));
-    if (bad) return bad_ids_error(idx);
+    uint64_t& hint = idx->walk_cap_hint[walk_mode == 5 ? 1 : 0];
+    speculative = speculate && hint > 0 && idx->opts.async_submit;
+    if (speculative) cap_total = hint;   // (k_walk_admit, below, holds the batch to it)
+    else {
+      VS_TRY(read_device_words(idx, cap_begin + n, &cap_total, c.bad_ids, &bad));
+      if (bad) return bad_ids_error(idx);
+      hint = cap_total + cap_total / 8 + 1024;
+    }
+    cap_total_dev = cap_begin + n;
     ws_capacity = cap_total;
     ws.cap_begin = cap_begin;
     VS_TRY(dev_alloc(idx, cap_total * 8 + 8, (void**)&ws.pos, &scratch.bufs));
@@ -1445,6 +1473,7 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch.bufs));
     VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch.bufs));
     HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
+    if (speculative) hipLaunchKernelGGL(k_walk_admit, dim3(1), dim3(1), 0, idx->stream, (const uint64_t*)cap_total_dev, cap_total, (const uint64_t*)c.bad_ids, ws.overflow);
 #ifdef VS_TUNING
     if (idx->opts.walk_stats) {
       VS_TRY(dev_alloc(idx, 128, (void**)&ws.stats, &scratch.bufs));
@@ -1500,8 +1529,21 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, lc);
     share_t4 = true;
   }
-  // the walk's overflow flag and the claims' arena total (the scan's totals are in mapped memory already)
-  VS_TRY(read_device_words(idx, single_walk ? ws.overflow : nullptr, &walk_overflow, share_t4 ? lc.own_base + n : nullptr, &t4_arena));
+  // the walk's overflow flag, the claims' arena total and what the capacities added up to (the scan's totals are in mapped memory
+  // already): THE host wait of a batch whose scratch was sized from the one before
+  uint64_t cap_seen = 0;
+  VS_TRY(read_device_words(idx, single_walk ? ws.overflow : nullptr, &walk_overflow, share_t4 ? lc.own_base + n : nullptr, &t4_arena,
+                           speculative ? cap_total_dev : nullptr, &cap_seen));
+  if (speculative) {
+    uint64_t& hint = idx->walk_cap_hint[walk_mode == 5 ? 1 : 0];
+    if (walk_overflow == 3) return bad_ids_error(idx);
+    if (walk_overflow == 2) {   // refused: the caller redoes the batch with the exact size (and the next batches get the bigger scratch)
+      hint = cap_seen + cap_seen / 8 + 1024;
+      *refused = true;
+      return VS_OK;
+    }
+    if (cap_seen < hint / 4) hint = cap_seen + cap_seen / 8 + 1024;   // (batches have become much smaller: so does the scratch)
+  }
   uint64_t rows = 0, arena = 0;
   batch_totals(c, &rows, &arena);
   if (share_t4 && !walk_overflow) arena = t4_arena;
@@ -1529,7 +1571,8 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
     HIP_TRY(hipGetLastError());
   }
   VS_TRY(batch_fill(c, false));
-  return batch_finish(c);
+  // the batch is enqueued: return (async_submit), unless a tuning aid wants the host in the loop
+  return batch_finish(c, idx->opts.async_submit && single_walk && !idx->opts.walk_stats && !idx->opts.lat_debug);
 }
 
 template <typename T>
@@ -1615,11 +1658,19 @@ static int fetch_headers(vs_result* r) {
   return VS_OK;
 }
 
-// Query types 2 and 3: count pieces and bytes per region, scan, emit the piece list, decode it.
+// Query types 2 and 3: count pieces and bytes per region, scan, emit the piece list, decode it.  ONE host wait per batch
+// (the byte total): the piece list is sized from the handle's previous batch of the type, as the walking types' scratch is.
+static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r, bool speculate, bool* refused);
 static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r) {
+  bool refused = false;
+  VS_TRY(run_sample_seq_once(idx, regions, n, sample_ids, mode, r, true, &refused));
+  if (!refused) return VS_OK;
+  return run_sample_seq_once(idx, regions, n, sample_ids, mode, r, false, &refused);
+}
+static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r, bool speculate, bool* refused) {
   DevSeqResult& q = r->sq;
   if (idx->srv_alive) VS_TRY(server_stop(idx));
-  idx->timing_pending = false; idx->timing_owner = nullptr;
+  idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;
   q.Q = n;
   r->d.Q = n;
   uint64_t* dreg = nullptr;
@@ -1655,8 +1706,16 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
     uint64_t bad = 0;
-    VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0], bad_ids, &bad));
-    if (bad) return bad_ids_error(idx);
+    uint64_t& hint = idx->seq_cap_hint[mode == 3 ? 1 : 0];
+    const bool speculative = speculate && hint > 0 && idx->opts.async_submit;
+    if (speculative) {
+      totals[0] = hint;
+      hipLaunchKernelGGL(k_walk_admit, dim3(1), dim3(1), 0, idx->stream, (const uint64_t*)(q.seg_begin + n), hint, (const uint64_t*)bad_ids, q.overflow);
+    } else {
+      VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0], bad_ids, &bad));
+      if (bad) return bad_ids_error(idx);
+      hint = totals[0] + totals[0] / 8 + 1024;
+    }
     VS_TRY(ralloc(r, totals[0], &q.seg_src));
     VS_TRY(ralloc(r, totals[0], &q.seg_len));
     VS_TRY(ralloc(r, totals[0], &q.seg_dst));
@@ -1665,8 +1724,13 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     else launch_sample_seq<3, 2>(idx, q, n);
     HIP_TRY(hipGetLastError());
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
-    uint64_t over = 0;
-    VS_TRY(read_device_words(idx, q.byte_begin + n, &totals[1], q.overflow, &over));
+    uint64_t over = 0, cap_seen = 0;
+    VS_TRY(read_device_words(idx, q.byte_begin + n, &totals[1], q.overflow, &over, speculative ? q.seg_begin + n : nullptr, &cap_seen));
+    if (speculative) {
+      if (over == 3) return bad_ids_error(idx);
+      if (over == 2) { hint = cap_seen + cap_seen / 8 + 1024; *refused = true; return VS_OK; }
+      if (cap_seen < hint / 4) hint = cap_seen + cap_seen / 8 + 1024;
+    }
     if (over) { single_walk = false; q.relative = 0; }
     else {
       VS_TRY(ralloc(r, totals[1], &q.chars));
@@ -1697,6 +1761,16 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
     }
   }
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  if (idx->opts.async_submit && single_walk) {   // the batch is enqueued: return; its temporaries stay with the result until its completion event
+    VS_TRY(pooled_event(idx, &r->ev_done));
+    HIP_TRY(hipEventRecord(r->ev_done, idx->stream));
+    r->pending = true;
+    idx->batch_in_flight = true;
+    r->bufs.insert(r->bufs.end(), scratch.bufs.begin(), scratch.bufs.end());
+    scratch.bufs.clear();
+    idx->timing_pending = true; idx->timing_total_only = true;
+    return VS_OK;
+  }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   scratch.release();
   vs_timing& t = idx->timing;
@@ -1811,7 +1885,7 @@ static int run_small_type6(vs_index* idx, const vs_region* regions, uint64_t n, 
     HIP_TRY(hipStreamSynchronize(idx->stream));
   }
   const auto host_enter = std::chrono::steady_clock::now();
-  idx->timing_pending = false; idx->timing_owner = nullptr;
+  idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;
   DevResult& d = r->d;
   uint64_t capA = 0, capS = 0, ntasks = 0;
   for (uint64_t q = 0; q < n; ++q) {
@@ -2153,20 +2227,19 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     if (value < 0 || value > 2) return fail(VS_ERR_ARG, "t4_walk takes 0 (literal), 1 (one lane per region, jumping) or 2 (cooperative, default)");
     o.t4_walk = (int)value;
   } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
-  else if (k == "fill_mode") { if (value < 0 || value > 2) return fail(VS_ERR_ARG, "fill_mode takes 0, 1 or 2"); o.fill_mode = (int)value; }
-  else if (k == "fill_dense_k") { if (value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_dense_k takes 8, 16, 32 or 64"); o.fill_dense_k = (uint32_t)value; }
-  else if (k == "fill_waves") { if (value < 1 || value > 8) return fail(VS_ERR_ARG, "fill_waves takes 1..8"); o.fill_waves = (uint32_t)value; }
-  else if (k == "fill_chunk") {
-    if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
-    o.fill_chunk = (uint32_t)value;
-  }
-  else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
+  else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_mode" || k == "fill_dense_k" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {
 #ifdef VS_TUNING
     if (value < 0) return fail(VS_ERR_ARG, "%s takes a non-negative value", key);
     if (k == "lat_debug") o.lat_debug = value != 0;
     else if (k == "fill_fused") o.fill_fused = value != 0;
     else if (k == "sc_group") o.sc_group = value > 1 ? 8 : 1;
+    else if (k == "fill_chunk") {
+      if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_chunk takes 0 (by the batch's shape), 8, 16, 32 or 64");
+      o.fill_chunk = (uint32_t)value;
+    }
+    else if (k == "fill_mode") { if (value != 0 && value != 2) return fail(VS_ERR_ARG, "fill_mode takes 0 or 2"); o.fill_mode = (int)value; }
+    else if (k == "fill_dense_k") { if (value != 8 && value != 16 && value != 32 && value != 64) return fail(VS_ERR_ARG, "fill_dense_k takes 8, 16, 32 or 64"); o.fill_dense_k = (uint32_t)value; }
     else if (k == "fill_stats") o.fill_stats = value != 0;
     else if (k == "walk_stats") o.walk_stats = value != 0;
     else if (k == "fill_ablate") o.fill_ablate = (uint32_t)value & 7u;

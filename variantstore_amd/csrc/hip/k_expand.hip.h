@@ -330,6 +330,11 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     }
   }
 
+  // The parameter and list phases are the kernel's memory-bound part, the dense phase its VALU- and LDS-bound part (round 5:
+  // profiles/r05_exp_split_pmc.json).  Callers that mix the two (k_fill_sites2) run the former at priority 3 so that a wave's
+  // loads are issued ahead of other waves' peel loops; from here on the wave is an ordinary one again (0.536 -> 0.522 ms on a
+  // fast box, no difference on a slow one: profiles/r05_exp_priorities_box_*.txt; the opposite order costs 1.5 %).
+  __builtin_amdgcn_s_setprio(0);
   if (TUNE && tstat) {   // (tstat: three words of the CALLER's registers -- list phase, dense phase, dense variants)
     __builtin_amdgcn_s_waitcnt(0);   // (the list phase's loads have returned; its stores are on their way)
     tstat[0] = wall_clock64() - t_enter; tstat[2] = (unsigned long long)__popcll(dmask);
@@ -603,6 +608,7 @@ template <bool WIDE, uint32_t CH, bool TUNE, bool DENSE>
 __device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevResult& r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
                                                 uint64_t U, uint64_t u_first, uint32_t lane, uint32_t* lds_wave, uint32_t ablate, uint32_t gt_words,
                                                 unsigned long long* tstat, uint64_t task, uint64_t t_start) {
+  __builtin_amdgcn_s_setprio(3);   // (back to 0 where expand_task's dense phase begins)
   const RowDelta d = shared_row_run(runs, coarse, n_runs, u_first, lane, lane < CH ? lane : 0u);
   const uint64_t u = u_first + lane;
   uint32_t cnt = 0, cls = 0;
@@ -643,34 +649,17 @@ __global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, c
     fill_sites_task<WIDE, CH, TUNE, DENSE>(im, r, runs, coarse, n_runs, U, u_first, lane, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], ablate, gt_words, tstat, wave, t_start);
 }
 
-// The same tasks pulled by RESIDENT waves (experiment, option fill_mode = 1): the grid is what the machine holds, a wave takes
-// task after task from one of eight counters (a block's counter: blockIdx & 7 -- one word saturates near 90 dequeues per
-// microsecond, the launch needs ~300); shard s owns the tasks congruent to s modulo 8.
-constexpr uint32_t kTaskShards = 8, kTaskShardStride = 16;   // counters 64 bytes apart
-template <bool WIDE, uint32_t CH, bool DENSE>
-__global__ void __launch_bounds__(256) k_fill_sites2_resident(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
-                                                              uint64_t U, uint32_t gt_words, uint32_t* __restrict__ counters) {
-  const uint32_t lane = threadIdx.x & 63;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_blk[];
-  const uint32_t lds_words_per_wave = WIDE ? gt_words + kRingWords : slice_lds_words(im.num_samples);
-  uint32_t* lds_wave = &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave];
-  const uint64_t ntasks = (U + CH - 1) / CH;
-  const uint32_t shard = blockIdx.x & (kTaskShards - 1);
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(&counters[shard * kTaskShardStride], 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
-    const uint64_t task = (uint64_t)t * kTaskShards + shard;
-    if (task >= ntasks) break;
-    fill_sites_task<WIDE, CH, false, DENSE>(im, r, runs, coarse, n_runs, U, task * CH, lane, lds_wave, 0u, gt_words, nullptr, task, 0);
-  }
-}
-
-// The DENSE variants of a shared batch in a launch of their own (experiment, option fill_mode = 2): the index keeps the list
+// Tuning builds only (option fill_mode = 2): the DENSE variants of a shared batch in a launch of their own, so that a profiler
+// sees the two regimes of the expansion apart -- round 5's counters: the lists + rows kernel moves its 1.34 GB in 0.21 ms
+// (6.3 TB/s: at the part's ceiling), the dense kernel its 1.33 GB in 0.38 - 0.40 ms with the VALU 60 - 65 % and the LDS
+// pipeline ~70 % busy (profiles/r05_exp_split_pmc.json); one after the other they take 0.59 ms where the mixed kernel takes
+// 0.51, so the mixed kernel stays.  (Also tried and removed: resident waves pulling tasks from eight counters, 0.545 - 0.56
+// against 0.505 ms -- the dispatcher is not what holds the kernel back.)  The index keeps the list
 // of its dense sites (more than list_max carriers: DevImage::dense_site); a wave owns K consecutive entries of that list,
 // its lanes look their sites up in the batch's runs -- covered or not, which row, which arena offset -- and the wave expands
 // the covered ones one after the other, rows requested two variants ahead and nibbles one, K deep instead of the two or
 // three a mixed task holds.  k_fill_sites2<..., DENSE = false> writes the rows and everything else.
+#ifdef VS_TUNING
 template <bool WIDE, uint32_t K>
 __global__ void __launch_bounds__(256) k_fill_dense(DevImage im, DevResult r, const RunRec* __restrict__ runs, uint64_t n_runs, uint64_t U, uint32_t gt_words) {
   const uint32_t lane = threadIdx.x & 63;
@@ -703,5 +692,6 @@ __global__ void __launch_bounds__(256) k_fill_dense(DevImage im, DevResult r, co
   if (__ballot(cnt != 0) == 0) return;
   expand_task<WIDE, true, false, false, true>(im, r.carriers, &lds_blk[(threadIdx.x >> 6) * lds_words_per_wave], lane, cnt, cls, gt0, cb, 0u, gt_words);
 }
+#endif
 
 }  // namespace vsamd

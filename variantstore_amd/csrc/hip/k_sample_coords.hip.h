@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_walk_sc(DevImage 
   constexpr bool EMIT = MODE == 1;
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
   const bool lead = (threadIdx.x % SUB) == 0;
+  if (MODE == 2 && walk_void(r, ws, q, lead)) return;
   if (q >= r.Q) return;
   const uint32_t sid = sid_per_region[q];
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
@@ -425,6 +426,14 @@ struct DevSeqResult {
   uint64_t* overflow;               // single-walk mode: set when a region outgrew its piece capacity
   uint32_t relative, pad_;          // single-walk mode: pieces sit at seg_begin[q] .. + q_nseg[q], seg_begin = capacities' scan
 };
+
+// a batch whose piece list was sized from the previous batch and does not fit (k_walk_admit set overflow to 2, or 3 for a
+// sample id out of range) records nothing: no pieces, no bytes
+__device__ __forceinline__ bool seq_void(const DevSeqResult& r, uint64_t q, bool writer) {
+  if (!r.overflow || *r.overflow < 2) return false;
+  if (writer && q < r.Q) { r.q_nseg[q] = 0; r.q_nbytes[q] = 0; }
+  return true;
+}
 
 // PASS 0 counts, PASS 1 writes the pieces at their scanned places (second walk), PASS 2 is the single walk: pieces go
 // to the region's slice of a capacity-sized list with byte offsets relative to the region's first byte.
@@ -585,6 +594,7 @@ __device__ __forceinline__ uint8_t seq_walk_region(const DevImage& im, const Dev
 template <int MODE, int PASS, uint32_t SUB = kScGroup>
 __global__ void __launch_bounds__(SUB > 1 ? 256 : 64) k_sample_seq(DevImage im, DevSeqResult r) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  if (PASS == 2 && seq_void(r, q, (threadIdx.x % SUB) == 0)) return;
   if (q >= r.Q) return;
   if (PASS == 1 && r.q_flags[q]) return;
   const uint32_t sid = r.sids[q];
@@ -653,6 +663,7 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
   constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
   const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  if (seq_void(r, q, l == 0)) return;
   const bool live = q < r.Q;
   uint32_t sid = 0;
   uint64_t x = 0, y = 0, seg0 = 0, cap = 0;
@@ -862,6 +873,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
   const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  if (walk_void(r, ws, q, l == 0)) return;
   const bool live = q < r.Q;
   uint32_t sid = 0;
   uint64_t x = 0, y = 0, s0 = 0, scap = 0;

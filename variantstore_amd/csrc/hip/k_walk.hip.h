@@ -151,7 +151,9 @@ struct WalkScratch {
   const uint64_t* cap_begin;   // [Q+1] exclusive scan of the capacities
   uint64_t* pos;
   uint32_t *cur, *ro, *rl, *ao, *al;
-  uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path)
+  uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path); 2 / 3 BEFORE the
+                               // walk starts (k_walk_admit): the scratch was sized from the previous batch and this one needs more / a
+                               // sample id of the batch is out of range -- the recording walks then record nothing (walk_void)
   unsigned long long* stats;   // tuning builds (VS_TUNING): 16 counters of k_sample_walk (iteration counts, device-clock ticks); else NULL
 };
 #ifdef VS_TUNING
@@ -163,6 +165,22 @@ struct WalkScratch {
 #define VS_WALK_STATMAX(i, v) do { } while (0)
 #define VS_WALK_CLOCK() 0ULL
 #endif
+
+// Round 5: the walking query types wait for the host ONCE per batch.  The scratch of the recording walk is sized from what the
+// handle's previous batch of the kind needed (+ 1/8); k_walk_admit, behind the capacities' scan, compares the scan's total with
+// that allocation and refuses the batch (overflow = 2) when it does not fit -- or when k_check_sample_ids found an id out of
+// range (3) -- and the recording walks, k_t4_claim and the emitters then touch nothing beyond the per-region arrays: the host
+// reads the word together with the batch's sizes and redoes a refused batch with an exact allocation (one more wait, once).
+__global__ void k_walk_admit(const uint64_t* cap_total, uint64_t cap_alloc, const uint64_t* bad_ids, uint64_t* overflow) {
+  if (bad_ids && *bad_ids) *overflow = 3;
+  else if (*cap_total > cap_alloc) *overflow = 2;
+}
+// first thing in a recording walk: a refused batch reports no rows (its regions' capacities are what the bounds left in q_nvar)
+__device__ __forceinline__ bool walk_void(const DevResult& r, const WalkScratch& ws, uint64_t q, bool writer) {
+  if (!ws.overflow || *ws.overflow < 2) return false;
+  if (writer && q < r.Q) { r.q_nvar[q] = 0; r.q_ncar[q] = 0; r.var_count[q] = 0; }
+  return true;
+}
 
 // What get_sample_var_in_ref reports for a vertex on the sample's path (query.h:680-704), from the walk's state at that
 // vertex: kind 0 insertion (ref_pos == next_ref_pos), 1 deletion (the vertex is a ref vertex: ref = sequence of
@@ -545,6 +563,7 @@ __global__ void __launch_bounds__(64) k_sample_walk(DevImage im, DevResult r, ui
                                                     WalkScratch ws) {
   constexpr bool EMIT = MODE == 1;
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (MODE == 2 && walk_void(r, ws, q, true)) return;
   if (q >= r.Q) return;
   WalkCtx cx{sid_per_region ? sid_per_region[q] : sid_all, r.regions[2 * q], r.regions[2 * q + 1], false, 0, 0};
   // Event and hold rows of this sample (DevImage::t4_events, t4_hold): clear event bits are ref-path slots where neither
@@ -792,6 +811,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   constexpr uint32_t kGroupMask = (1u << SUB) - 1u;
   const uint32_t lane = threadIdx.x & 63, l = lane & (SUB - 1), gbase = lane & (64 - SUB);
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+  if (walk_void(r, ws, q, l == 0)) return;
   const bool live = q < r.Q;
   WalkCtx cx{0, 0, 0, false, 0, 0};
   if (live) { cx.sid = sid_per_region ? sid_per_region[q] : sid_all; cx.x = r.regions[2 * q]; cx.y = r.regions[2 * q + 1]; }
@@ -1005,7 +1025,7 @@ constexpr uint64_t kClaimRowMask = (1ULL << 40) - 1;
 __global__ void __launch_bounds__(256) k_t4_claim(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {
   const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const bool live = q < r.Q;
-  uint64_t n = live ? r.q_nvar[q] : 0;
+  uint64_t n = live ? r.q_nvar[q] : 0;   // (a refused batch: the walk left zeros)
   const uint64_t a0 = live ? r.var_begin[q] : 0, s0 = live ? ws.cap_begin[q] : 0;
   // a region that outgrew its scratch capacity recorded only the first rows (ws.overflow is set and the host redoes the
   // batch with the two-walk path): nothing beyond the capacity may be read here
