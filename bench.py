@@ -248,6 +248,22 @@ def committed_traffic(workload, nreg_matches):
     return t
 
 
+def box_ceilings():
+    """What plain streaming kernels reach on THIS box in THIS run (tools/microbench/hbm_ceiling --quick, a child process, before
+    this process touches the GPU): a 1:1 copy and the expansion's own 2 bytes read : 3 written mix with non-temporal stores, 1 GiB
+    per stream.  The mix moves between boxes and runs (5.4 - 6.4 TB/s seen), and the expansion kernel's time with it."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "microbench", "hbm_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--quick"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except Exception:
+        return None
+
+
 def spawn_ranks(ngpus):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a torch.distributed.run child and
     relay its JSON line.  Nothing in THIS process has touched the GPU yet (device_count() does not initialise it)."""
@@ -532,6 +548,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    ceil = box_ceilings() if int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1099,6 +1116,11 @@ def main():
                          # what a plain streaming kernel with THIS kernel's traffic shape (2 bytes read : 3 written, non-temporal
                          # 16-byte stores) reaches on the part: 6.4 TB/s (tools/microbench/hbm_ceiling.hip, profiles/r04_hbm_ceiling.txt)
                          "frac_of_measured_mix_ceiling_6400": achieved / HBM_MIX_CEILING_GBPS,
+                         # the same two ceilings measured on THIS box just before this run (tools/microbench/hbm_ceiling --quick)
+                         "box_ceilings": ceil,
+                         "frac_of_box_mix_ceiling": (achieved / ceil["mix_2to3_GBps"]) if ceil and ceil.get("mix_2to3_GBps") else None,
+                         "frac_alone_of_box_mix_ceiling": (achieved * (fill_ms / args.steps) / alone_ms / ceil["mix_2to3_GBps"])
+                                                          if ceil and ceil.get("mix_2to3_GBps") and alone_ms > 0 else None,
                          "layout": {"bytes_per_launch": fill_bytes_layout, "GBps": layout_gbps, "frac": layout_gbps / HBM_PEAK_GBPS,
                                     "note": "bytes the data layout obliges the kernel to move (DESIGN.md section 5)"},
                          "survey_formula": {"bytes_per_launch": fill_bytes_survey, "GBps": survey_gbps,

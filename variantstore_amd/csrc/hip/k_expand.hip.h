@@ -444,10 +444,34 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         //  the lane's cursor, ceil(sb / 4) steps whatever the popcount.  A store that is only 2-byte aligned is legal on
         //  gfx950 but the LDS takes it one LANE at a time: 64 cycles per wave-instruction against 5.6 for ds_write_b16 and
         //  7.2 for an aligned ds_write_b64 (tools/microbench/lds_store.hip); the kernel went from 0.51 to 0.59 ms.)
+#ifdef VS_PEEL_SINGLE   // (rounds 2-4: one id, one ds_write_b16 per iteration -- as many iterations as the fullest lane has bits)
         while (bits) {
           ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
           bits &= bits - 1;
         }
+#else
+        // Two ids per iteration, one aligned ds_write_b32: the LDS store pipeline takes 5.6 cycles per ds_write_b16 and 6.5 per
+        // ds_write_b32 (tools/microbench/lds_store.hip) and is ~70 % busy in this phase (profiles/r05_exp_split_pmc.json), so
+        // pairs halve what the peel asks of it, and the loop's scalar bookkeeping with it.  A lane whose cursor is odd writes its
+        // first id alone, a lane with one bit left its last.
+        {
+          if ((j & 1u) && bits) {
+            ids16[j++] = (uint16_t)(idb + __builtin_ctz(bits));
+            bits &= bits - 1;
+          }
+          uint32_t* pair = reinterpret_cast<uint32_t*>(ids16 + j);     // (j is even here for every lane that has bits left)
+          uint32_t idbpk = idb * 0x10001u;
+          asm volatile("" : "+v"(idbpk));                               // (kept out of the loop: the compiler otherwise rebuilds it per iteration)
+          uint32_t t = bits & (bits - 1);
+          while (t) {                                                   // at least two bits left
+            const uint32_t w = ((uint32_t)__builtin_ctz(bits) | ((uint32_t)__builtin_ctz(t) << 16)) + idbpk;
+            *pair++ = w;
+            bits = t & (t - 1);
+            t = bits & (bits - 1);
+          }
+          if (bits) *reinterpret_cast<uint16_t*>(pair) = (uint16_t)(idb + __builtin_ctz(bits));
+        }
+#endif
         // copy-out: lane q of a pass owns list entries 8q..8q+7 (one 16-byte store); their nibbles are 32 consecutive
         // bits of the stream.  Round 0 writes complete groups only, round 1 everything (the range owns its padding).
         const uint32_t flush = round ? ((end + 7u) & ~7u) : (end & ~7u);
