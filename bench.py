@@ -310,6 +310,70 @@ def back_to_back(call, reps):
     return dt
 
 
+def mixed_types_leg(types, vs, comm, rank, world, local_rank, regions, regions_dev, nreg, region_base, counts, num_samples, use_dist):
+    """BASELINE configs[4] ("mixed types 3/6/7 ... 8 x MI355X"; the reference's loop dispatches every type, src/commands.cc:150-193):
+    every rank answers ITS regions with each requested type's entry point, submitted back to back; at N > 1 (or
+    VS_BENCH_FORCE_DIST=1) each batch's per-region summary records are all-gathered through the C ABI's collective.  Regions and
+    sample ids are in device memory (16 samples round-robin); type 7 asks for an A>C substitution at every region's start (nearly
+    always "no such variant": the same walk).  Per type: whole-job regions/s = world x regions per rank / slowest rank's time."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from variantstore_amd import DeviceArray
+    dev = torch.device("cuda", local_rank)
+    sids = np.array([1 + ((i % 16) * 157) % (num_samples - 1) for i in range(nreg)], dtype=np.uint32)
+    sids_t = torch.from_numpy(sids.view(np.int32)).to(dev)
+    reg_d, sid_d = DeviceArray(regions_dev.data_ptr(), nreg), DeviceArray(sids_t.data_ptr(), nreg)
+    positions = np.ascontiguousarray(regions[:, 0])
+    refs7, alts7 = ["A"] * nreg, ["C"] * nreg
+    calls = {6: lambda: vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg),
+             4: lambda: vs.get_sample_var_in_ref(reg_d, sid_d),
+             5: lambda: vs.get_sample_var_in_sample(reg_d, sid_d),
+             2: lambda: vs.query_sample_seq(reg_d, sid_d, sample_coordinates=False),
+             3: lambda: vs.query_sample_seq(reg_d, sid_d, sample_coordinates=True),
+             7: lambda: vs.samples_has_var(positions, refs7, alts7)}
+    max_n = max(int(c) for c in counts)
+    gathered = torch.empty((world * max_n, 4), dtype=torch.int64, device=dev) if comm is not None else None
+    out = {}
+    for t in types:
+        def one():
+            r = calls[t]()
+            if comm is not None:
+                comm.allgather_regions(r, region_base, max_n, gathered.data_ptr(), async_op=False)
+            return r
+        prev = one()
+        nxt = one()
+        prev.close()
+        prev = nxt
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _k in range(reps):
+            nxt = one()
+            prev.close()
+            prev = nxt
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dt = float(el.item()) / reps
+        entry = {"queries_per_s": world * nreg / dt, "ms_per_batch": dt * 1e3, "regions_per_rank": nreg}
+        if comm is not None:   # what came back: this rank's own records, as gathered
+            mine = gathered.view(world, max_n, 4)[rank, :nreg].cpu().numpy().view(np.uint64)
+            entry["gathered_region_ids_ok"] = bool(np.array_equal(mine[:, 0], np.arange(region_base, region_base + nreg, dtype=np.uint64)))
+            if t in (2, 3):
+                entry["bases_per_region"] = float(mine[:, 3].mean())
+            else:
+                entry["variants_per_region"] = float((mine[:, 2] >> np.uint64(32)).mean())
+        prev.close()
+        out[f"type{t}"] = entry
+    out["note"] = ("every rank its own regions, each type submitted back to back" + ("; per-region summary records all-gathered through vs_comm_* after "
+                   "every batch (synchronous)" if comm is not None else "") + "; type 7's strings are built on the host per call")
+    return out
+
+
 def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nreg, region_base, counts, strong, torch_collective, step, fence,
                      in_flight):
     """What the N > 1 line says about the collective itself, outside the headline's timed region:
@@ -524,6 +588,10 @@ def main():
                     help="comma list of the untimed legs to run: t4,points,sc,delivery,resident,cli,pipelined | all (= all but cli and pipelined, "
                          "which run by name only) | none")
     ap.add_argument("--skip-extras", action="store_true", help="same as --extras none")
+    ap.add_argument("--types", default="", metavar="LIST",
+                    help="mixed-type leg (BASELINE configs[4]: types 3 / 6 / 7 over N GPUs; src/commands.cc:150-193 dispatches all seven): comma list "
+                         "out of 2,3,4,5,6,7 -- every rank answers its shard with each type's entry point and, at N > 1, the per-region "
+                         "summary records are all-gathered through vs_comm_*; per-type whole-job regions/s under `mixed_types`")
     ap.add_argument("--async-fill", action="store_true",
                     help="headline loop with the engine's pipelined expansion (option async_fill): step k's carrier expansion runs beside step "
                          "k + 1's bounds, scans and rows.  Off by default: the expansion kernel then shares the machine and its own duration -- "
@@ -594,7 +662,10 @@ def main():
         total_regions = world * nreg
         counts = [nreg] * world
     t_build = time.perf_counter()
-    vs = VariantStore.synthetic(device=local_rank, **synth_kwargs(w))
+    mixed = sorted({int(t) for t in args.types.split(",") if t.strip()})
+    if any(t not in (2, 3, 4, 5, 6, 7) for t in mixed):
+        raise SystemExit("--types takes a comma list out of 2,3,4,5,6,7")
+    vs = VariantStore.synthetic(device=local_rank, sample_coordinates=any(t in (2, 3, 5) for t in mixed), **synth_kwargs(w))
     t_build = time.perf_counter() - t_build
     info = vs.info()
     # the batch's input is resident in HBM before the timed region starts (uploaded once); VS_BENCH_HOST_REGIONS=1 hands
@@ -722,6 +793,11 @@ def main():
     if use_dist:
         dist_info = distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nreg, region_base, counts, strong,
                                      torch_collective, step, fence, in_flight)
+
+    mixed_info = None
+    if mixed:
+        mixed_info = mixed_types_leg(mixed, vs, comm if use_dist else None, rank, world, local_rank, regions, regions_dev, nreg, region_base, counts,
+                                     info.num_samples, use_dist)
 
     # ---- result-derived figures of one batch (last step's result is still alive) ----
     nq, nvar, ncar, nbases = res.totals()
@@ -1143,6 +1219,7 @@ def main():
             "rccl_ranks": (dist_info or {}).get("rccl_ranks"), "gathered_ok": (dist_info or {}).get("gathered_ok"),
             "strong": (dist_info or {}).pop("strong", None) if dist_info else None,
             "distributed": dist_info,
+            "mixed_types": mixed_info,
             "emulated_shard": ({"shard": emu[0], "of": emu[1], "regions_in_shard": nreg, "batch_regions": (args.regions or 1_000_000),
                                 "ms_per_step": elapsed / args.steps * 1e3,
                                 "predicted_value_at_n_gpus": (args.regions or 1_000_000) * args.steps / elapsed,

@@ -291,7 +291,11 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
  * its range of the position-ordered site table.  n_regions records of 4 x uint64 in DEVICE memory:
  *   {region_base+q, first_site | region_flags<<32 | has_dropped<<40, sites | variants reported<<32, carriers}.
  * (A region with has_dropped set lost entries to the reference's duplicate rule: fewer variants reported than
- * sites; vs_query_expand_site_ranges applies the rule again.)  device_dst == NULL only reports the record count. */
+ * sites; vs_query_expand_site_ranges applies the rule again.)  device_dst == NULL only reports the record count.
+ * Results of the other query types pack per-region SUMMARIES in the same 32 bytes -- what the reference's driver prints
+ * per region (src/commands.cc:150-193) and what a sharded run gathers: types 4, 5, 1, 7 the same fields (flags incl.
+ * VS_REGION_NOT_FOUND of the point queries, variants reported, carriers; the site fields mean nothing there); types 2, 3
+ *   {region_base+q, region_flags<<32, pieces, bytes of the sequence}. */
 int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records);
 void vs_result_free(vs_result* r);

@@ -216,3 +216,50 @@ def test_query_nprocs_form_matches_the_single_process(golden_dir, tmp_path):
         assert len(lines) == 120 and len(msgs) == 120
         got.append((lines, msgs, open(bfile).read()))
     assert got[0] == got[1]
+
+
+@pytest.mark.gpu
+def test_query_nprocs_form_for_every_query_type(golden_dir, tmp_path):
+    """`--nprocs 1` for the other six query types (BASELINE configs[4] mixes 3 / 6 / 7; src/commands.cc:150-193 dispatches all
+    seven): the rank answers its shard with the type's own entry point, the per-region SUMMARY records (vs_result_pack_regions:
+    counts and flags for row results, pieces and bytes for sequences) go through vs_comm_*, rank 0 prints every region's log
+    lines from the gathered records -- same messages, same --batch-out text, same -o file as the single-process form."""
+    d = str(tmp_path / "ser")
+    os.makedirs(d)
+    out = subprocess.run([CLI, "construct", "-r", os.path.join(golden_dir, "x.small.fa"), "-v",
+                          os.path.join(golden_dir, "g4.vcf"), "-p", d], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    rfile = str(tmp_path / "regions.txt")
+    with open(rfile, "w") as f:
+        for i in range(30):
+            f.write(f"{1 + 2 * i}:{1 + 2 * i + 12 + (i % 4) * 9}\n")
+    pfile = str(tmp_path / "points.txt")
+    pts = [9, 20, 54, 39, 8, 21, 60, 70, 9, 20]
+    with open(pfile, "w") as f:
+        f.write("".join(f"{p}\n" for p in pts))
+    # (-a/-b pair with the SORTED positions, commands.cc:91,185: 8 9 9 20 20 21 39 54 60 70)
+    refs, alts = "G,G,G,T,T,A,T,,C,G", "A,A,C,C,G,C,,AG,T,T"
+    cases = [(["-t", "1", "-r", "@" + pfile], "1. return closest"),
+             (["-t", "7", "-r", "@" + pfile, "-b", refs, "-a", alts], "7. Get samples"),
+             (["-t", "2", "-r", "@" + rfile, "-s", "S2"], "2. Get sample's sequence"),
+             (["-t", "3", "-r", "@" + rfile, "-s", "S10"], "3. Get sample's sequence"),
+             (["-t", "4", "-r", "@" + rfile, "-s", "S1"], "4. Get sample's variants"),
+             (["-t", "5", "-r", "@" + rfile, "-s", "S10"], "5. Get sample's variants")]
+    for args, head in cases:
+        got = []
+        for flag in ([], ["--nprocs", "1"]):
+            bfile, ofile = str(tmp_path / f"b{len(flag)}.txt"), str(tmp_path / f"o{len(flag)}.txt")
+            for fpath in (bfile, ofile):
+                if os.path.exists(fpath):
+                    os.remove(fpath)
+            out = subprocess.run([CLI, "query", "-p", d, "-m", "1", "-o", ofile, "-v", "--batch-out", bfile] + args + flag,
+                                 capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, (args, out.stdout + out.stderr)
+            msgs = [m for m in _msgs(out.stdout) if not re.match(r"Query\d+: ", m) and not m.startswith(("Loading", "Read ", "Graph stats", "Chromosome"))]
+            assert sum(m.startswith(head) for m in msgs) == (len(pts) if args[1] in ("1", "7") else 30), (args, msgs[:5])
+            got.append((msgs, open(bfile).read(), open(ofile).read() if os.path.exists(ofile) else None))
+        assert got[0] == got[1], args
+        assert got[0][2], args      # (the -o file was written by both forms)
+    # a sample the index does not know: every rank stops, the parent reports the failure
+    out = subprocess.run([CLI, "query", "-p", d, "-m", "1", "-t", "4", "-r", "1:30", "-s", "nobody", "--nprocs", "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "Sample not found" in out.stdout + out.stderr

@@ -13,12 +13,14 @@
 //   --device N          GPU ordinal (default 0)
 //   --resident-lists    expand every carrier list of the index once, when it is opened, into an arena that stays in
 //                       HBM (vs_index_set_option "resident_lists"): batches then copy rows only across PCIe
-//   --nprocs N          query type 6 as N PROCESSES, one per GPU (device .. device + N - 1): the parent forks before anything
-//                       touches a GPU, every rank answers its contiguous shard, the ranks all-gather the per-region hit-list
-//                       records through the C ABI's collective (vs_comm_*: RCCL over xGMI; the unique id travels through a
-//                       file) and rank 0 prints the log lines of ALL regions from the gathered records; --batch-out text is
-//                       written per rank and concatenated in rank order.  --ngpus (threads in one process, no collective)
-//                       remains the fallback.
+//   --nprocs N          any query type (1 - 7: the dispatch of src/commands.cc:150-193) as N PROCESSES, one per GPU (device ..
+//                       device + N - 1): the parent forks before anything touches a GPU, every rank answers its contiguous shard
+//                       of the sorted region list, the ranks all-gather the per-region records (counts and flags: what the
+//                       reference prints per region) through the C ABI's collective (vs_comm_*: RCCL over xGMI; the unique id
+//                       travels through a file) and rank 0 prints the log lines of ALL regions from the gathered records;
+//                       --batch-out text is written per rank and concatenated in rank order, -o holds the last region's
+//                       text (the last FOUND position's for types 1 and 7).  A rank that fails ends the others.  --ngpus
+//                       (threads in one process, no collective) remains the fallback.
 //   --ngpus N           shard the sorted region list over GPUs device .. device + N - 1 (query types 4, 5, 6): one handle
 //                       and one host thread per GPU, contiguous shards (the reference's serial loop, commands.cc:145,
 //                       carries no state between regions), results printed in region order
@@ -323,11 +325,25 @@ int draw_main(const Args& a) {
   return EXIT_SUCCESS;
 }
 
-// `--nprocs N`: one process per GPU and the hit-list collective of the C ABI (see the header comment).
+// `--nprocs N`: one process per GPU and the collective of the C ABI (see the header comment), for every query type the
+// reference's loop dispatches (src/commands.cc:150-193).  The sorted region list is cut into contiguous shards, every rank
+// answers its shard with the type's own entry point, the per-region records (vs_result_pack_regions: counts and flags --
+// all the reference prints per region) are all-gathered through vs_comm_*, rank 0 prints the log lines of EVERY region from
+// the gathered records, and the ranks' shards of the --batch-out text are put together by the parent.
 int query_multiproc_main(const Args& a) {
   auto regions = read_regions(a.region);
+  if (a.type < 1 || a.type > 7) {
+    for (size_t i = 0; i < regions.size(); ++i) error("Unsupported query type");  // commands.cc:191
+    return EXIT_SUCCESS;
+  }
   std::vector<vs_region> batch;
   for (auto& r : regions) batch.push_back(vs_region{std::get<0>(r), std::get<1>(r)});
+  std::vector<std::string> refs, alts;
+  if (a.type == 7) {
+    alts = read_sequences(a.alt);
+    refs = read_sequences(a.refseq);
+    if (refs.size() < batch.size() || alts.size() < batch.size()) { error("-a/-b must list one sequence per region"); return EXIT_FAILURE; }
+  }
   const int world = (int)std::min<size_t>((size_t)a.nprocs, std::max<size_t>(batch.size(), 1));
   char tmpl[] = "/tmp/vs_nprocs_XXXXXX";
   if (!mkdtemp(tmpl)) { error("cannot create a temporary directory"); return EXIT_FAILURE; }
@@ -360,6 +376,11 @@ int query_multiproc_main(const Args& a) {
     }
     if (a.resident_lists && vs_index_set_option(idx, "resident_lists", 1) != VS_OK)
       log_line("warning", std::string("--resident-lists: ") + vs_last_error() + " (lists are expanded per batch)");
+    uint32_t sid = 0;
+    if (a.type >= 2 && a.type <= 5 && vs_index_sample_id(idx, a.sample.c_str(), &sid) != VS_OK) {   // variant_graph.h:2010-2013
+      if (rank == 0) error("Sample not found");
+      _exit(EXIT_FAILURE);
+    }
     // the communicator: rank 0 makes the unique id, the others wait for its file
     unsigned char uid[VS_COMM_ID_BYTES];
     if (rank == 0) {
@@ -382,26 +403,48 @@ int query_multiproc_main(const Args& a) {
     if (rc != VS_OK) die(rc, "vs_comm_init");
     size_t lo, hi;
     shard(rank, &lo, &hi);
+    const uint64_t n = hi - lo;
     gettimeofday(&start, nullptr);
     vs_result* res = nullptr;
-    rc = vs_query_var_in_ref(idx, batch.data() + lo, hi - lo, &res);
+    if (a.type == 6) rc = vs_query_var_in_ref(idx, batch.data() + lo, n, &res);
+    else if (a.type == 4) rc = vs_query_sample_var_in_ref(idx, batch.data() + lo, n, sid, &res);
+    else if (a.type == 5) { std::vector<uint32_t> sids(n, sid); rc = vs_query_sample_var_in_sample(idx, batch.data() + lo, n, sids.data(), &res); }
+    else if (a.type == 2 || a.type == 3) { std::vector<uint32_t> sids(n, sid); rc = vs_query_sample_seq(idx, batch.data() + lo, n, sids.data(), a.type == 3 ? 1 : 0, &res); }
+    else {
+      std::vector<uint64_t> positions;
+      for (size_t i = lo; i < hi; ++i) positions.push_back(batch[i].x);
+      if (a.type == 7) {
+        std::vector<const char*> refp, altp;
+        for (size_t i = lo; i < hi; ++i) { refp.push_back(refs[i].c_str()); altp.push_back(alts[i].c_str()); }
+        rc = vs_query_samples_has_var(idx, positions.data(), refp.data(), altp.data(), n, &res);
+      } else rc = vs_query_closest_var(idx, positions.data(), n, &res);
+    }
     if (rc != VS_OK) die(rc, "query");
     std::vector<uint64_t> recs((size_t)world * max_count * 4);
     rc = vs_comm_allgather_regions_host(comm, res, lo, max_count, recs.data());
     if (rc != VS_OK) die(rc, "vs_comm_allgather_regions_host");
+    const bool point = a.type == 1 || a.type == 7;
+    auto own_flags = [&](size_t k) { return (recs[((size_t)rank * max_count + k) * 4 + 1] >> 32) & 0xFF; };
     if (!a.batch_out.empty()) {   // this rank's shard of the text
       std::ofstream out(dir + "/out." + std::to_string(rank));
-      for (size_t k = 0; k < hi - lo; ++k) {
+      for (size_t k = 0; k < n; ++k) {
+        const bool found = !(own_flags(k) & VS_REGION_NOT_FOUND);
+        if (point) out << "#region " << (lo + k) << " " << batch[lo + k].x << (found ? "" : " not-found") << "\n";
+        else out << "#region " << (lo + k) << " " << batch[lo + k].x << ":" << batch[lo + k].y << "\n";
         const char* text; uint64_t len;
-        if (vs_result_format_region(res, k, &text, &len) == VS_OK) {
-          out << "#region " << (lo + k) << " " << batch[lo + k].x << ":" << batch[lo + k].y << "\n";
-          out.write(text, len);
-        }
+        if ((!point || found) && vs_result_format_region(res, k, &text, &len) == VS_OK) out.write(text, len);
       }
     }
-    if (a.verbose && hi == batch.size() && hi > lo) {   // the -o file holds the last region (query.h:774-781)
+    if (a.verbose) {   // the -o file: the last region's text (query.h:774-781) -- the last FOUND one for the point queries; a rank that
+                       // holds a candidate leaves it for the parent, which keeps the highest rank's
+      size_t last = n;
+      for (size_t k = n; k-- > 0;)
+        if (!point || !(own_flags(k) & VS_REGION_NOT_FOUND)) { last = k; break; }
       const char* text; uint64_t len;
-      if (vs_result_format_region(res, hi - lo - 1, &text, &len) == VS_OK) { std::ofstream out(a.outfile); out.write(text, len); }
+      if (last < n && (point || hi == batch.size()) && vs_result_format_region(res, last, &text, &len) == VS_OK) {
+        std::ofstream out(dir + "/last." + std::to_string(rank));
+        out.write(text, len);
+      }
     }
     int status = EXIT_SUCCESS;
     if (rank == 0) {   // the log lines of every region, from the gathered records
@@ -409,13 +452,35 @@ int query_multiproc_main(const Args& a) {
       for (int k = 0; k < world && status == EXIT_SUCCESS; ++k) {
         size_t klo, khi;
         shard(k, &klo, &khi);
-        for (size_t j = 0; j < khi - klo; ++j) {
+        for (size_t j = 0; j < khi - klo && status == EXIT_SUCCESS; ++j) {
           const uint64_t* rec = &recs[((size_t)k * max_count + j) * 4];
           const uint64_t i = rec[0], flags = (rec[1] >> 32) & 0xFF, nvar = rec[2] >> 32;
-          info("6. Get variants in ref coordinate. " + std::to_string(i));
-          if (flags & VS_REGION_INVALID) { error("Can't find node corresponding to pos " + std::to_string(batch[i].x)); status = EXIT_FAILURE; break; }
-          const char* label = !(flags & VS_REGION_EMPTY) ? "get_var_in_ref" : "get_sample_var_in_ref";   // query.h:746
-          std::cout << "Number of variants " << label << ": " << nvar << '\n';
+          switch (a.type) {
+            case 1: info("1. return closest mutation in ref coordinate. " + std::to_string(i)); break;
+            case 2: info("2. Get sample's sequence in ref coordinate. " + std::to_string(i)); break;
+            case 3: info("3. Get sample's sequence in sample's coordinate. " + std::to_string(i)); break;
+            case 4: info("4. Get sample's variants in ref coordinate. " + std::to_string(i)); break;
+            case 5: info("5. Get sample's variants in sample coordinate. " + std::to_string(i)); break;
+            case 6: info("6. Get variants in ref coordinate. " + std::to_string(i)); break;
+            default:
+              info("7. Get samples have given variant. " + std::to_string(i));
+              info("Looking for variant POS: " + std::to_string(batch[i].x) + ", REF: " + refs[i] + ", ALT: " + alts[i]);
+              if (flags & VS_REGION_NOT_FOUND) error("There is no such variant!");
+          }
+          if (!point && (flags & VS_REGION_ENDLESS)) {
+            error("the reference's backward search does not terminate on region " + std::to_string(batch[i].x) + ":" + std::to_string(batch[i].y));
+            status = EXIT_FAILURE; break;
+          }
+          if (!point && (flags & VS_REGION_INVALID)) {
+            if (a.type == 2 || a.type == 3) std::cerr << "terminate called after throwing an instance of 'std::out_of_range'\n";
+            else error("Can't find node corresponding to pos " + std::to_string(batch[i].x));   // index.h:151-154
+            status = EXIT_FAILURE; break;
+          }
+          if (a.type >= 4 && a.type <= 6) {
+            const char* label = (a.type == 6 && !(flags & VS_REGION_EMPTY)) ? "get_var_in_ref" : "get_sample_var_in_ref";   // query.h:746
+            if (a.type == 5) label = "get_sample_var_in_sample";  // query.h:599
+            std::cout << "Number of variants " << label << ": " << nvar << '\n';
+          }
           query_num += 1;
           if (query_num == 10 || query_num == 100 || query_num == 1000) {
             gettimeofday(&end, nullptr);
@@ -424,7 +489,7 @@ int query_multiproc_main(const Args& a) {
         }
       }
       gettimeofday(&end, nullptr);
-      print_time_elapsed("Query" + std::to_string(query_num) + ": (query_var_in_ref) ", start, end);
+      print_time_elapsed("Query" + std::to_string(query_num) + ": " + (a.type == 6 ? "(query_var_in_ref) " : ""), start, end);
     }
     fflush(stdout);
     vs_result_free(res);
@@ -457,14 +522,22 @@ int query_multiproc_main(const Args& a) {
       out << in.rdbuf();
     }
   }
-  for (int k = 0; k < world; ++k) remove((dir + "/out." + std::to_string(k)).c_str());
+  if (!failed && a.verbose)
+    for (int k = world; k-- > 0;) {
+      std::ifstream in(dir + "/last." + std::to_string(k), std::ios::binary);
+      if (!in) continue;
+      std::ofstream out(a.outfile, std::ios::binary);
+      out << in.rdbuf();
+      break;
+    }
+  for (int k = 0; k < world; ++k) { remove((dir + "/out." + std::to_string(k)).c_str()); remove((dir + "/last." + std::to_string(k)).c_str()); }
   remove(uid_file.c_str());
   rmdir(dir.c_str());
   return failed ? EXIT_FAILURE : EXIT_SUCCESS;
 }
 
 int query_main(const Args& a) {
-  if (a.nprocs >= 1 && a.type == 6) return query_multiproc_main(a);
+  if (a.nprocs >= 1) return query_multiproc_main(a);
   info("Loading Index ...");
   info("Loading variant graph ...");
   info(a.mode == 0 ? "Read index only .." : "Read complete graph ..");

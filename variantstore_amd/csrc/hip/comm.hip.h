@@ -144,7 +144,6 @@ int vs_comm_info(vs_comm* c, int* rank, int* world, int* rccl_ranks) {
 
 int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, uint64_t max_count, void* device_dst, int async_op) {
   if (!c || !r || !device_dst) return fail(VS_ERR_ARG, "null argument");
-  VS_NOT_SEQ(r);
   if (r->idx != c->idx) return fail(VS_ERR_ARG, "the result belongs to another index handle than the communicator");
   if (r->d.Q > max_count) return fail(VS_ERR_ARG, "this rank holds %llu regions, max_count is %llu", (unsigned long long)r->d.Q, (unsigned long long)max_count);
   RcclApi* api = rccl_api();
@@ -161,8 +160,7 @@ int vs_comm_allgather_regions(vs_comm* c, vs_result* r, uint64_t region_base, ui
   }
   // this rank's records (rows beyond its count are never read: the counts delimit them), on the handle's stream ...
   if (r->d.Q) {
-    hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((r->d.Q + 255) / 256)), dim3(256), 0, idx->stream, r->d, (uint64_t*)c->send, region_base);
-    HIP_TRY(hipGetLastError());
+    VS_TRY(launch_pack_regions(r, (uint64_t*)c->send, region_base));
     // the pack kernel reads the result's per-region arrays: the result's completion event moves behind it, so that a
     // vs_result_free before vs_comm_wait does not hand those arrays back to the pool under the kernel
     VS_TRY(pooled_event(idx, &r->ev_done));

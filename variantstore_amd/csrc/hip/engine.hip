@@ -1388,7 +1388,7 @@ static int run_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_res
 template <int MODE>
 static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const uint32_t* dsids, const WalkScratch& ws) {
   // the recording walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
-  if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
+  if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->opts.sc_group <= 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc_coop<8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
     return;
   }
@@ -1399,7 +1399,7 @@ static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const 
 template <int MODE, int PASS>
 static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) {
   // the single walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
-  if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
+  if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->opts.sc_group <= 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq_coop<MODE, 8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
     return;
   }
@@ -1777,6 +1777,18 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
   t.ms_bounds = t.ms_scan = t.ms_emit = t.ms_fill = 0.f;
   HIP_TRY(hipEventElapsedTime(&t.ms_total, idx->ev[0], idx->ev[4]));
   t.fill_launches = 0;
+  return VS_OK;
+}
+
+// the per-region records of any result on the handle's stream: site ranges + counts (k_pack_regions: query types 6, 4, 5, 1, 7)
+// or pieces + bytes (k_pack_seq_regions: types 2, 3)
+static int launch_pack_regions(vs_result* r, uint64_t* dst, uint64_t region_base) {
+  vs_index* idx = r->idx;
+  const uint64_t n = r->d.Q;
+  if (!n) return VS_OK;
+  if (r->kind == 2 || r->kind == 3) hipLaunchKernelGGL(k_pack_seq_regions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, r->sq, dst, region_base);
+  else hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, r->d, dst, region_base);
+  HIP_TRY(hipGetLastError());
   return VS_OK;
 }
 
@@ -2848,18 +2860,13 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
 int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_records, uint64_t region_base,
                            uint64_t* n_records) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
-  VS_NOT_SEQ(r);
   if (n_records) *n_records = r->d.Q;
   if (!device_dst) return VS_OK;
   if (capacity_records < r->d.Q) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
                                              (unsigned long long)capacity_records, (unsigned long long)r->d.Q);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
-  if (r->d.Q) {
-    hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((r->d.Q + 255) / 256)), dim3(256), 0, idx->stream, r->d,
-                       (uint64_t*)device_dst, region_base);
-    HIP_TRY(hipGetLastError());
-  }
+  VS_TRY(launch_pack_regions(r, (uint64_t*)device_dst, region_base));
   HIP_TRY(hipStreamSynchronize(idx->stream));
   return VS_OK;
 }
