@@ -325,7 +325,7 @@ def mixed_types_leg(types, vs, comm, rank, world, local_rank, regions, regions_d
     sids_t = torch.from_numpy(sids.view(np.int32)).to(dev)
     reg_d, sid_d = DeviceArray(regions_dev.data_ptr(), nreg), DeviceArray(sids_t.data_ptr(), nreg)
     positions = np.ascontiguousarray(regions[:, 0])
-    refs7, alts7 = ["A"] * nreg, ["C"] * nreg
+    refs7, alts7 = vs.c_strings(["A"] * nreg), vs.c_strings(["C"] * nreg)   # (the char*[] of the C ABI, built once)
     calls = {6: lambda: vs.get_var_in_ref_device(regions_dev.data_ptr(), nreg),
              4: lambda: vs.get_sample_var_in_ref(reg_d, sid_d),
              5: lambda: vs.get_sample_var_in_sample(reg_d, sid_d),
@@ -370,7 +370,7 @@ def mixed_types_leg(types, vs, comm, rank, world, local_rank, regions, regions_d
         prev.close()
         out[f"type{t}"] = entry
     out["note"] = ("every rank its own regions, each type submitted back to back" + ("; per-region summary records all-gathered through vs_comm_* after "
-                   "every batch (synchronous)" if comm is not None else "") + "; type 7's strings are built on the host per call")
+                   "every batch (synchronous)" if comm is not None else ""))
     return out
 
 

@@ -443,12 +443,17 @@ class VariantStore:
         n = pos.shape[0]
         if len(refs) != n or len(alts) != n:
             raise ValueError("one ref and one alt per position expected")
-        r = (C.c_char_p * max(n, 1))(*[x.encode("latin-1") for x in refs])
-        a = (C.c_char_p * max(n, 1))(*[x.encode("latin-1") for x in alts])
+        r = refs if isinstance(refs, C.Array) else self.c_strings(refs)      # (a caller that asks again and again builds the arrays once)
+        a = alts if isinstance(alts, C.Array) else self.c_strings(alts)
         h = C.c_void_p()
         _check(self._lib.vs_query_samples_has_var(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint64)), r, a, n,
                                                   C.byref(h)), "vs_query_samples_has_var")
         return QueryResult(self, h)
+
+    @staticmethod
+    def c_strings(strings):
+        """`strings` as the char*[] the C ABI takes (samples_has_var accepts the result in place of a list)."""
+        return (C.c_char_p * max(len(strings), 1))(*[x.encode("latin-1") for x in strings])
 
     def _sample_ids(self, sample, n):
         if isinstance(sample, DeviceArray):

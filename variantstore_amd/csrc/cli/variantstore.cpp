@@ -399,7 +399,16 @@ int query_multiproc_main(const Args& a) {
       }
     }
     vs_comm* comm = nullptr;
-    rc = vs_comm_init(idx, rank, world, uid, &comm);
+    {   // RCCL prints a version banner through C stdio when a communicator is made: stdout is the reference's log, so file
+        // descriptor 1 points at stderr for the duration of the call
+      fflush(stdout);
+      const int saved = dup(1);
+      dup2(2, 1);
+      rc = vs_comm_init(idx, rank, world, uid, &comm);
+      fflush(stdout);
+      dup2(saved, 1);
+      close(saved);
+    }
     if (rc != VS_OK) die(rc, "vs_comm_init");
     size_t lo, hi;
     shard(rank, &lo, &hi);

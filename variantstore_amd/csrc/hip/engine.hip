@@ -1388,7 +1388,7 @@ static int run_type6(vs_index* idx, const vs_region* regions, uint64_t n, vs_res
 template <int MODE>
 static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const uint32_t* dsids, const WalkScratch& ws) {
   // the recording walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
-  if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->opts.sc_group <= 1) {
+  if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc_coop<8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
     return;
   }
@@ -1399,7 +1399,7 @@ static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const 
 template <int MODE, int PASS>
 static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) {
   // the single walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
-  if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->opts.sc_group <= 1) {
+  if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq_coop<MODE, 8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
     return;
   }

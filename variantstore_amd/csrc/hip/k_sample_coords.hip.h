@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
   uint32_t sid = 0;
   uint64_t x = 0, y = 0, seg0 = 0, cap = 0;
   if (live) { sid = r.sids[q]; x = r.regions[2 * q]; y = r.regions[2 * q + 1]; seg0 = r.seg_begin[q]; cap = r.seg_begin[q + 1] - seg0; }
-  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x;
+  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && y >= x && im.t4_ev_shift == 0;
   // group-uniform state
   bool serial = live && !fast, busy = false, record = false;
   SeqSink s{0, 0, l == 0};
@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(256) k_sample_seq_coop(DevImage im, DevSeqResu
     const uint32_t w0 = cur_slot >> 6, wi = w0 + l;
     uint64_t word = 0;
     if (busy && ((uint64_t)wi << 6) < last_slot) {
-      word = event_slot_word(ev, wi) | im.seq_breaks[wi];
+      word = ev.row[wi] | im.seq_breaks[wi];
       if (l == 0) word &= ~0ULL << (cur_slot & 63);
       if (wi == (last_slot >> 6)) word &= (1ULL << (last_slot & 63)) - 1;
     }
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   uint32_t sid = 0;
   uint64_t x = 0, y = 0, s0 = 0, scap = 0;
   if (live) { sid = sid_per_region[q]; x = r.regions[2 * q]; y = r.regions[2 * q + 1]; s0 = ws.cap_begin[q]; scap = ws.cap_begin[q + 1] - s0; }
-  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0;
+  const bool fast = live && im.t4_events != nullptr && im.seq_breaks != nullptr && sid != 0 && im.t4_ev_shift == 0;
   // group-uniform state
   bool serial = live && !fast, busy = false;
   uint8_t fl = 0;
@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint32_t w0 = cur_slot >> 6, wi = w0 + l;
     uint64_t word = 0;
     if (busy && ((uint64_t)wi << 6) < last_slot) {
-      word = event_slot_word(ev, wi) | im.seq_breaks[wi];
+      word = ev.row[wi] | im.seq_breaks[wi];
       if (l == 0) word &= ~0ULL << (cur_slot & 63);
       if (wi == (last_slot >> 6)) word &= (1ULL << (last_slot & 63)) - 1;
     }

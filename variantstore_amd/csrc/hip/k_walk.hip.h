@@ -316,16 +316,10 @@ __device__ __forceinline__ uint64_t irr_word_from(const uint64_t* __restrict__ i
   const uint64_t x = irr[wi];
   return wi == (from >> 6) ? x & (~0ULL << (from & 63)) : x;
 }
-// Word wi of a sample's event row AS A SLOT-LEVEL word (slots 64 wi .. 64 wi + 63).  Class-row cohorts: the row's own word.
-// Explicit-id cohorts keep one bit per EIGHT slots (t4_ev_shift = 3; a superset of the events is exact -- a slot that is none
-// costs one literal step): the eight coarse bits of byte (wi & 7) of coarse word (wi >> 3), each spread over its eight slots.
-__device__ __forceinline__ uint64_t event_slot_word(const BitRow& ev, uint32_t wi) {
-  if (ev.sh == 0) return ev.row[wi];
-  const uint32_t b = (uint32_t)(ev.row[wi >> 3] >> ((wi & 7u) * 8u)) & 0xFFu;
-  // bits 0-3 -> bytes 0-3 of the low half, bits 4-7 -> bytes 0-3 of the high half: one bit per byte, then every set byte filled
-  const uint32_t lo = ((b & 0xFu) * 0x00204081u) & 0x01010101u, hi = ((b >> 4) * 0x00204081u) & 0x01010101u;
-  return ((uint64_t)(hi * 0xFFu) << 32) | (uint64_t)(lo * 0xFFu);
-}
+// (Round 5, tried and removed: the cooperative kernels of types 2 / 3 / 5 over the COARSE event rows of explicit-id cohorts -- a coarse
+//  bit spread over its eight slots, every slot of a set block a one-step episode.  Text-exact, and slower than the one-lane kernels on
+//  the 10,000-sample cohort: 71 / 72 / 84 against 80 / 82 / 98 M regions/s.  A region there has one or two events; its time is the
+//  backward search over thousands of ranks, which a group of eight lanes runs redundantly -- eight times the instructions.)
 typedef BitRow EventRow;
 
 // ---- the walk of get_sample_var_in_ref as reusable pieces (serial kernel k_sample_walk, cooperative k_sample_walk_coop) ----
