@@ -232,7 +232,8 @@ def test_query_nprocs_form_for_every_query_type(golden_dir, tmp_path):
     rfile = str(tmp_path / "regions.txt")
     with open(rfile, "w") as f:
         for i in range(30):
-            f.write(f"{1 + 2 * i}:{1 + 2 * i + 12 + (i % 4) * 9}\n")
+            if i != 19:   # (39:78: the reference's backward search of types 2 / 3 / 5 does not terminate there for S1 and S10 -- by the oracle)
+                f.write(f"{1 + 2 * i}:{1 + 2 * i + 12 + (i % 4) * 9}\n")
     pfile = str(tmp_path / "points.txt")
     pts = [9, 20, 54, 39, 8, 21, 60, 70, 9, 20]
     with open(pfile, "w") as f:
@@ -241,7 +242,7 @@ def test_query_nprocs_form_for_every_query_type(golden_dir, tmp_path):
     refs, alts = "G,G,G,T,T,A,T,,C,G", "A,A,C,C,G,C,,AG,T,T"
     cases = [(["-t", "1", "-r", "@" + pfile], "1. return closest"),
              (["-t", "7", "-r", "@" + pfile, "-b", refs, "-a", alts], "7. Get samples"),
-             (["-t", "2", "-r", "@" + rfile, "-s", "S2"], "2. Get sample's sequence"),
+             (["-t", "2", "-r", "@" + rfile, "-s", "S10"], "2. Get sample's sequence"),
              (["-t", "3", "-r", "@" + rfile, "-s", "S10"], "3. Get sample's sequence"),
              (["-t", "4", "-r", "@" + rfile, "-s", "S1"], "4. Get sample's variants"),
              (["-t", "5", "-r", "@" + rfile, "-s", "S10"], "5. Get sample's variants")]
@@ -256,7 +257,7 @@ def test_query_nprocs_form_for_every_query_type(golden_dir, tmp_path):
                                  capture_output=True, text=True, timeout=300)
             assert out.returncode == 0, (args, out.stdout + out.stderr)
             msgs = [m for m in _msgs(out.stdout) if not re.match(r"Query\d+: ", m) and not m.startswith(("Loading", "Read ", "Graph stats", "Chromosome"))]
-            assert sum(m.startswith(head) for m in msgs) == (len(pts) if args[1] in ("1", "7") else 30), (args, msgs[:5])
+            assert sum(m.startswith(head) for m in msgs) == (len(pts) if args[1] in ("1", "7") else 29), (args, msgs[:5])
             got.append((msgs, open(bfile).read(), open(ofile).read() if os.path.exists(ofile) else None))
         assert got[0] == got[1], args
         assert got[0][2], args      # (the -o file was written by both forms)
