@@ -390,7 +390,7 @@ def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nr
     import numpy as np
     import torch
     import torch.distributed as dist
-    from variantstore_amd.parallel import allgather_hit_lists, allgather_region_records, shard_bounds, unpack_region_records
+    from variantstore_amd.parallel import allgather_hit_lists, allgather_region_records, shard_bounds, unpack_region_records, verify_gathered_regions
     dev = torch.device("cuda", local_rank)
     out = {"world": world, "collective": "torch.distributed" if comm is None else "vs_comm_allgather_regions (C ABI, RCCL by dlopen)"}
     out["rccl_ranks"] = comm.info()[2] if comm is not None else dist.get_world_size()
@@ -411,18 +411,9 @@ def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nr
         dist.all_gather_into_tensor(allt, mine)
         ok = 1
         if rank == 0:
-            per = unpack_region_records(recs, c)
-            allt_h = allt.cpu().numpy()
-            for k in range(world):
-                n_k = int(cnts[k])
-                want_ids = np.arange(bases[k], bases[k] + n_k, dtype=np.uint64)
-                if len(per[k]["region"]) != n_k or not np.array_equal(per[k]["region"], want_ids):
-                    sys.stderr.write(f"gathered_ok[{label}]: rank {k}'s records do not carry regions [{bases[k]}, {bases[k] + n_k}) at record {k} x max_count\n")
-                    ok = 0
-                elif int(per[k]["variants"].sum()) != int(allt_h[k, 0]) or int(per[k]["carriers"].sum()) != int(allt_h[k, 1]):
-                    sys.stderr.write(f"gathered_ok[{label}]: rank {k}'s records add up to {int(per[k]['variants'].sum())} variants / "
-                                     f"{int(per[k]['carriers'].sum())} carriers, the rank itself counted {int(allt_h[k, 0])} / {int(allt_h[k, 1])}\n")
-                    ok = 0
+            for fault in verify_gathered_regions(unpack_region_records(recs, c), cnts, bases, allt.cpu().numpy()):
+                sys.stderr.write(f"gathered_ok[{label}]: {fault}\n")
+                ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.broadcast(flag, src=0)
         return bool(int(flag.item())), recs, c

@@ -73,6 +73,63 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _region_records(rank, n, base):
+    """compact per-region records as k_pack_regions writes them (before region_base is added)"""
+    r = np.zeros((n, 4), dtype=np.uint64)
+    r[:, 0] = np.arange(n)
+    r[:, 1] = np.uint64(100 * rank) + np.arange(n, dtype=np.uint64)                                   # first site, no flags
+    r[:, 2] = np.uint64(3) | ((np.arange(n, dtype=np.uint64) % np.uint64(4)) << np.uint64(32))       # 3 sites | variants reported
+    r[:, 3] = np.uint64(10 + rank)                                                                    # carriers
+    return r
+
+
+class FakeRegionResult(FakeResult):
+    def pack_regions_into(self, ptr, cap, region_base):
+        assert cap >= self.recs.shape[0]
+        r = self.recs.copy()
+        r[:, 0] += np.uint64(region_base)
+        ctypes.memmove(ptr, r.ctypes.data, r.nbytes)
+        return r.shape[0]
+
+
+def _worker_verify(rank, world, port, q):
+    """the self-check of the N > 1 bench line (gathered_ok) over a real world-2 gather: placement by rank, region numbers, totals"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from variantstore_amd.parallel import allgather_hit_lists, shard_bounds, unpack_region_records, verify_gathered_regions
+    total = 11
+    counts = [shard_bounds(total, k, world)[1] - shard_bounds(total, k, world)[0] for k in range(world)]
+    bases = [shard_bounds(total, k, world)[0] for k in range(world)]
+    mine = _region_records(rank, counts[rank], bases[rank])
+    out, c = allgather_hit_lists(FakeRegionResult(mine), bases[rank], torch.device("cpu"), compact=True, counts=counts)
+    totals = [(int((_region_records(k, counts[k], 0)[:, 2] >> np.uint64(32)).sum()), counts[k] * (10 + k)) for k in range(world)]
+    per = unpack_region_records(out, c)
+    ok = verify_gathered_regions(per, counts, bases, totals) == []
+    # faults it must see: ranks swapped in the receive buffer, a shard numbered from the wrong base, totals that do not add up
+    ok &= len(verify_gathered_regions(per[::-1], counts, bases, totals)) == world
+    ok &= len(verify_gathered_regions(per, counts, [b + 1 for b in bases], totals)) == world
+    ok &= len(verify_gathered_regions(per, counts, bases, [(v + 1, cc) for v, cc in totals])) == world
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gathered_records_self_check_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_verify, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 def test_allgatherv_of_hit_lists_world2():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -976,10 +976,11 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     launch_bounds(src);
     hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
+    hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, (const Scan5*)tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u);
     if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
-                                     ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, idx->res_entries);
+                                     ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, idx->res_entries);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
-                            ntiles, items, runs, coarse, slow_list, pt, (const uint32_t*)status, seq, (uint64_t)0);
+                            ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     return wait_posted(idx, &pt->seq, seq, 200);
   };

@@ -59,6 +59,16 @@ __device__ __forceinline__ void store_group_nt(uint4* p, uint4 v) {
   __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
 }
 
+// Read-once streams (genotype nibbles, site rows and their parameters): loaded non-temporally under VS_NT_LOADS, so that they do not
+// push the class rows and decoded lists -- which several sites of a batch share -- out of the L2 / MALL.
+#ifdef VS_NT_LOADS
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
+}
+#else
+__device__ __forceinline__ uint4 ld_stream16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+#endif
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
@@ -214,8 +224,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     if (!lists || EARLY_NIB) {
       const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
       const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
-      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+      if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + b0 + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + b0 + 1024 + lane * 16);
     }
     const uint64_t d1 = dmask & (dmask - 1);
     if (d1) {
@@ -348,8 +358,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     const uint64_t gt0_0 = wave_bcast64(gt0, t0);
     const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;
     const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;
-    if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
-    if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+    if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + b0 + lane * 16);
+    if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + b0 + 1024 + lane * 16);
   }
   // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
   // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
@@ -386,8 +396,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
       const uint64_t bn = (gt0_n >> 1) & ~15ULL;
       const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
-      if ((uint64_t)lane * 16 < need) nq0 = *reinterpret_cast<const uint4*>(gtp + bn + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = *reinterpret_cast<const uint4*>(gtp + bn + 1024 + lane * 16);
+      if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + bn + lane * 16);
+      if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + bn + 1024 + lane * 16);
       const uint64_t d2 = dmask & (dmask - 1);
       if (d2) {
         const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
@@ -640,10 +650,15 @@ __device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevRes
   if (u < U && lane < CH) {
     const uint32_t g = (uint32_t)(u + d.dg);
     const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
-    const uint4 x = src[0];
-    uint4 y = src[1];
+    const uint4 x = ld_stream16(src);
+    uint4 y = ld_stream16(src + 1);
+#ifdef VS_NT_LOADS
+    cls = __builtin_nontemporal_load(&im.s_class[g]);
+    gt0 = __builtin_nontemporal_load(&im.s_gt0[g]);
+#else
     cls = im.s_class[g];
     gt0 = im.s_gt0[g];
+#endif
     cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
     y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
     uint4* dst = reinterpret_cast<uint4*>(r.rows + u);

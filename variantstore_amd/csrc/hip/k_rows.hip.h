@@ -61,10 +61,10 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 //   k_t6_bounds   region bounds (or bounds from gathered records) + the {max end, max start} of every tile
 //   k_t6_mid      every tile reduces the tiles before it by itself (a few thousand words at most: no spine launch),
 //                 E_prev per region, what each region adds to the batch, the tile sums of that
+//   k_t6_totals   one block: the batch's totals into mapped host memory, sequence word last -- the host spins on it
 //   k_t6_apply    every tile reduces the tile sums before it AND all of them (the totals: every block knows the size
 //                 of the shared table, so regions under the duplicate rule get their private rows' place here), the
-//                 per-region arrays, the run records of k_share_rows2 / k_fill_sites2, the list of slow regions;
-//                 block 0 posts the totals into mapped host memory, sequence word last -- the host spins on it.
+//                 per-region arrays, the run records of k_share_rows2 / k_fill_sites2, the list of slow regions
 // A thread owns `items` consecutive regions (1 up to a million regions per batch), so the number of tiles stays
 // within what a block reduces by itself whatever the batch.
 // ---------------------------------------------------------------------------
@@ -240,7 +240,7 @@ constexpr uint32_t kCoarseRows = 64;
 template <bool RESIDENT>
 __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
                                            RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
-                                           PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
+                                           const uint32_t* status, uint64_t resident_entries) {
   __shared__ Scan5 red[2][kPlanBlock / 64];
   Scan5 pre{0, 0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0, 0};
   for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) {
@@ -305,8 +305,23 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const uint64_t arena = RESIDENT ? resident_entries : all.c;
     r.var_begin[r.Q] = all.u + all.p; r.car_base[r.Q] = arena;
-    const uint64_t ns = *status;
-    totals_host->rows = all.u + all.p; totals_host->arena = arena; totals_host->shared_rows = all.u; totals_host->not_sorted = ns;
+  }
+}
+// The batch's totals for the host, from ONE block right behind k_t6_mid (round 5): the host sizes table and arena and enqueues
+// the expansion while k_t6_apply -- which beside a running expansion is starved of wave slots and may end only when that
+// expansion does -- writes the per-region arrays nobody on the host is waiting for.
+__global__ void __launch_bounds__(kPlanBlock) k_t6_totals(const Scan5* tile_sums, uint32_t ntiles, const uint32_t* status, PlanTotals* totals_host, uint64_t seq,
+                                                          uint64_t resident_entries, uint32_t resident) {
+  __shared__ Scan5 red[kPlanBlock / 64];
+  Scan5 all{0, 0, 0, 0, 0, 0};
+  for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) all = all + tile_sums[t];
+  for (int d = 32; d >= 1; d >>= 1) all = all + wave_shfl_xor5(all, d);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = all;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    all = red[0] + red[1] + red[2] + red[3];
+    totals_host->rows = all.u + all.p; totals_host->arena = resident ? resident_entries : all.c; totals_host->shared_rows = all.u;
+    totals_host->not_sorted = *status;
     totals_host->reported = all.a; totals_host->n_slow = all.s; totals_host->n_runs = all.r;
     __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -314,8 +329,8 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
 template <bool RESIDENT>
 __global__ void __launch_bounds__(kPlanBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
                                                          RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
-                                                         PlanTotals* totals_host, const uint32_t* status, uint64_t seq, uint64_t resident_entries) {
-  plan_apply<RESIDENT>(im, r, e_prev, tile_sums, ntiles, items, runs, coarse, slow_list, totals_host, status, seq, resident_entries);
+                                                         const uint32_t* status, uint64_t resident_entries) {
+  plan_apply<RESIDENT>(im, r, e_prev, tile_sums, ntiles, items, runs, coarse, slow_list, status, resident_entries);
 }
 // (The three steps as ONE launch with hand-made grid barriers between them -- 512 resident blocks, a growing counter,
 //  agent-scope release / acquire around it -- was built and measured in round 4: 0.19 ms against 0.05 ms for the three

@@ -173,3 +173,22 @@ def unpack_region_records(records, counts):
             "carriers": a[:, 3].copy(),
         })
     return out
+
+
+def verify_gathered_regions(per_rank, counts, bases, totals):
+    """What rank 0 of `bench.py --gpus N` checks about a gather of compact records (`gathered_ok`): `per_rank` is
+    `unpack_region_records(records, counts)`, `bases[k]` the first region of rank k's shard, `totals[k]` the (variants,
+    carriers) rank k counted over its own result.  Rank k's records must lie in slot k (the padded all-gather places rank k
+    at record k x max_count), carry the regions [bases[k], bases[k] + counts[k]) in order and add up to rank k's totals.
+    Returns the list of faults (empty: the gather is what the ranks computed)."""
+    faults = []
+    for k, rec in enumerate(per_rank):
+        n_k = int(counts[k])
+        want = np.arange(int(bases[k]), int(bases[k]) + n_k, dtype=np.uint64)
+        if len(rec["region"]) != n_k or not np.array_equal(rec["region"], want):
+            faults.append(f"rank {k}'s records do not carry regions [{int(bases[k])}, {int(bases[k]) + n_k}) at record {k} x max_count")
+            continue
+        v, c = int(rec["variants"].sum()), int(rec["carriers"].sum())
+        if (v, c) != (int(totals[k][0]), int(totals[k][1])):
+            faults.append(f"rank {k}'s records add up to {v} variants / {c} carriers, the rank itself counted {int(totals[k][0])} / {int(totals[k][1])}")
+    return faults
