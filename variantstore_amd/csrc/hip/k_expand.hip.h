@@ -59,16 +59,9 @@ __device__ __forceinline__ void store_group_nt(uint4* p, uint4 v) {
   __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
 }
 
-// Read-once streams (genotype nibbles, site rows and their parameters): loaded non-temporally under VS_NT_LOADS, so that they do not
-// push the class rows and decoded lists -- which several sites of a batch share -- out of the L2 / MALL.
-#ifdef VS_NT_LOADS
-__device__ __forceinline__ uint4 ld_stream16(const void* p) {
-  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-  return uint4{v.x, v.y, v.z, v.w};
-}
-#else
+// (Round 5, tried and removed: non-temporal LOADS for the read-once streams -- genotype nibbles, site rows and their parameters -- so that
+//  they would not push the shared class rows and decoded lists out of the L2 / MALL: 0.559 -> 0.569 ms.)
 __device__ __forceinline__ uint4 ld_stream16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
-#endif
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
@@ -652,13 +645,8 @@ __device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevRes
     const uint4* src = reinterpret_cast<const uint4*>(im.s_row + g);
     const uint4 x = ld_stream16(src);
     uint4 y = ld_stream16(src + 1);
-#ifdef VS_NT_LOADS
-    cls = __builtin_nontemporal_load(&im.s_class[g]);
-    gt0 = __builtin_nontemporal_load(&im.s_gt0[g]);
-#else
     cls = im.s_class[g];
     gt0 = im.s_gt0[g];
-#endif
     cb = (((uint64_t)y.w << 32) | y.z) + d.dc;
     y.z = (uint32_t)cb; y.w = (uint32_t)(cb >> 32);
     uint4* dst = reinterpret_cast<uint4*>(r.rows + u);
