@@ -264,3 +264,22 @@ def test_query_nprocs_form_for_every_query_type(golden_dir, tmp_path):
     # a sample the index does not know: every rank stops, the parent reports the failure
     out = subprocess.run([CLI, "query", "-p", d, "-m", "1", "-t", "4", "-r", "1:30", "-s", "nobody", "--nprocs", "1"], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "Sample not found" in out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_query_nprocs_ends_all_ranks_when_one_fails(golden_dir, tmp_path):
+    """`--nprocs N` with more ranks than GPUs: the rank whose device does not exist fails at vs_index_open, the others would sit in
+    ncclCommInitRank (or wait for rank 0's unique id) for good -- the parent reaps whichever rank ends first and stops the rest
+    (it used to wait for them in rank order, forever)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    d = str(tmp_path / "ser")
+    assert _construct(golden_dir, d).returncode == 0
+    rfile = str(tmp_path / "regions.txt")
+    with open(rfile, "w") as f:
+        for i in range(4 * n):
+            f.write(f"{1 + 11 * i}:{40 + 11 * i}\n")
+    out = subprocess.run([CLI, "query", "-p", d, "-t", "6", "-r", "@" + rfile, "-m", "1", "--nprocs", str(n)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "a rank of --nprocs failed; stopping the others" in out.stdout + out.stderr
