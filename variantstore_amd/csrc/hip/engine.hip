@@ -265,11 +265,6 @@ static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out,
     HIP_TRY(hipMemsetAsync(out, 0, 8, idx->stream));
     return VS_OK;
   }
-  if (n <= kScanOneMax) {   // one launch
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_one<T>), dim3(1), dim3(kScanBlock), 0, idx->stream, in, n, out);
-    HIP_TRY(hipGetLastError());
-    return VS_OK;
-  }
   const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
   void* ts = nullptr;
   VS_TRY(dev_alloc(idx, ntiles * 8, &ts, scratch_owner));
@@ -284,11 +279,6 @@ static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out,
 // spine kernel also writes to `host_totals` (mapped host memory; NULL = not wanted) -- no staged device-to-host copy.
 static int scan_offsets(vs_index* idx, const uint64_t* nvar, const uint64_t* ncar, uint64_t n, uint64_t* var_begin, uint64_t* car_base,
                         uint64_t* host_totals, std::vector<DevBuf>* scratch_owner) {
-  if (n <= kScanOneMax) {   // one launch
-    hipLaunchKernelGGL(k_scan2_one, dim3(1), dim3(kScanBlock), 0, idx->stream, nvar, ncar, n, var_begin, car_base, host_totals);
-    HIP_TRY(hipGetLastError());
-    return VS_OK;
-  }
   const uint64_t ntiles = n ? (n + kScanTile - 1) / kScanTile : 0;
   void* ts = nullptr;
   VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan2), &ts, scratch_owner));

@@ -72,31 +72,6 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const T* in, uint64_t
   }
 }
 
-// The same scan in ONE launch for short arrays (n <= kScanOneMax: a batch of some ten thousand regions is a chain of ~20 launches
-// of a few microseconds each, and three per scan were a third of them): one block works through the tiles with a carry.
-constexpr uint64_t kScanOneMax = 32768;
-template <typename T>
-__global__ void __launch_bounds__(kScanBlock) k_scan_one(const T* in, uint64_t n, uint64_t* out) {
-  uint64_t carry = 0;
-  for (uint64_t tile = 0; tile < n; tile += kScanTile) {
-    const uint64_t base = tile + (uint64_t)threadIdx.x * kScanItems;
-    uint64_t loc[kScanItems];
-    uint64_t s = 0;
-    for (int i = 0; i < kScanItems; ++i) {
-      loc[i] = base + i < n ? (uint64_t)in[base + i] : 0;
-      s += loc[i];
-    }
-    uint64_t tot;
-    uint64_t ex = block_exclusive_scan(s, &tot) + carry;
-    for (int i = 0; i < kScanItems; ++i) {
-      if (base + i < n) out[base + i] = ex;
-      ex += loc[i];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) out[n] = carry;
-}
-
 // ---------------------------------------------------------------------------
 // Both offset arrays of a batch -- var_begin (slots) and car_base (padded arena entries) -- in ONE pass over the
 // regions: three launches instead of six.  The grand totals also go to `totals` (mapped host memory).
@@ -167,33 +142,6 @@ __global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const uint64_t* nvar
   for (int i = 0; i < kScanItems; ++i) {
     if (base + i < n) { var_begin[base + i] = ex.a; car_base[base + i] = ex.c; }
     ex.a += loc[i].a; ex.c += loc[i].c;
-  }
-}
-
-// (one launch for short batches, as k_scan_one)
-__global__ void __launch_bounds__(kScanBlock) k_scan2_one(const uint64_t* nvar, const uint64_t* ncar, uint64_t n, uint64_t* var_begin, uint64_t* car_base,
-                                                          uint64_t* totals) {
-  Scan2 carry{0, 0};
-  for (uint64_t tile = 0; tile < n; tile += kScanTile) {
-    const uint64_t base = tile + (uint64_t)threadIdx.x * kScanItems;
-    Scan2 loc[kScanItems];
-    Scan2 s{0, 0};
-    for (int i = 0; i < kScanItems; ++i) {
-      loc[i] = base + i < n ? Scan2{nvar[base + i], ncar[base + i]} : Scan2{0, 0};
-      s.a += loc[i].a; s.c += loc[i].c;
-    }
-    Scan2 tot;
-    Scan2 ex = block_exclusive_scan2(s, &tot);
-    ex.a += carry.a; ex.c += carry.c;
-    for (int i = 0; i < kScanItems; ++i) {
-      if (base + i < n) { var_begin[base + i] = ex.a; car_base[base + i] = ex.c; }
-      ex.a += loc[i].a; ex.c += loc[i].c;
-    }
-    carry.a += tot.a; carry.c += tot.c;
-  }
-  if (threadIdx.x == 0) {
-    var_begin[n] = carry.a; car_base[n] = carry.c;
-    if (totals) { totals[0] = carry.a; totals[1] = carry.c; }
   }
 }
 
