@@ -124,3 +124,45 @@ def test_c_abi_collective_round_trip(tmp_path):
     local.close()
     vs.close()
     comm.close()
+
+
+def test_summary_records_of_every_query_type(tmp_path):
+    """The per-region records a sharded run gathers for the query types other than 6 (BASELINE configs[4] mixes 3 / 6 / 7; the CLI's
+    --nprocs prints its log lines from them): through vs_comm_allgather_regions at world size 1, against what the result itself says
+    -- region numbers from the base, region flags, variants reported and carriers (types 4, 5, 1, 7), pieces and sequence bytes
+    (types 2, 3)."""
+    import torch
+    from variantstore_amd.parallel import make_comm
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 433, n_rows=300, ref_len=5000, n_samples=40, carrier_p=0.3, p_near=0.5, p_multi=0.2)
+    vs = VariantStore.from_vcf(fasta, vcf, device=0)
+    regions = sorted(random_regions(np.random.default_rng(8), vs.info().ref_length, 150))
+    n = len(regions)
+    dev = torch.device("cuda", 0)
+    comm = make_comm(vs, 0, 1)
+    per = [names[i % len(names)] for i in range(n)]
+    out = torch.zeros((n + 3, 4), dtype=torch.int64, device=dev)
+
+    def gathered(res, base):
+        comm.allgather_regions(res, base, n + 3, out.data_ptr())
+        return out[:n].cpu().numpy().view(np.uint64)
+
+    for kind, res in (("4", vs.get_sample_var_in_ref(regions, per)), ("5", vs.get_sample_var_in_sample(regions, per)),
+                      ("1", vs.closest_var([x for x, _y in regions]))):
+        rec = gathered(res, 500)
+        v = res.view(with_carriers=False)
+        assert np.array_equal(rec[:, 0], np.arange(500, 500 + n, dtype=np.uint64)), kind
+        assert np.array_equal((rec[:, 1] >> np.uint64(32)) & np.uint64(0x7F), v["region_flags"].astype(np.uint64) & np.uint64(0x7F)), kind
+        assert np.array_equal(rec[:, 2] >> np.uint64(32), v["var_count"]), kind
+        assert int(rec[:, 3].sum()) == res.totals()[2], kind
+        res.close()
+    for sc in (False, True):
+        res = vs.query_sample_seq(regions, per, sample_coordinates=sc)
+        rec = gathered(res, 7)
+        flags, seqs = res.sequences()
+        assert np.array_equal(rec[:, 0], np.arange(7, 7 + n, dtype=np.uint64))
+        assert np.array_equal((rec[:, 1] >> np.uint64(32)) & np.uint64(0xFF), flags.astype(np.uint64))
+        assert [int(b) for b in rec[:, 3]] == [len(s) for s in seqs]
+        assert all(int(p) >= 1 for p, s in zip(rec[:, 2], seqs) if s)
+        res.close()
+    comm.close()
+    vs.close()
