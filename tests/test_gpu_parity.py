@@ -663,6 +663,43 @@ def test_walking_queries_take_regions_and_sample_ids_in_device_memory(tmp_path):
     r.close()
 
 
+def test_walking_batches_that_outgrow_the_previous_batch_are_redone(tmp_path):
+    """Round 5: a walking batch waits for the host once -- its recording walk's scratch (types 4, 5) or piece list (types 2, 3) is
+    sized from the handle's PREVIOUS batch of the kind, and a batch that needs more is refused on the device (k_walk_admit) and
+    redone with the exact size.  A small batch, then one several times its size (refused and redone), then the same again (fits):
+    the same answers every time, and the oracle's."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 416, n_samples=50, n_rows=350, ref_len=6000, p_near=0.5, carrier_p=0.3)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(416)
+    big = np.array(sorted(random_regions(rng, vs.info().ref_length, 400, max_len=1500)), dtype=np.uint64)
+    small = big[:30].copy()
+    small[:, 1] = small[:, 0] + 20
+    ids_big = rng.integers(1, vs.info().num_samples, size=len(big)).astype(np.uint32)
+    for name, call in (("4", lambda r, i: vs.get_sample_var_in_ref(r, i)), ("5", lambda r, i: vs.get_sample_var_in_sample(r, i))):
+        call(small, ids_big[:30]).close()                       # (sets the handle's expectation: a few rows)
+        a = call(big, ids_big)                                   # outgrows it: refused, redone
+        b = call(big, ids_big)                                   # fits
+        assert a.totals() == b.totals() and a.digest() == b.digest(), name
+        for q in range(0, len(big), 9):
+            smp = vs.sample_name(int(ids_big[q]))
+            want = (orc.get_sample_var_in_ref if name == "4" else orc.get_sample_var_in_sample)(int(big[q, 0]), int(big[q, 1]), smp)
+            if want[0] >= 0:
+                assert a.region_text(q) == want[2], (name, q)
+        a.close(); b.close()
+    for coords in (False, True):
+        vs.query_sample_seq(small, ids_big[:30], sample_coordinates=coords).close()
+        a = vs.query_sample_seq(big, ids_big, sample_coordinates=coords)
+        b = vs.query_sample_seq(big, ids_big, sample_coordinates=coords)
+        (fa, sa), (fb, sb) = a.sequences(), b.sequences()
+        assert np.array_equal(fa, fb) and sa == sb
+        for q in range(0, len(big), 9):
+            smp = vs.sample_name(int(ids_big[q]))
+            n, seq = (orc.query_sample_from_sample if coords else orc.query_sample_from_ref)(int(big[q, 0]), int(big[q, 1]), smp)
+            if n >= 0:
+                assert sa[q] == seq, (coords, q)
+        a.close(); b.close()
+
+
 def test_sample_coordinate_queries_synthetic_midsize(tmp_path):
     """20k variants x 200 samples (bit-vector classes), 300 regions of 5 kb, three samples: types 2, 3 and 5."""
     vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=23,
