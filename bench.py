@@ -129,6 +129,11 @@ def cpu_baseline(w, device, budget_s=20.0, parity_regions=600):
            "sample": f"{done} regions x {w['region_len']} bp ({nvar / max(done, 1):.0f} variants/region) on a "
                      f"1/{scale}-length slice of the same synthetic cohort ({kw['num_variants']} sites, "
                      f"{w['num_samples']} samples), CPU oracle, {dt:.1f} s"}
+    # what the sample IS, as fields: not the full index and region file of BASELINE.md section 3, but a slice of the
+    # same generator -- same cohort size, variant density, allele-frequency spectrum and region length -- that the oracle can load in seconds
+    out["slice"] = {"of_workload_length": f"1/{scale}", "ref_length": kw["ref_length"], "sites": kw["num_variants"], "samples": w["num_samples"],
+                    "region_len": w["region_len"], "regions_timed": done, "variants_per_region": nvar / max(done, 1),
+                    "same_generator_and_density_as_the_gpu_workload": True, "oracle_seconds": dt}
     if all_cores:
         out["all_cores"] = all_cores
     parity = {"parity_checked_regions": npar, "parity_checked_rows": rows, "parity_variant_count_regions": done,

@@ -17,10 +17,15 @@
 // k_emit_headers        building std::vector<Variant> (query.h:736-771)
 // k_dedup_slow          the literal "already seen" rule for the rare regions
 //                       that contain a repeated (pos, alt)
-// k_fill_carriers       get_samples -> get_sample_id / get_sample_phasing
-//                       (query.h:268-285, variant_graph.h:875-942): expansion of
-//                       decoded class id lists / class bit rows + genotype bits into
-//                       carrier lists.  This is the dominant kernel.
+// k_t6_bounds / _mid /  the plan of a SORTED type-6 batch whose regions share rows and carrier lists (the reference's
+//  _totals / _apply     driver sorts its regions, src/commands.cc:91): is_empty / find / stop rule per region, the sites each
+//                       region is the first to cover, run records, totals for the host (k_rows.hip.h)
+// k_t6_slow             private rows + the literal "already seen" rule for the regions under it
+// k_fill_sites2         the shared rows AND their carrier lists: get_samples -> get_sample_id / get_sample_phasing
+//                       (query.h:268-285, variant_graph.h:875-1006) once per covered site.  THE DOMINANT KERNEL
+//                       (DESIGN.md section 6); k_fill_dense: its dense variants alone (tuning builds, for profilers)
+// k_fill_carriers       the same expansion over private rows (share_lists = 0, point queries, the walking types' lists):
+//                       decoded class id lists / class bit rows + genotype bits into carrier lists
 // k_query_small         a whole get_var_in_ref batch of <= 64 regions in one launch
 //                       (bounds, offsets, headers, carriers, dedup): the latency path
 // k_query_server        the same, resident: polls requests in mapped host memory
@@ -34,6 +39,12 @@
 //                       (query.h:118-261, types 2 and 3): the walk emits (offset, length)
 //                       pieces of the sequence pool; k_copy_segments decodes them;
 // k_sample_seq_coop      the cooperative form (window logic of query.h:160-177 / :236-247 at the hand-over)
+// k_sample_walk_coop    get_prev_vertex_with_sample + get_sample_var_in_ref (query.h:618-729, type 4), eight lanes per region;
+//  (k_sample_walk)       k_walk_admit holds a batch to the scratch its predecessor needed; k_t4_claim / _offsets: one carrier
+//                       list per reported vertex; k_emit_from_walk: the rows (query.h:680-704)
+// k_pack_regions /      what a sharded run gathers per region (the reference's loop, src/commands.cc:145-193, prints counts and
+//  k_pack_seq_regions    flags per region): site range + counts, or pieces + bytes of a sequence; k_bounds_from_records: the
+//                       receiving side (vs_query_expand_site_ranges)
 // k_find                Index::find batched
 #pragma once
 #include "k_image.hip.h"
