@@ -411,6 +411,7 @@ static int build_device_image(vs_index* idx) {
   VS_TRY(upload_image(idx, im.cls_list16, &d.cls_list16));
   d.list_max = im.list_max;
   VS_TRY(upload_image(idx, im.gt_nibbles, &d.gt_nibbles));
+  VS_TRY(upload_image(idx, im.gt_groups, &d.gt_groups));
   VS_TRY(upload_image(idx, im.car_sid, &d.car_sid));
   VS_TRY(upload_image(idx, im.car_index, &d.car_index));
   d.has_car_index = im.car_index.empty() ? 0u : 1u;

@@ -119,6 +119,35 @@ __device__ __noinline__ void expand_generic(const uint64_t* row, uint32_t wpc, c
   }
 }
 
+// One finished 16-byte arena group of 16-bit carrier words from four id pairs and the group's genotype word (DevImage::gt_groups:
+// genotype k at bit 3 (k / 2) + 16 (k & 1)): W << (13 - 3 j) puts pair j's two genotypes at bits 13-15 and 29-31.
+__device__ __forceinline__ uint4 merge_group16(uint4 ids, uint32_t W, uint32_t m_both) {
+  uint4 v;
+  v.x = and_or(W << 13, m_both, ids.x);
+  v.y = and_or(W << 10, m_both, ids.y);
+  v.z = and_or(W << 7, m_both, ids.z);
+  v.w = and_or(W << 4, m_both, ids.w);
+  return v;
+}
+// The genotypes of one dense variant, requested as up to two 16-byte loads per lane: raw nibbles from the 16-byte-aligned byte
+// below its first carrier (WIDE), or group words from the 4-word-aligned word below its first group (a vertex's carriers start
+// on a multiple of 8 pool records: gt0 % 8 == 0).
+template <bool WIDE>
+__device__ __forceinline__ void request_genotypes(const DevImage& im, uint64_t gt0_v, uint32_t cnt_v, uint32_t lane, uint4& q0, uint4& q1) {
+  if constexpr (WIDE) {
+    const uint8_t* __restrict__ gtp = im.gt_nibbles;
+    const uint64_t b0 = (gt0_v >> 1) & ~15ULL;                        // aligned byte base
+    const uint64_t need = ((gt0_v + cnt_v + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
+    if ((uint64_t)lane * 16 < need) q0 = *reinterpret_cast<const uint4*>(gtp + b0 + lane * 16);
+    if ((uint64_t)lane * 16 + 1024 < need) q1 = *reinterpret_cast<const uint4*>(gtp + b0 + 1024 + lane * 16);
+  } else {
+    const uint64_t w0 = gt0_v >> 3, wb = w0 & ~3ULL;
+    const uint32_t need = (uint32_t)(w0 - wb) + (cnt_v + 7) / 8;      // words from the aligned base on
+    if (lane * 4 < need) q0 = *reinterpret_cast<const uint4*>(im.gt_groups + wb + lane * 4);
+    if (lane * 4 + 256 < need) q1 = *reinterpret_cast<const uint4*>(im.gt_groups + wb + 256 + lane * 4);
+  }
+}
+
 // Expansion of one task: the lanes hold (cnt, cls, gt0, cb) of up to 64 variant slots (cnt == 0: nothing to do for the
 // lane) and the wave writes their carrier words into the arena.  Shared by k_fill_carriers (slots whose headers an
 // earlier kernel wrote) and k_query_small (single-launch latency path, slots read straight from the site table).
@@ -143,8 +172,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
   // carrier word in the arena: 16 bits when every sample id fits 13 bits (the non-WIDE instantiation), else 32
   using CT = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
   CT* __restrict__ carriers = reinterpret_cast<CT*>(arena);
-  uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;   // genotype fields of the two 16-bit carrier words in a dword
-  asm volatile("" : "+s"(m_lo), "+s"(m_hi));
+  uint32_t m_both = 0xE000E000u;   // genotype fields of the two 16-bit carrier words in a dword (in an SGPR: VOP3 takes no literals on gfx9)
+  asm volatile("" : "+s"(m_both));
   const bool explicit_ids = !im.use_bv;   // sparse cohorts: sample ids stored per carrier instead of class rows
   if (explicit_ids) {
     // Explicit-id cohorts (somatic-like: a handful of carriers per variant, ids in the carrier pool): LANE PER GROUP of
@@ -173,9 +202,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         uint4 ia, ib;
         __builtin_memcpy(&ia, im.car_sid + g, 16);
         __builtin_memcpy(&ib, im.car_sid + g + 4, 16);
-        uint2 nw;
-        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
-        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        // (g is a multiple of 8: a vertex's records start on a group boundary of the padded pool)
+        const uint32_t n = WIDE ? gt32[g >> 3] : im.gt_groups[g >> 3];   // eight nibbles / the group's genotype word
         const uint32_t id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
         CT* dst = carriers + (s_cb[L] + k8);
         if constexpr (WIDE) {
@@ -188,13 +216,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           store_group_nt(reinterpret_cast<uint4*>(dst) + 1, hi);
         } else {
           // (every word of car_sid is a valid sample id < 4032 or zero padding: 13 bits, nothing to mask)
-          uint4 v;
-          const uint32_t p0 = id[0] | (id[1] << 16), p1 = id[2] | (id[3] << 16), p2 = id[4] | (id[5] << 16), p3 = id[6] | (id[7] << 16);
-          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, p0));
-          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, p1));
-          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, p2));
-          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, p3));
-          store_group_nt(reinterpret_cast<uint4*>(dst), v);
+          const uint4 pairs{id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16), id[6] | (id[7] << 16)};
+          store_group_nt(reinterpret_cast<uint4*>(dst), merge_group16(pairs, n, m_both));
         }
       }
     }
@@ -214,12 +237,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     const uint32_t cls_0 = __builtin_amdgcn_readlane(cls, t0), cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
     const uint64_t gt0_0 = wave_bcast64(gt0, t0);
     if (lane < wpc) word_cur = class_rows[(uint64_t)cls_0 * wpc + lane];
-    if (!lists || EARLY_NIB) {
-      const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;                        // aligned byte base
-      const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;            // bytes that hold this variant's nibbles
-      if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + b0 + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + b0 + 1024 + lane * 16);
-    }
+    if (!lists || EARLY_NIB) request_genotypes<WIDE>(im, gt0_0, cnt_0, lane, nq0, nq1);
     const uint64_t d1 = dmask & (dmask - 1);
     if (d1) {
       const uint32_t cls_1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d1));
@@ -260,9 +278,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         const uint32_t k = e - s_off[L];
         const uint64_t g = s_gt0[L] + (uint64_t)k * kCarAlign;
         const uint4 ia = list_groups[2 * ((uint64_t)s_idb[L] + k)], ib = list_groups[2 * ((uint64_t)s_idb[L] + k) + 1];
-        uint2 nw;
-        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
-        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
+        const uint32_t n = gt32[g >> 3];   // (g is a multiple of 8: eight nibbles, one aligned word)
         uint4 lo, hi;
         lo.x = ia.x | (((n >> 0) & 7u) << 29); lo.y = ia.y | (((n >> 4) & 7u) << 29);
         lo.z = ia.z | (((n >> 8) & 7u) << 29); lo.w = ia.w | (((n >> 12) & 7u) << 29);
@@ -288,7 +304,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       s_gt0[lane] = gt0;
       s_cb[lane] = cb;
       const uint4* __restrict__ list_groups = reinterpret_cast<const uint4*>(im.cls_list16);
-      const uint32_t* __restrict__ gt32 = reinterpret_cast<const uint32_t*>(gtp);
+      const uint32_t* __restrict__ gt_groups = im.gt_groups;
       uint4* __restrict__ arena_groups = reinterpret_cast<uint4*>(arena);
       for (uint32_t e0 = lane; e0 < total; e0 += 128) {
         const uint32_t e1 = e0 + 64;
@@ -300,35 +316,18 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           if (s_off[L1 + step] <= e1) L1 += step;
         }
         const uint32_t k0 = e0 - s_off[L0], k1 = e1 - s_off[L1];   // group within its variant
-        const uint64_t g0 = s_gt0[L0] + (uint64_t)k0 * kCarAlign;   // its first genotype nibble: 32 bits from bit 4g
-        const uint64_t g1 = s_gt0[L1] + (uint64_t)k1 * kCarAlign;
+        const uint64_t w0 = (s_gt0[L0] >> 3) + k0, w1 = (s_gt0[L1] >> 3) + k1;   // the groups' genotype words (a vertex's records start on a multiple of 8)
         const uint4 iw0 = list_groups[(uint64_t)s_idb[L0] + k0];
-        uint2 nw0, nw1 = {0, 0};
-        __builtin_memcpy(&nw0, gt32 + (g0 >> 3), 8);
+        const uint32_t gw0 = gt_groups[w0];
         uint4 iw1 = {0, 0, 0, 0};
+        uint32_t gw1 = 0;
         if (two) {
           iw1 = list_groups[(uint64_t)s_idb[L1] + k1];
-          __builtin_memcpy(&nw1, gt32 + (g1 >> 3), 8);
+          gw1 = gt_groups[w1];
         }
         const uint64_t dst0 = (s_cb[L0] >> 3) + k0, dst1 = (s_cb[L1] >> 3) + k1;   // arena ranges start on group boundaries
-        {
-          const uint32_t n = __builtin_amdgcn_alignbit(nw0.y, nw0.x, ((uint32_t)g0 & 7u) * 4);
-          uint4 v;
-          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw0.x));
-          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw0.y));
-          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw0.z));
-          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw0.w));
-          store_group_nt(&arena_groups[dst0], v);
-        }
-        if (two) {
-          const uint32_t n = __builtin_amdgcn_alignbit(nw1.y, nw1.x, ((uint32_t)g1 & 7u) * 4);
-          uint4 v;
-          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw1.x));
-          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw1.y));
-          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw1.z));
-          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw1.w));
-          store_group_nt(&arena_groups[dst1], v);
-        }
+        store_group_nt(&arena_groups[dst0], merge_group16(iw0, gw0, m_both));
+        if (two) store_group_nt(&arena_groups[dst1], merge_group16(iw1, gw1, m_both));
       }
     }
   }
@@ -349,10 +348,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     const int t0 = __builtin_ctzll(dmask);
     const uint32_t cnt_0 = __builtin_amdgcn_readlane(cnt, t0);
     const uint64_t gt0_0 = wave_bcast64(gt0, t0);
-    const uint64_t b0 = (gt0_0 >> 1) & ~15ULL;
-    const uint64_t need = ((gt0_0 + cnt_0 + 1) >> 1) - b0;
-    if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + b0 + lane * 16);
-    if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + b0 + 1024 + lane * 16);
+    request_genotypes<WIDE>(im, gt0_0, cnt_0, lane, nq0, nq1);
   }
   // Per-wave LDS block: the genotype staging area (raw nibbles; cohorts above 4032 samples: one byte per carrier),
   // the id list of the slice path (the medium path of wide cohorts keeps its ids at word 256..) and, for wide
@@ -374,10 +370,9 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
     if (WIDE) {   // one byte per carrier
       stage_unpacked(gt_lds + lane * 32, nq0);
       if (nshift + cnt_t > 2048) stage_unpacked(gt_lds + 2048 + lane * 32, nq1);
-    } else {      // raw nibbles, behind the row staging area
-      uint8_t* nib_st = gt_lds + 16;   // 16 bytes (32 nibbles) of bias: see the copy-out
-      *reinterpret_cast<uint4*>(nib_st + lane * 16) = nq0;
-      if ((uint64_t)lane * 32 + 2048 < (uint64_t)nshift + cnt_t) *reinterpret_cast<uint4*>(nib_st + 1024 + lane * 16) = nq1;
+    } else {      // the genotype words of the variant's groups from the 4-word-aligned word below the first one
+      *reinterpret_cast<uint4*>(gt_lds + lane * 16) = nq0;
+      if (lane * 4 + 256 < ((uint32_t)(gt0_t >> 3) & 3u) + (cnt_t + 7) / 8) *reinterpret_cast<uint4*>(gt_lds + 1024 + lane * 16) = nq1;
     }
     // request the next variant's nibbles and the row of the one after it before expanding this one (rows are the
     // random 320-byte reads of this kernel: two of them stay in flight per wave)
@@ -387,10 +382,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       const int tn = __builtin_ctzll(dmask);
       const uint64_t gt0_n = wave_bcast64(gt0, tn);
       const uint32_t cnt_n = __builtin_amdgcn_readlane(cnt, tn);
-      const uint64_t bn = (gt0_n >> 1) & ~15ULL;
-      const uint64_t need = ((gt0_n + cnt_n + 1) >> 1) - bn;
-      if ((uint64_t)lane * 16 < need) nq0 = ld_stream16(gtp + bn + lane * 16);
-      if ((uint64_t)lane * 16 + 1024 < need) nq1 = ld_stream16(gtp + bn + 1024 + lane * 16);
+      request_genotypes<WIDE>(im, gt0_n, cnt_n, lane, nq0, nq1);
       const uint64_t d2 = dmask & (dmask - 1);
       if (d2) {
         const uint32_t cls_2 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(d2));
@@ -417,7 +409,7 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       //      genotypes merged from the raw nibble stream on the way out; the (< 8) ids of the last, incomplete group
       //      move to the front of the list and the second round continues behind them.  The list therefore holds
       //      half a row at most -- the per-wave LDS block is what limits this kernel's occupancy. ----
-      const uint8_t* nib_lds = gt_lds;
+      const uint32_t* gw_lds = reinterpret_cast<const uint32_t*>(gt_lds);
       uint16_t* ids16 = reinterpret_cast<uint16_t*>(gt_lds + slice_gt_words(im.num_samples) * 4);
       uint64_t* rowq = reinterpret_cast<uint64_t*>(ids16);                      // [65], dead before the list is written
       rowq[lane] = mine;
@@ -430,8 +422,8 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
       uint32_t bits1 = __builtin_amdgcn_alignbit(rowd[(bp1 >> 5) + 1], rowd[bp1 >> 5], bp1 & 31u) & smask;
       const uint32_t a1k = (uint32_t)(cb_t & (kListWindow - 1));   // offset of the variant inside its 128-byte line
       uint16_t* g1k = carriers + (cb_t - a1k);            // that block's base: g1k[a1k + k] is carrier k
-      // nibble index = list index + D; the staging is biased by 32 nibbles
-      uint32_t D = nshift + 32 - a1k;
+      // staged genotype word of the group at list index q8 (a multiple of 8, as a1k is): (q8 + D) / 8
+      uint32_t D = ((uint32_t)(gt0_t >> 3) & 3u) * 8u - a1k;
       uint32_t pos = a1k;                                 // list index of the round's first carrier
       const bool fits = a1k + cnt_t + 16u <= slice_ids_words(im.num_samples) * 2u;   // (entries of the list's LDS block)
       uint32_t done8 = a1k;                               // groups below this list index have been written
@@ -483,16 +475,10 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         const uint32_t flush = round ? ((end + 7u) & ~7u) : (fits ? done8 : (end & ~7u));
         for (uint32_t q8 = done8 + lane * 8; q8 < flush; q8 += 512) {
           const uint4 iw = *reinterpret_cast<const uint4*>(ids16 + q8);
-          const uint32_t n0 = q8 + D;
-          const uint32_t* np = reinterpret_cast<const uint32_t*>(nib_lds) + (n0 >> 3);
-          const uint32_t n = __builtin_amdgcn_alignbit(np[1], np[0], (n0 & 7u) * 4);
-          uint4 v;   // two carriers per word: id | gt << 13 in each half.  The masks live in SGPRs (made opaque once per
-                     // kernel) so that every term is a shift plus one v_and_or_b32 -- VOP3 takes no literals on gfx9
-          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, iw.x));
-          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, iw.y));
-          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, iw.z));
-          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, iw.w));
-          store_group_nt(reinterpret_cast<uint4*>(g1k + q8), v);   // a1k is a multiple of 8 and the range owns its padding (pad_car)
+          // two carriers per word: id | gt << 13 in each half; the group's genotype word gives all four pairs by one shift and one
+          // v_and_or_b32 each (round 5; a nibble stream cost two of each and an unaligned window per group)
+          const uint32_t gw = gw_lds[(q8 + D) >> 3];
+          store_group_nt(reinterpret_cast<uint4*>(g1k + q8), merge_group16(iw, gw, m_both));   // a1k is a multiple of 8 and the range owns its padding (pad_car)
         }
         if (round == 0) {
           // rebase: the incomplete group [flush, end) moves down by a whole number of 128-byte lines
