@@ -498,7 +498,7 @@ def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nr
                 flight.append((_W(), g))
             else:
                 g, _c, work = allgather_hit_lists(r, lo, dev, compact=True, counts=s_counts, async_op=True)
-                flight.append((work[0], g))
+                flight.append((work[0], g, work))   # (work[1]: the send buffer, alive until the wait)
             while len(flight) > 1:
                 flight.pop(0)[0].wait()
             return r
