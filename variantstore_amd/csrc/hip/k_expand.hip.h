@@ -202,8 +202,9 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
         uint4 ia, ib;
         __builtin_memcpy(&ia, im.car_sid + g, 16);
         __builtin_memcpy(&ib, im.car_sid + g + 4, 16);
-        // (g is a multiple of 8: a vertex's records start on a group boundary of the padded pool)
-        const uint32_t n = WIDE ? gt32[g >> 3] : im.gt_groups[g >> 3];   // eight nibbles / the group's genotype word
+        uint2 nw;                                                 // (the explicit-id pool is not padded: an unaligned window of the nibble stream)
+        __builtin_memcpy(&nw, gt32 + (g >> 3), 8);
+        const uint32_t n = __builtin_amdgcn_alignbit(nw.y, nw.x, ((uint32_t)g & 7u) * 4);
         const uint32_t id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
         CT* dst = carriers + (s_cb[L] + k8);
         if constexpr (WIDE) {
@@ -216,8 +217,15 @@ __device__ __forceinline__ void expand_task(const DevImage& im, void* arena, uin
           store_group_nt(reinterpret_cast<uint4*>(dst) + 1, hi);
         } else {
           // (every word of car_sid is a valid sample id < 4032 or zero padding: 13 bits, nothing to mask)
-          const uint4 pairs{id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16), id[6] | (id[7] << 16)};
-          store_group_nt(reinterpret_cast<uint4*>(dst), merge_group16(pairs, n, m_both));
+          uint32_t m_lo = 0xE000u, m_hi = 0xE0000000u;
+          asm volatile("" : "+s"(m_lo), "+s"(m_hi));
+          uint4 v;
+          const uint32_t p0 = id[0] | (id[1] << 16), p1 = id[2] | (id[3] << 16), p2 = id[4] | (id[5] << 16), p3 = id[6] | (id[7] << 16);
+          v.x = and_or(n << 25, m_hi, and_or(n << 13, m_lo, p0));
+          v.y = and_or(n << 17, m_hi, and_or(n << 5, m_lo, p1));
+          v.z = and_or(n << 9, m_hi, and_or(n >> 3, m_lo, p2));
+          v.w = and_or(n << 1, m_hi, and_or(n >> 11, m_lo, p3));
+          store_group_nt(reinterpret_cast<uint4*>(dst), v);
         }
       }
     }

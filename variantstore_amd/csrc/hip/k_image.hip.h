@@ -35,8 +35,9 @@ struct DevImage {
   const uint32_t* cls_list_begin;
   const uint32_t* cls_list_ids;
   const uint16_t* cls_list16;   // 16-bit lists, 8-entry aligned and padded, of every class of at most list_max carriers (wpc <= 63)
-  const uint8_t* gt_nibbles;    // cohorts above 4032 samples: 4 bits per carrier record of the (padded) pool
-  const uint32_t* gt_groups;    // cohorts of at most 4032 samples: one word per 8 carrier records, genotype k at bit 3 (k / 2) + 16 (k & 1)
+  const uint8_t* gt_nibbles;    // cohorts above 4032 samples and explicit-id cohorts: 4 bits per carrier record of the pool
+  const uint32_t* gt_groups;    // class-row cohorts of at most 4032 samples (their pool is padded: a vertex's records start on a multiple
+                                // of 8): one word per 8 carrier records, genotype k at bit 3 (k / 2) + 16 (k & 1)
   const uint32_t* car_sid;
   const uint32_t* car_index;  // sample-coordinate index per carrier record (types 2/3/5); valid when has_car_index
   const uint8_t* seq_codes;

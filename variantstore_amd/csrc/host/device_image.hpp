@@ -110,10 +110,10 @@ struct HostImage {
   std::vector<uint32_t> rk_anc;
   std::vector<uint32_t> slot_rank;   // [P] rank of every ref-path slot (slots of rank r: [rank_to_slot[r], rank_to_slot[r + 1]))
   std::vector<uint32_t> rk_back;    // 2 words per rank: {first ref-path slot of the rank, out-degree of that slot's node}
-  // The carrier pool of the IMAGE is padded: every vertex's run starts on a multiple of 8 records (v_car_begin), so that a group of
-  // 8 carriers of the result -- one 16-byte arena group -- is also one group of the pool (round 5).
-  std::vector<uint8_t> gt_nibbles;   // cohorts above 4032 samples: 2 carriers per byte, low nibble first
-  // cohorts of at most 4032 samples (16-bit carrier words): ONE 32-bit word per group of 8 carriers, genotype k of the group
+  // The carrier pool of a CLASS-ROW cohort's image is padded: every vertex's run starts on a multiple of 8 records (v_car_begin), so
+  // that a group of 8 carriers of the result -- one 16-byte arena group -- is also one group of the pool (round 5).
+  std::vector<uint8_t> gt_nibbles;   // cohorts above 4032 samples and explicit-id cohorts: 2 carriers per byte, low nibble first
+  // class-row cohorts of at most 4032 samples (16-bit carrier words): ONE 32-bit word per group of 8 carriers, genotype k of the group
   // (3 bits: phase, gt_1, gt_2) at bit 3 (k / 2) + 16 (k & 1) -- the word shifted left by 13 - 3 j and masked with 0xE000E000
   // is the genotype part of the group's j-th pair of carrier words (id | gt << 13 in each half): one shift and one
   // v_and_or_b32 per pair where a nibble stream cost two of each and an unaligned 8-byte load
@@ -185,11 +185,15 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
   // ---- vertex table ----
   im.v_off = g.off; im.v_len = g.len; im.v_ridx = g.ref_index; im.v_class = g.class_id;
   im.v_ncar.resize(V); im.v_car_begin.resize(V);
-  uint64_t pool_padded = 0;   // the image's pool: a vertex's records start on a multiple of 8
+  // the image's pool: for class-row cohorts a vertex's records start on a multiple of 8 (explicit-id cohorts -- a handful of carriers per
+  // vertex, ids in the pool itself -- keep the dense pool: padding it made the 10,000-sample cohort's pool 44 % larger and its
+  // expansion 6 % slower)
+  const bool pad_pool = g.use_bit_vector != 0;
+  uint64_t pool_padded = 0;
   for (uint64_t v = 0; v < V; ++v) {
     im.v_ncar[v] = g.num_carriers((uint32_t)v);
     im.v_car_begin[v] = pool_padded;
-    pool_padded += ((uint64_t)im.v_ncar[v] + 7) & ~7ULL;
+    pool_padded += pad_pool ? (((uint64_t)im.v_ncar[v] + 7) & ~7ULL) : im.v_ncar[v];
   }
 
   // The device expands a class row into exactly v_ncar carriers without bounds checks:
@@ -351,7 +355,8 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     for (uint64_t v = 0; v < V; ++v)
       if (im.v_ncar[v] <= im.list_max) im.v_src[v] = im.cls_list_begin[im.v_class[v]] / kListGroup;
   // genotypes, explicit ids and sample-coordinate indexes in the padded pool's order
-  if (narrow) im.gt_groups.assign(pool_padded / 8 + 16, 0);   // (16-byte reads of the staging run up to 3 words past a run)
+  const bool groups = narrow && pad_pool;                      // genotype group words need group-aligned runs
+  if (groups) im.gt_groups.assign(pool_padded / 8 + 16, 0);   // (16-byte reads of the staging run up to 3 words past a run)
   else im.gt_nibbles.assign(pool_padded / 2 + 32, 0);         // windowed 64-bit reads run up to 24 bytes past a list
   if (!g.car_sid.empty()) im.car_sid.assign(pool_padded, 0);
   if (!g.car_index.empty()) im.car_index.assign(pool_padded, 0);
@@ -360,7 +365,7 @@ inline void build_host_image(const HostGraph& g, HostImage& im) {
     for (uint32_t j = 0; j < im.v_ncar[v]; ++j) {
       const uint64_t c = dst + j;
       const uint32_t gt = g.car_flags[src + j] & 7u;
-      if (narrow) im.gt_groups[c >> 3] |= gt << (3 * ((c & 7) >> 1) + 16 * (c & 1));
+      if (groups) im.gt_groups[c >> 3] |= gt << (3 * ((c & 7) >> 1) + 16 * (c & 1));
       else im.gt_nibbles[c >> 1] |= (uint8_t)(gt << ((c & 1) * 4));
       if (!g.car_sid.empty()) im.car_sid[c] = g.car_sid[src + j];
       if (!g.car_index.empty()) im.car_index[c] = g.car_index[src + j];
