@@ -100,7 +100,8 @@ typedef struct {
   uint32_t reserved_;
   uint64_t t4_rows_bytes;    /* of device_bytes: the per-sample event and hold rows of query type 4 (O(samples x ref-path slots):
                               * taken when they fit half of the free HBM and 176 GB -- VS_T4_ROWS_MAX_GB in the environment
-                              * lowers the cap; 0: not built, the walks then visit every vertex) */
+                              * lowers the cap, option "t4_rows_max_mb" drops / rebuilds them on the open handle; 0: not built, the walks
+                              * then visit every vertex) */
   uint64_t pool_mallocs;     /* hipMalloc / hipFree calls the handle's pool of batch buffers has made since it was opened: a loop */
   uint64_t pool_frees;       /* of like batches makes none once it is warm (hipFree waits for the whole device)                  */
 } vs_index_info;
@@ -330,7 +331,7 @@ void vs_comm_destroy(vs_comm* c);
 
 /* ---- switches of one handle ----
  * The environment is read once when a handle is opened; afterwards only this call changes a
- * switch.  The production library has EIGHT keys:
+ * switch.  The production library has NINE keys:
  *   "latency_server"  0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first small query
  *   "server_blocks"   1..64 blocks of the resident server
  *   "share_lists"     1 (default): a type-6 batch of more than 64 regions holds one row and one carrier list per covered
@@ -345,6 +346,11 @@ void vs_comm_destroy(vs_comm* c);
  *   "t4_walk"         the walk of the query types that follow one sample's path: 2 cooperative (8 lanes per region, a region's
  *                     events walked in parallel: types 4, 2 and 3; default), 1 one lane per region jumping over uneventful
  *                     ref-path runs, 0 literal (type 4: every vertex of the sample's path; types 2 / 3 / 5 as 1)
+ *   "t4_rows_max_mb"  the per-sample event and hold rows of query type 4 (vs_index_info.t4_rows_bytes: 7.6 GB for 2504
+ *                     samples over chr1) on an OPEN handle: rows larger than the value in MiB are dropped (0: always -- the walks
+ *                     then visit every vertex, same answers), absent rows are built when they fit it and half of the free
+ *                     memory.  Several handles on one GPU: the caller decides which of them keeps its rows.  Waits for the
+ *                     device before it frees anything.
  *   "force_fallbacks" 1 = query types 2 - 5 take the count-then-emit pair of walks they fall back to when a region outgrows
  *                     the capacity of its recording walk (tests of that path)
  * Tuning builds (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) add "lat_debug", "fill_fused", "fill_chunk",

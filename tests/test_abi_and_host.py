@@ -130,8 +130,9 @@ def test_handle_options_are_checked():
                       ("async_fill", 1), ("async_fill", 0), ("async_submit", 0), ("async_submit", 1), ("resident_lists", 0)):
         vs.set_option(key, good)
     for key, bad in (("latency_server", 3), ("server_blocks", 0), ("server_blocks", 65), ("t4_walk", 3), ("no_such_switch", 1),
-                     ("fill_chunk", 16), ("fill_split", 0), ("lat_debug", 1), ("t4_coop", 8),   # tuning builds only / gone: the production library has eight keys
-                     ("share_lists", 2), ("resident_lists", 2), ("resident_lists", 1)):   # (resident lists need a device)
+                     ("fill_chunk", 16), ("fill_split", 0), ("lat_debug", 1), ("t4_coop", 8),   # tuning builds only / gone: the production library has nine keys
+                     ("share_lists", 2), ("resident_lists", 2), ("resident_lists", 1),   # (resident lists need a device)
+                     ("t4_rows_max_mb", -1), ("t4_rows_max_mb", 0), ("t4_rows_max_mb", 64)):   # (and so do the rows of query type 4)
         with pytest.raises(VariantStoreError):
             vs.set_option(key, bad)
     with pytest.raises(VariantStoreError) as e:       # this is not a tuning build

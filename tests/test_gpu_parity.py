@@ -622,6 +622,42 @@ def test_sample_sequence_batch_with_one_sample_per_region(tmp_path):
         assert res.totals()[3] == sum(len(s) for s in seqs)
 
 
+def test_type4_rows_can_be_dropped_and_rebuilt_on_an_open_handle(tmp_path):
+    """Option t4_rows_max_mb (variantstore_hip.h): the per-sample event / hold rows of query type 4 leave and come back on an
+    open handle, vs_index_get_info accounts for them, and every walking query type answers the same as the oracle either way."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 977, n_samples=60, n_rows=260, ref_len=5000, p_near=0.5)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(977)
+    regions = np.array(random_regions(rng, vs.info().ref_length, 150, max_len=900), dtype=np.uint64)
+    ids = rng.integers(1, vs.info().num_samples, size=len(regions)).astype(np.uint32)
+    want = [orc.get_sample_var_in_ref(int(x), int(y), vs.sample_name(int(i)))[2] for (x, y), i in zip(regions, ids)]
+    info0 = vs.info()
+    assert info0.t4_rows_bytes > 0
+
+    def answers():
+        a = vs.get_sample_var_in_ref(regions, ids)
+        b = vs.get_sample_var_in_sample(regions, ids)
+        c = vs.query_sample_seq(regions, ids)
+        out = ([a.region_text(q) for q in range(len(regions))], a.digest(), b.digest(), c.sequences()[1])
+        a.close(); b.close(); c.close()
+        return out
+
+    with_rows = answers()
+    assert with_rows[0] == want
+    vs.set_option("t4_rows_max_mb", 0)
+    info1 = vs.info()
+    assert info1.t4_rows_bytes == 0 and info1.device_bytes < info0.device_bytes
+    assert answers() == with_rows
+    vs.set_option("t4_rows_max_mb", 0)            # (nothing to drop: no-op)
+    vs.set_option("t4_rows_max_mb", 1 << 20)
+    info2 = vs.info()
+    assert info2.t4_rows_bytes == info0.t4_rows_bytes and info2.device_bytes == info0.device_bytes
+    assert answers() == with_rows
+    vs.set_option("t4_rows_max_mb", 1 << 20)      # (they fit the cap: kept)
+    assert vs.info().t4_rows_bytes == info0.t4_rows_bytes
+    vs.close()
+
+
 def test_walking_queries_take_regions_and_sample_ids_in_device_memory(tmp_path):
     """Query types 4 (one sample per region), 2, 3 and 5 with their inputs already on the GPU (variantstore_hip.h:
     vs_query_samples_var_in_ref): the same answers as from host arrays, in both walk forms; an id out of range in a device

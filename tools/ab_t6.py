@@ -36,6 +36,20 @@ def run(label, opts, steps=30):
     dt = (time.perf_counter() - t0) / steps * 1e3
     prev.close()
     label = f"{label} [fill in the loop {np.mean(fills):.4f}]"
+    if os.environ.get("HOSTTIME"):   # where the host's time goes in a loop that reads nothing back: the call, the close one step late
+        prev = None; tc = tcl = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ta = time.perf_counter()
+            r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
+            tb = time.perf_counter()
+            if prev is not None: prev.close()
+            tcl += time.perf_counter() - tb; tc += tb - ta
+            prev = r
+        torch.cuda.synchronize()
+        dtl = (time.perf_counter() - t0) / steps * 1e3
+        prev.close()
+        label += f" [lean loop {dtl:.4f} ms: call {tc / steps * 1e3:.4f}, close {tcl / steps * 1e3:.4f}]"
     for _ in range(steps):     # phases by the handle's events (reading them waits for the batch)
         r = vs.get_var_in_ref_device(dev.data_ptr(), nreg)
         t = vs.last_timing()

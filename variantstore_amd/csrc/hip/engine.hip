@@ -94,6 +94,7 @@ struct vs_index {
   std::vector<void*> image_allocs;
   uint64_t device_bytes = 0;
   uint64_t t4_rows_bytes = 0;   // of which: the per-sample event and hold rows of query type 4
+  uint64_t t4_alloc_bytes = 0;   // what build_t4_rows added to device_bytes (drop_t4_rows takes it off again)
   uint64_t pool_mallocs = 0, pool_frees = 0;   // hipMalloc / hipFree calls of the batch-buffer pool (vs_index_info)
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
@@ -101,7 +102,6 @@ struct vs_index {
   unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
   uint64_t t4_gen = 0;
   hipStream_t plan_stream = nullptr;        // the plan of an async_submit batch runs here, beside the previous batch's expansion on `stream`
-  hipEvent_t plan_ev = nullptr;
   hipStream_t fill_stream = nullptr;        // second stream: the expansion of an async_fill batch
   hipEvent_t fill_ev[2] = {nullptr, nullptr};
   bool sort_hint = false;                   // the last shared batch arrived unsorted and was sorted on the device
@@ -354,6 +354,72 @@ struct ScratchBufs {
 };
 
 // ----------------------------------------------------------- image on device
+// ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
+//      what this part has plenty of).  Skipped when they would take more than half of the free memory or `cap` bytes; dropped
+//      and rebuilt on an open handle by option t4_rows_max_mb (several handles on one GPU: the caller decides who gets them --
+//      without the rows type 4 walks one lane per region). ----
+static void free_image_alloc(vs_index* idx, const void* p) {
+  if (!p) return;
+  auto it = std::find(idx->image_allocs.begin(), idx->image_allocs.end(), const_cast<void*>(p));
+  if (it != idx->image_allocs.end()) idx->image_allocs.erase(it);
+  (void)hipFree(const_cast<void*>(p));
+}
+static int drop_t4_rows(vs_index* idx) {
+  DevImage& d = idx->d;
+  if (!d.t4_events) return VS_OK;
+  HIP_TRY(hipDeviceSynchronize());   // (batches that returned when they were enqueued may still be walking over the rows)
+  free_image_alloc(idx, d.t4_events); free_image_alloc(idx, d.t4_hold); free_image_alloc(idx, d.t4_irr);
+  idx->device_bytes -= idx->t4_alloc_bytes;
+  idx->t4_alloc_bytes = 0; idx->t4_rows_bytes = 0;
+  d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0; d.t4_irr = nullptr; d.t4_ev_shift = 0; d.t4_irr_reach = 1;
+  return VS_OK;
+}
+static int build_t4_rows(vs_index* idx, uint64_t cap) {
+  const HostImage& im = idx->im;
+  DevImage& d = idx->d;
+  if (d.t4_events) return VS_OK;
+  if (im.slots_follow_ranks && im.P && d.num_samples > 1) {
+    // Class-row cohorts: a bit per slot and sample, a bit per vertex and sample (3.0 + 4.6 GB at 2504 samples).  Explicit-id
+    // cohorts (thousands of samples, a handful of carriers per variant): one bit per EIGHT slots -- any superset of the
+    // events is exact, a coarse bit costs a few literal steps where the sample does have an event, and those are rare -- and
+    // no hold rows at all: "does v hold the sample" is read from v's carrier list (k_walk.hip.h: BitRow).  10,000 samples x
+    // 20 M variants: 6.3 GB instead of round 3's 125 GB.
+    const uint32_t shift = d.use_bv ? 0u : 3u;
+    const uint64_t istride = (im.P + 63) / 64 + 1;                                   // the global irregular row: a bit per slot
+    const uint64_t stride = d.use_bv ? istride : ((im.P >> shift) + 64) / 64 + 1, hstride = d.use_bv ? (im.V + 63) / 64 + 1 : 0;
+    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
+      idx->t4_rows_bytes = bytes + hbytes;
+      const uint64_t bytes_before = idx->device_bytes;
+      uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
+      VS_TRY(alloc_image(idx, (size_t)istride, &irr));
+      HIP_TRY(hipMemsetAsync(irr, 0, istride * 8, idx->stream));
+      VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
+      HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
+      if (hstride) {
+        VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
+        HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
+      }
+      d.t4_stride = stride; d.t4_hold_stride = hstride; d.t4_ev_shift = shift;
+      const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
+      if (d.use_bv) {
+        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events, irr);
+        hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, d, hold);
+      } else {
+        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, irr);
+        hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
+      }
+      HIP_TRY(hipGetLastError());
+      d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr; d.t4_irr_reach = im.irr_reach;
+      idx->t4_alloc_bytes = idx->device_bytes - bytes_before;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(idx->stream));
+  return VS_OK;
+}
+
 static int build_device_image(vs_index* idx) {
   HostImage& im = idx->im;
   DevImage& d = idx->d;
@@ -519,48 +585,14 @@ static int build_device_image(vs_index* idx) {
   }
   VS_TRY(upload_image(idx, sus_g, &d.sus_g));
   VS_TRY(upload_image(idx, sus_prev, &d.sus_prev));
-  // ---- event bitmaps of query type 4: one row of P bits per sample (3 GB for 2504 samples x 9.6 M ref-path slots; HBM is
-  //      what this part has plenty of).  Skipped when they would take more than half of the free memory or the cap below. ----
+  // ---- the per-sample rows of query type 4 (build_t4_rows below) ----
   d.t4_events = nullptr; d.t4_stride = 0; d.t4_hold = nullptr; d.t4_hold_stride = 0; d.t4_irr = nullptr; d.t4_ev_shift = 0; d.t4_irr_reach = 1;
-  if (im.slots_follow_ranks && im.P && d.num_samples > 1 && !idx->opts.no_t4_events) {
-    // Class-row cohorts: a bit per slot and sample, a bit per vertex and sample (3.0 + 4.6 GB at 2504 samples).  Explicit-id
-    // cohorts (thousands of samples, a handful of carriers per variant): one bit per EIGHT slots -- any superset of the
-    // events is exact, a coarse bit costs a few literal steps where the sample does have an event, and those are rare -- and
-    // no hold rows at all: "does v hold the sample" is read from v's carrier list (k_walk.hip.h: BitRow).  10,000 samples x
-    // 20 M variants: 6.3 GB instead of round 3's 125 GB.
-    const uint32_t shift = d.use_bv ? 0u : 3u;
-    const uint64_t istride = (im.P + 63) / 64 + 1;                                   // the global irregular row: a bit per slot
-    const uint64_t stride = d.use_bv ? istride : ((im.P >> shift) + 64) / 64 + 1, hstride = d.use_bv ? (im.V + 63) / 64 + 1 : 0;
-    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    // Budget: half of the free memory, at most 176 GB -- or VS_T4_ROWS_MAX_GB from the environment; vs_index_get_info
-    // reports what was taken (t4_rows_bytes).
+  if (!idx->opts.no_t4_events) {
+    // Budget: half of the free memory, at most 176 GB -- or VS_T4_ROWS_MAX_GB from the environment, or option t4_rows_max_mb
+    // on the open handle; vs_index_get_info reports what was taken (t4_rows_bytes).
     uint64_t cap = 176ull << 30;
     if (const char* gb = getenv("VS_T4_ROWS_MAX_GB")) cap = (uint64_t)(std::max(0.0, atof(gb)) * (double)(1ull << 30));
-    if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
-      idx->t4_rows_bytes = bytes + hbytes;
-      uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
-      VS_TRY(alloc_image(idx, (size_t)istride, &irr));
-      HIP_TRY(hipMemsetAsync(irr, 0, istride * 8, idx->stream));
-      VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
-      HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
-      if (hstride) {
-        VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
-        HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
-      }
-      d.t4_stride = stride; d.t4_hold_stride = hstride; d.t4_ev_shift = shift;
-      const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
-      if (d.use_bv) {
-        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events, irr);
-        hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, d, hold);
-      } else {
-        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, irr);
-        hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
-      }
-      HIP_TRY(hipGetLastError());
-      d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr; d.t4_irr_reach = im.irr_reach;
-    }
+    VS_TRY(build_t4_rows(idx, cap));
   }
   HIP_TRY(hipStreamSynchronize(idx->stream));
   return VS_OK;
@@ -666,7 +698,6 @@ static int ensure_plan_stream(vs_index* idx) {
   // (stream priorities, lowest and highest, were measured: the expansion beside a plan takes 0.031 ms longer than alone
   //  whatever the plan's priority -- the plan's 137 MB of scattered lines are what it shares, not wave slots)
   HIP_TRY(hipStreamCreateWithFlags(&idx->plan_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&idx->plan_ev, hipEventDisableTiming));
   return VS_OK;
 }
 // Regions and sample ids of the walking query types may be handed over in device memory (the copies below are
@@ -945,7 +976,11 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   bool plan_aside = async_submit && !(idx->sort_hint && idx->sort_probe_in > 0);
   if (plan_aside) VS_TRY(ensure_plan_stream(idx));
   hipStream_t ps = plan_aside ? idx->plan_stream : idx->stream;
-  if (regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ps));
+  // (regions already in device memory are copied by the kernel that reads them first: k_t6_bounds)
+  const uint64_t* regions_dev = regions && regions_on_device && !site_records && (reinterpret_cast<uintptr_t>(regions) & 15) == 0
+                                    ? reinterpret_cast<const uint64_t*>(regions) : nullptr;
+  if (regions_dev) {}
+  else if (regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ps));
   else HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, ps));
   HIP_TRY(hipEventRecord(idx->ev[0], ps));
   ScratchBufs scratch(idx);
@@ -960,24 +995,23 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   uint32_t* coarse = nullptr;
   VS_TRY(dev_alloc(idx, (idx->d.G / kCoarseRows + 2) * 4, (void**)&coarse, &scratch.bufs));
   VS_TRY(dev_alloc(idx, ntiles * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, ntiles * sizeof(Scan5), (void**)&tile_sums, &scratch.bufs));
+  VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan5), (void**)&tile_sums, &scratch.bufs));   // (+ the totals: k_t6_totals)
   VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
   VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
   VS_TRY(dev_alloc(idx, n * 4, (void**)&slow_list, &scratch.bufs));
   VS_TRY(dev_alloc(idx, (n + 1) * sizeof(RunRec), (void**)&runs, &scratch.bufs));
   PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
   auto launch_bounds = [&](int src) {
-    if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
-    else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, site_records, items, tile_max);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max);
+    if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, regions_dev, items, tile_max, status);
+    else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, site_records, items, tile_max, status);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max, status);
   };
   // the plan over the regions as they stand in `d`; the totals arrive in mapped host memory
   auto plan = [&](int src) -> int {
-    HIP_TRY(hipMemsetAsync(status, 0, 4, ps));
-    launch_bounds(src);
+    launch_bounds(src);   // (block 0 clears `status`)
     hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
-    hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, (const Scan5*)tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u);
+    hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u);
     if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                                      ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, idx->res_entries);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
@@ -1039,8 +1073,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
   HIP_TRY(hipEventRecord(idx->ev[1], ps));
   if (plan_aside) {   // (the host has seen the totals block 0 posted; the handle's stream waits for the whole plan)
-    HIP_TRY(hipEventRecord(idx->plan_ev, ps));
-    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->plan_ev, 0));
+    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->ev[1], 0));
   }
   const uint64_t U = pt->shared_rows, n_slow = pt->n_slow, n_runs = pt->n_runs;
   d.A = pt->rows;
@@ -2082,7 +2115,6 @@ void vs_index_close(vs_index* idx) {
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->fill_stream) (void)hipStreamDestroy(idx->fill_stream);
     if (idx->plan_stream) (void)hipStreamDestroy(idx->plan_stream);
-    if (idx->plan_ev) (void)hipEventDestroy(idx->plan_ev);
     for (auto& e : idx->fill_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev_pool) if (e) (void)hipEventDestroy(e);
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
@@ -2240,6 +2272,15 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
   else if (k == "t4_walk") {
     if (value < 0 || value > 2) return fail(VS_ERR_ARG, "t4_walk takes 0 (literal), 1 (one lane per region, jumping) or 2 (cooperative, default)");
     o.t4_walk = (int)value;
+  } else if (k == "t4_rows_max_mb") {
+    // the per-sample rows of query type 4 on an open handle: dropped when they take more than `value` MiB (0: always), built
+    // when they are absent and fit it (and half of the free memory); vs_index_get_info().t4_rows_bytes says what is there
+    if (value < 0) return fail(VS_ERR_ARG, "t4_rows_max_mb takes a size in MiB (0: drop the rows)");
+    if (idx->device < 0) return fail(VS_ERR_ARG, "the handle has no device image");
+    HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t cap = (uint64_t)value << 20;
+    if (idx->d.t4_events && idx->t4_rows_bytes > cap) VS_TRY(drop_t4_rows(idx));
+    else if (!idx->d.t4_events && cap) VS_TRY(build_t4_rows(idx, cap));
   } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
   else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_mode" || k == "fill_dense_k" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {

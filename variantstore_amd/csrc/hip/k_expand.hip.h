@@ -661,7 +661,7 @@ __device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevRes
 }
 
 template <bool WIDE, uint32_t CH, bool TUNE, bool DENSE = true>
-__global__ void __launch_bounds__(256) k_fill_sites2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fill_sites2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
                                                      uint64_t U, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
   const uint64_t t_start = (TUNE && tstat) ? wall_clock64() : 0;
   const uint32_t lane = threadIdx.x & 63;

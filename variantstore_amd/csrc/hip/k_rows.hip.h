@@ -57,14 +57,15 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 // so a row's carrier offset keeps its form car_base[q] + carpre[g] - carpre[g0].  Needs g0 ascending over the
 // regions with any site; a batch that is not reports so (PlanTotals::not_sorted) and is sorted on the device first.
 //
-// THE PLAN of a batch is three launches (round 4; rounds 2-3 took bounds + five scan launches):
+// THE PLAN of a batch is four short launches (rounds 2-3 took bounds + five scan launches):
 //   k_t6_bounds   region bounds (or bounds from gathered records) + the {max end, max start} of every tile
 //   k_t6_mid      every tile reduces the tiles before it by itself (a few thousand words at most: no spine launch),
 //                 E_prev per region, what each region adds to the batch, the tile sums of that
-//   k_t6_totals   one block: the batch's totals into mapped host memory, sequence word last -- the host spins on it
-//   k_t6_apply    every tile reduces the tile sums before it AND all of them (the totals: every block knows the size
-//                 of the shared table, so regions under the duplicate rule get their private rows' place here), the
-//                 per-region arrays, the run records of k_share_rows2 / k_fill_sites2, the list of slow regions
+//   k_t6_totals   one block: the tile sums become their exclusive prefix in place, the batch's totals go into mapped host
+//                 memory, sequence word last -- the host spins on it
+//   k_t6_apply    the per-region arrays (regions under the duplicate rule get their private rows' place behind the shared
+//                 table: every block reads the totals), the run records of k_share_rows2 / k_fill_sites2, the list of
+//                 slow regions.  No host attention; it has to fit the holes an expansion in flight leaves (<= 64 VGPRs).
 // A thread owns `items` consecutive regions (1 up to a million regions per batch), so the number of tiles stays
 // within what a block reduces by itself whatever the batch.
 // ---------------------------------------------------------------------------
@@ -164,8 +165,12 @@ __device__ __forceinline__ RecordBounds record_bounds(const DevImage& im, const 
   if ((w1 >> 40) & 1) fl |= kRegionSlow;   // the producing rank dropped rows: the literal rule runs again here
   return RecordBounds{g0, nsites, fl, im.s_carpre[g0 + nsites] - im.s_carpre[g0]};
 }
+// `recs`: SRC 1 the gathered records; SRC 0 the caller's regions when they are in device memory (NULL: already copied into
+// the result) -- the kernel that reads them anyway keeps the result's copy, and block 0 clears the plan's status word:
+// two operations fewer on the plan's stream than a copy and a memset in front of it (each is a launch: ~5 us on either side).
 template <int SRC>
-__device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult& r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
+__device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult& r, const uint64_t* recs, uint32_t items, ShareMax* tile_max, uint32_t* status) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
   ShareMax m{0, 0};
   for (uint32_t i = 0; i < items; ++i) {
@@ -173,7 +178,13 @@ __device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult&
     if (q >= r.Q) break;
     uint32_t g0, nv;
     if (SRC == 0) {
-      const RegionBounds b = region_bounds_of(im, r.regions[2 * q], r.regions[2 * q + 1]);
+      uint64_t x, y;
+      if (recs) {
+        const ulonglong2 xy = *reinterpret_cast<const ulonglong2*>(recs + 2 * q);
+        x = xy.x; y = xy.y;
+        *reinterpret_cast<ulonglong2*>(const_cast<uint64_t*>(r.regions) + 2 * q) = xy;
+      } else { x = r.regions[2 * q]; y = r.regions[2 * q + 1]; }
+      const RegionBounds b = region_bounds_of(im, x, y);
       g0 = b.g0; nv = b.g1 - b.g0;
       r.q_flags[q] = b.flags; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad;
     } else if (SRC == 1) {
@@ -190,8 +201,8 @@ __device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult&
   if (threadIdx.x == 0) tile_max[blockIdx.x] = tot;
 }
 template <int SRC>
-__global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult r, const uint64_t* recs, uint32_t items, ShareMax* tile_max) {
-  plan_bounds<SRC>(im, r, recs, items, tile_max);
+__global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult r, const uint64_t* recs, uint32_t items, ShareMax* tile_max, uint32_t* status) {
+  plan_bounds<SRC>(im, r, recs, items, tile_max, status);
 }
 // per region: E_prev (kept for the last pass); per tile: the sums
 __device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
@@ -237,50 +248,57 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r,
 struct RunRec { uint64_t u_start, dg, dc, pad_; };
 struct RowDelta { uint64_t dg, dc; };
 constexpr uint32_t kCoarseRows = 64;
+// what k_t6_apply scans per region (the rows reported are the totals' business alone): 8 registers where Scan5 takes 12
+struct Scan4 { uint64_t u, c, p; uint32_t s, r; };
+__device__ __forceinline__ Scan4 block_exclusive_scan4(Scan4 v) {
+  __shared__ Scan4 wsum[kPlanBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  Scan4 incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t tu = __shfl_up(incl.u, d, 64), tc = __shfl_up(incl.c, d, 64), tp = __shfl_up(incl.p, d, 64);
+    const uint32_t ts = __shfl_up(incl.s, d, 64), tr = __shfl_up(incl.r, d, 64);
+    if (lane >= d) { incl.u += tu; incl.c += tc; incl.p += tp; incl.s += ts; incl.r += tr; }
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  Scan4 o{incl.u - v.u, incl.c - v.c, incl.p - v.p, incl.s - v.s, incl.r - v.r};
+  for (int w = 0; w < kPlanBlock / 64 - 1; ++w)
+    if (w < wid) { const Scan4 t = wsum[w]; o.u += t.u; o.c += t.c; o.p += t.p; o.s += t.s; o.r += t.r; }
+  return o;
+}
+// tile_pre: k_t6_totals' exclusive prefix of the tile sums, the batch's totals at [ntiles] -- a block reads its own entry and the
+// last one (two uniform loads) where round 4's kernel reduced all the tiles by itself in twenty-four registers.
 template <bool RESIDENT>
-__device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+__device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const Scan5* tile_pre, uint32_t ntiles, uint32_t items,
                                            RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                            const uint32_t* status, uint64_t resident_entries) {
-  __shared__ Scan5 red[2][kPlanBlock / 64];
-  Scan5 pre{0, 0, 0, 0, 0, 0}, all{0, 0, 0, 0, 0, 0};
-  for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) {
-    const Scan5 v = tile_sums[t];
-    all = all + v;
-    if (t < blockIdx.x) pre = pre + v;
-  }
-  for (int d = 32; d >= 1; d >>= 1) {
-    pre = pre + wave_shfl_xor5(pre, d);
-    all = all + wave_shfl_xor5(all, d);
-  }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
-  __syncthreads();
-  pre = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-  const uint64_t U = all.u;
+  const uint64_t U = tile_pre[ntiles].u, all_p = tile_pre[ntiles].p, all_c = tile_pre[ntiles].c;
+  const bool many_runs = tile_pre[ntiles].r > 64;
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
-  Scan5 s{0, 0, 0, 0, 0, 0};
-  ShareNew w_first{0, 0, 0, 0, 0, 0};   // (items == 1, the usual case: what the region adds is worked out once)
+  Scan4 s{0, 0, 0, 0, 0};
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
     const uint64_t q = base + i;
     const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q], ep = e_prev[q];
     const ShareNew w = share_new(im, g0, nv, ep);
-    if (i == 0) w_first = w;
-    s.a += nv; s.u += w.n_new; s.c += w.arena_new;
+    s.u += w.n_new; s.c += w.arena_new;
     if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
     if (nv && ep <= g0) s.r += 1;
   }
-  Scan5 tot;
-  Scan5 ex = block_exclusive_scan5(s, &tot) + pre;
+  Scan4 ex = block_exclusive_scan4(s);
+  {
+    const Scan5 pre = tile_pre[blockIdx.x];
+    ex.u += pre.u; ex.c += pre.c; ex.p += pre.p; ex.s += (uint32_t)pre.s; ex.r += (uint32_t)pre.r;
+  }
   const bool sorted = *status == 0;   // a batch that is not sorted is planned again after the sort: its per-region inputs stay as the bounds left them
   for (uint32_t i = 0; sorted && i < items && base + i < r.Q; ++i) {
     const uint64_t q = base + i;
-    const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q];
+    const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q], ep = e_prev[q];
     const bool slow = (r.q_flags[q] & kRegionSlow) != 0;
-    const ShareNew w = i == 0 ? w_first : share_new(im, g0, nv, e_prev[q]);
-    const bool run_start = nv && e_prev[q] <= g0;
+    const ShareNew w = share_new(im, g0, nv, ep);   // (worked out again: the site table's prefixes are in cache, registers held across the scan are not free)
+    const bool run_start = nv && ep <= g0;
     if (run_start) runs[ex.r] = RunRec{ex.u, (uint64_t)g0 - ex.u, RESIDENT ? 0 : ex.c - w.pre_ns, 0};   // (a run starts at the region's first site: ns == g0)
-    if (all.r > 64 && w.n_new) {   // the region's own run, for every kCoarseRows-th row it is the first to cover
-      const uint32_t rid = (uint32_t)(ex.r + (run_start ? 1 : 0) - 1);
+    if (many_runs && w.n_new) {   // the region's own run, for every kCoarseRows-th row it is the first to cover
+      const uint32_t rid = ex.r + (run_start ? 1u : 0u) - 1u;
       for (uint64_t m = (ex.u + kCoarseRows - 1) & ~(uint64_t)(kCoarseRows - 1); m < ex.u + w.n_new; m += kCoarseRows) coarse[m / kCoarseRows] = rid;
     }
     // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
@@ -298,39 +316,42 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
       r.var_count[q] = nv;
       r.q_ncar[q] = im.s_kpre[g0 + nv] - im.s_kpre[g0];
     }
-    ex.a += nv; ex.u += w.n_new; ex.c += w.arena_new;
+    ex.u += w.n_new; ex.c += w.arena_new;
     if (slow) { ex.p += nv; ex.s += 1; }
     if (run_start) ex.r += 1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const uint64_t arena = RESIDENT ? resident_entries : all.c;
-    r.var_begin[r.Q] = all.u + all.p; r.car_base[r.Q] = arena;
+    const uint64_t arena = RESIDENT ? resident_entries : all_c;
+    r.var_begin[r.Q] = U + all_p; r.car_base[r.Q] = arena;
   }
 }
-// The batch's totals for the host, from ONE block right behind k_t6_mid (round 5): the host sizes table and arena and enqueues
-// the expansion while k_t6_apply -- which beside a running expansion is starved of wave slots and may end only when that
-// expansion does -- writes the per-region arrays nobody on the host is waiting for.
-__global__ void __launch_bounds__(kPlanBlock) k_t6_totals(const Scan5* tile_sums, uint32_t ntiles, const uint32_t* status, PlanTotals* totals_host, uint64_t seq,
+// ONE block right behind k_t6_mid (round 5): the tile sums become their exclusive prefix in place (the batch's totals at
+// [ntiles]) and the totals go to the host, which sizes table and arena and enqueues the expansion while k_t6_apply writes the
+// per-region arrays nobody on the host is waiting for.
+__global__ void __launch_bounds__(kPlanBlock) k_t6_totals(Scan5* tile_sums, uint32_t ntiles, const uint32_t* status, PlanTotals* totals_host, uint64_t seq,
                                                           uint64_t resident_entries, uint32_t resident) {
-  __shared__ Scan5 red[kPlanBlock / 64];
-  Scan5 all{0, 0, 0, 0, 0, 0};
-  for (uint32_t t = threadIdx.x; t < ntiles; t += kPlanBlock) all = all + tile_sums[t];
-  for (int d = 32; d >= 1; d >>= 1) all = all + wave_shfl_xor5(all, d);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = all;
-  __syncthreads();
+  Scan5 carry{0, 0, 0, 0, 0, 0};
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += kPlanBlock) {
+    const uint32_t t = t0 + threadIdx.x;
+    const Scan5 v = t < ntiles ? tile_sums[t] : Scan5{0, 0, 0, 0, 0, 0};
+    Scan5 tot;
+    const Scan5 ex = block_exclusive_scan5(v, &tot);
+    if (t < ntiles) tile_sums[t] = carry + ex;
+    carry = carry + tot;
+  }
   if (threadIdx.x == 0) {
-    all = red[0] + red[1] + red[2] + red[3];
-    totals_host->rows = all.u + all.p; totals_host->arena = resident ? resident_entries : all.c; totals_host->shared_rows = all.u;
+    tile_sums[ntiles] = carry;
+    totals_host->rows = carry.u + carry.p; totals_host->arena = resident ? resident_entries : carry.c; totals_host->shared_rows = carry.u;
     totals_host->not_sorted = *status;
-    totals_host->reported = all.a; totals_host->n_slow = all.s; totals_host->n_runs = all.r;
+    totals_host->reported = carry.a; totals_host->n_slow = carry.s; totals_host->n_runs = carry.r;
     __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 template <bool RESIDENT>
-__global__ void __launch_bounds__(kPlanBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_sums, uint32_t ntiles, uint32_t items,
+__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_pre, uint32_t ntiles, uint32_t items,
                                                          RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                                          const uint32_t* status, uint64_t resident_entries) {
-  plan_apply<RESIDENT>(im, r, e_prev, tile_sums, ntiles, items, runs, coarse, slow_list, status, resident_entries);
+  plan_apply<RESIDENT>(im, r, e_prev, tile_pre, ntiles, items, runs, coarse, slow_list, status, resident_entries);
 }
 // (The three steps as ONE launch with hand-made grid barriers between them -- 512 resident blocks, a growing counter,
 //  agent-scope release / acquire around it -- was built and measured in round 4: 0.19 ms against 0.05 ms for the three
