@@ -110,6 +110,9 @@ struct vs_index {
   uint64_t walk_cap_hint[2] = {0, 0};       // scratch entries the last type-4 / type-5 batch's recording walk needed (+ 1/8): the next batch's allocation
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
+  uint64_t* walk_words = nullptr;           // the flag words of the walking batches (batch_words): zero between batches
+  bool walk_words_dirty = true;
+  hipStream_t pre = nullptr;                // the stream the part of a walking batch IN FRONT of its host wait is on (PreStream below); NULL: the handle's
   bool batch_in_flight = false;             // a batch returned when it was enqueued (async_submit) and nothing has synchronised the stream since
   hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the events collect_timing reads: the handle's own (ev[]) or, for a
                                             // lean batch, the result's pair around its expansion (timing_owner)
@@ -258,19 +261,39 @@ static int alloc_image(vs_index* idx, size_t n, T** dptr) {
   return VS_OK;
 }
 
+// Walking batches (query types 4, 5, 2, 3) under async_submit run everything in front of their one host wait -- copies, capacities,
+// scans, the recording walk, the claims -- on the handle's SECOND stream (vs_index::plan_stream), beside the rows and the carrier
+// expansion of the batch before, which are on the handle's stream; the host has seen that part's last kernel post its words before
+// it enqueues the rest, so no event links the two.  What the part reads is the caller's input and the index, what it writes is the
+// batch's own (a batch that returned when it was enqueued keeps its temporaries until its completion event) -- but for the claim
+// table of the type-4 lists, which belongs to the handle: k_t4_claim waits for the previous batch's emitter (ev[3]).
+// The helpers below launch on work_stream(idx): the second stream while a PreStream guard is alive, else the handle's.
+static inline hipStream_t work_stream(const vs_index* idx) { return idx->pre ? idx->pre : idx->stream; }
+struct PreStream {
+  vs_index* idx;
+  PreStream(vs_index* i, hipStream_t s) : idx(i) { i->pre = s; }
+  ~PreStream() { idx->pre = nullptr; }
+  void done() { idx->pre = nullptr; }
+};
+
 // out[0..n) = exclusive prefix of in, out[n] = total
 template <typename T>
 static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out, std::vector<DevBuf>* scratch_owner) {
   if (n == 0) {
-    HIP_TRY(hipMemsetAsync(out, 0, 8, idx->stream));
+    HIP_TRY(hipMemsetAsync(out, 0, 8, work_stream(idx)));
+    return VS_OK;
+  }
+  if (n <= kScanSmallMax && (const void*)in != (const void*)out) {   // one launch instead of three
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_small<T>), dim3((unsigned)((n + kScanSmallTile - 1) / kScanSmallTile)), dim3(kScanSmallBlock), 0, work_stream(idx), in, (uint32_t)n, out);
+    HIP_TRY(hipGetLastError());
     return VS_OK;
   }
   const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
   void* ts = nullptr;
   VS_TRY(dev_alloc(idx, ntiles * 8, &ts, scratch_owner));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_tile_sums<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, in, n, (uint64_t*)ts);
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanBlock), 0, idx->stream, (uint64_t*)ts, ntiles, out + n);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, in, n, (const uint64_t*)ts, out);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_tile_sums<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, work_stream(idx), in, n, (uint64_t*)ts);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kScanBlock), 0, work_stream(idx), (uint64_t*)ts, ntiles, out + n);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<T>), dim3((unsigned)ntiles), dim3(kScanBlock), 0, work_stream(idx), in, n, (const uint64_t*)ts, out);
   HIP_TRY(hipGetLastError());
   return VS_OK;
 }
@@ -279,12 +302,18 @@ static int exclusive_scan(vs_index* idx, const T* in, uint64_t n, uint64_t* out,
 // spine kernel also writes to `host_totals` (mapped host memory; NULL = not wanted) -- no staged device-to-host copy.
 static int scan_offsets(vs_index* idx, const uint64_t* nvar, const uint64_t* ncar, uint64_t n, uint64_t* var_begin, uint64_t* car_base,
                         uint64_t* host_totals, std::vector<DevBuf>* scratch_owner) {
+  if (n <= kScanSmallMax) {   // one launch instead of three
+    hipLaunchKernelGGL(k_scan2_small, dim3((unsigned)std::max<uint64_t>(1, (n + kScanSmallTile - 1) / kScanSmallTile)), dim3(kScanSmallBlock), 0, work_stream(idx), nvar, ncar,
+                       (uint32_t)n, var_begin, car_base, host_totals);
+    HIP_TRY(hipGetLastError());
+    return VS_OK;
+  }
   const uint64_t ntiles = n ? (n + kScanTile - 1) / kScanTile : 0;
   void* ts = nullptr;
   VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan2), &ts, scratch_owner));
-  if (ntiles) hipLaunchKernelGGL(k_scan2_tile_sums, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, nvar, ncar, n, (Scan2*)ts);
-  hipLaunchKernelGGL(k_scan2_spine, dim3(1), dim3(kScanBlock), 0, idx->stream, (Scan2*)ts, ntiles, var_begin + n, car_base + n, host_totals);
-  if (ntiles) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, idx->stream, nvar, ncar, n, (const Scan2*)ts, var_begin, car_base);
+  if (ntiles) hipLaunchKernelGGL(k_scan2_tile_sums, dim3((unsigned)ntiles), dim3(kScanBlock), 0, work_stream(idx), nvar, ncar, n, (Scan2*)ts);
+  hipLaunchKernelGGL(k_scan2_spine, dim3(1), dim3(kScanBlock), 0, work_stream(idx), (Scan2*)ts, ntiles, var_begin + n, car_base + n, host_totals);
+  if (ntiles) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(kScanBlock), 0, work_stream(idx), nvar, ncar, n, (const Scan2*)ts, var_begin, car_base);
   HIP_TRY(hipGetLastError());
   return VS_OK;
 }
@@ -895,10 +924,10 @@ static int read_device_words(vs_index* idx, const uint64_t* a, uint64_t* va, con
                              const uint64_t* c = nullptr, uint64_t* vc = nullptr) {
   uint64_t* dst = idx->pinned + vs_index::kPinWords;
   const uint64_t seq = ++idx->done_seq;
-  hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, idx->stream, dst, a, b, c, seq);
+  hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, work_stream(idx), dst, a, b, c, seq);
   HIP_TRY(hipGetLastError());
   VS_TRY(wait_posted(idx, dst + 3, seq, 2000));
-  idx->batch_in_flight = false;
+  if (!idx->pre) idx->batch_in_flight = false;   // (the handle's own stream has drained)
   if (va) *va = ((volatile uint64_t*)dst)[0];
   if (vb) *vb = ((volatile uint64_t*)dst)[1];
   if (vc) *vc = ((volatile uint64_t*)dst)[2];
@@ -1234,24 +1263,43 @@ struct BatchCtx {
   uint64_t n;
   ScratchBufs scratch;
   uint32_t* dsids = nullptr;     // one sample per region (types 4 / 5), on the device
-  uint64_t* bad_ids = nullptr;   // ids that arrived in device memory: set by k_check_sample_ids, read with the batch's first sizes
+  uint64_t* bad_ids = nullptr;   // ids that arrived in device memory: set by k_walk_setup / k_check_sample_ids, read with the batch's first sizes
+  uint64_t* words = nullptr;     // a walking batch's flag words (the handle's, zero when the batch starts: batch_words): [0] bad_ids, [1] the walk's overflow word
+  bool caps_done = false;        // the capacities of the recording walk were written by the batch's first kernel (k_walk_setup)
   bool resident = false;         // rows point into the index's resident arena: nothing is expanded
   bool async_fill = false;
   BatchCtx(vs_index* i, vs_result* res, uint64_t nn) : idx(i), r(res), n(nn), scratch(i) {}
 };
 
-static int check_device_ids(vs_index* idx, vs_result* r, const uint32_t* dsids, uint64_t n, uint64_t** bad) {
-  VS_TRY(ralloc(r, 1, bad));
-  HIP_TRY(hipMemsetAsync(*bad, 0, 8, idx->stream));
-  hipLaunchKernelGGL(k_check_sample_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, dsids, n, idx->g.num_samples, *bad);
+// (`bad`: a word the batch's memset has cleared)
+static int check_device_ids(vs_index* idx, const uint32_t* dsids, uint64_t n, uint64_t* bad) {
+  hipLaunchKernelGGL(k_check_sample_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), dsids, n, idx->g.num_samples, bad);
   HIP_TRY(hipGetLastError());
   return VS_OK;
 }
+// The flag words of a walking batch (BatchCtx::words: ids out of range, the walk's overflow word).  They belong to the HANDLE and
+// are zero between batches: only the part of a batch in front of its host wait writes them, the host reads them in that wait, and
+// a batch that read anything but zeros (or did not get that far) leaves them marked for the one memset the next batch then pays --
+// a stream of healthy batches pays none.
+static int batch_words(vs_index* idx, uint64_t** words) {
+  if (!idx->walk_words) {
+    HIP_TRY(hipMalloc((void**)&idx->walk_words, 32));
+    idx->image_allocs.push_back(idx->walk_words);
+    idx->walk_words_dirty = true;
+  }
+  if (idx->walk_words_dirty) HIP_TRY(hipMemsetAsync(idx->walk_words, 0, 32, work_stream(idx)));
+  idx->walk_words_dirty = true;   // (until this batch's host wait has read zeros: words_read_clean)
+  *words = idx->walk_words;
+  return VS_OK;
+}
+static void words_read_clean(vs_index* idx, uint64_t overflow_seen) { if (!overflow_seen) idx->walk_words_dirty = false; }
 static int bad_ids_error(vs_index* idx) {
   return fail(VS_ERR_UNKNOWN_SAMPLE, "a sample id of the batch is out of range (%u samples)", idx->g.num_samples);
 }
 
-static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_device, const uint32_t* sample_ids) {
+// walk_caps: -1 none; 0 / 1: the batch is a recording walk of query type 4 / 5 -- when its regions and sample ids are in device
+// memory the capacities come from the same kernel that takes the copies (k_walk_setup: BatchCtx::caps_done).
+static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_device, const uint32_t* sample_ids, int walk_caps = -1) {
   vs_index* idx = c.idx;
   vs_result* r = c.r;
   const uint64_t n = c.n;
@@ -1270,14 +1318,29 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
-  if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDefault, idx->stream));
-  else if (n) HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, idx->stream));
-  if (sample_ids && n) {
-    VS_TRY(ralloc(r, n, &c.dsids));
-    HIP_TRY(hipMemcpyAsync(c.dsids, sample_ids, n * 4, hipMemcpyDefault, idx->stream));
-    if (is_device_ptr(sample_ids)) VS_TRY(check_device_ids(idx, r, c.dsids, n, &c.bad_ids));
+  const bool ids_on_device = sample_ids && n && is_device_ptr(sample_ids);
+  if (n && (walk_caps >= 0 || ids_on_device)) {
+    VS_TRY(batch_words(idx, &c.words));
+    if (ids_on_device) c.bad_ids = c.words;
   }
-  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  if (sample_ids && n) VS_TRY(ralloc(r, n, &c.dsids));
+  if (n && walk_caps >= 0 && regions && (ids_on_device || !sample_ids) && is_device_ptr(regions)) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (walk_caps == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_setup<true>), grid, dim3(256), 0, work_stream(idx), idx->d, d, reinterpret_cast<const uint64_t*>(regions), sample_ids,
+                                           c.dsids, idx->g.num_samples, c.words);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_setup<false>), grid, dim3(256), 0, work_stream(idx), idx->d, d, reinterpret_cast<const uint64_t*>(regions), sample_ids,
+                            c.dsids, idx->g.num_samples, c.words);
+    HIP_TRY(hipGetLastError());
+    c.caps_done = true;
+  } else {
+    if (n && regions) HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, regions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDefault, work_stream(idx)));
+    else if (n) HIP_TRY(hipMemsetAsync(dreg, 0, n * 16, work_stream(idx)));
+    if (sample_ids && n) {
+      HIP_TRY(hipMemcpyAsync(c.dsids, sample_ids, n * 4, hipMemcpyDefault, work_stream(idx)));
+      if (ids_on_device) VS_TRY(check_device_ids(idx, c.dsids, n, c.bad_ids));
+    }
+  }
+  HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));
   return VS_OK;
 }
 
@@ -1424,23 +1487,23 @@ template <int MODE>
 static void launch_walk_sc(vs_index* idx, const DevResult& d, uint64_t n, const uint32_t* dsids, const WalkScratch& ws) {
   // the recording walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
   if (MODE == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc_coop<8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc_coop<8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, d, dsids, ws);
     return;
   }
   if (idx->opts.sc_group > 1)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d, dsids, ws);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, d, dsids, ws);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, d, dsids, ws);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_sc<MODE, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, work_stream(idx), idx->d, d, dsids, ws);
 }
 template <int MODE, int PASS>
 static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) {
   // the single walk: cooperative (eight lanes per region, episodes in parallel) where the samples' event rows name slots
   if (PASS == 2 && idx->opts.t4_walk >= 2 && idx->d.t4_events && idx->d.seq_breaks && idx->d.t4_ev_shift == 0 && idx->opts.sc_group <= 1) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq_coop<MODE, 8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq_coop<MODE, 8>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, q);
     return;
   }
   if (idx->opts.sc_group > 1)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, idx->d, q);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, kScGroup>), dim3((unsigned)((n * kScGroup + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, q);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_seq<MODE, PASS, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, work_stream(idx), idx->d, q);
 }
 
 // Query types 4 (walk_mode 4: get_sample_var_in_ref, one sample's path in reference coordinates) and 5 (walk_mode 5:
@@ -1452,7 +1515,7 @@ static void launch_sample_seq(vs_index* idx, const DevSeqResult& q, uint64_t n) 
 static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode,
                                bool speculate, bool* refused);
 // ONE host wait per batch (round 5): the recording walk's scratch is sized from the handle's previous batch of the kind; a batch
-// that does not fit is refused on the device (k_walk_admit) and redone here with the exact size -- the first batch of a handle
+// that does not fit is refused on the device (WalkAdmit: the walk's first look) and redone here with the exact size -- the first batch of a handle
 // and a batch 12 % bigger than any before it pay the second wait, a steady stream of batches never does.
 static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode) {
   bool refused = false;
@@ -1463,7 +1526,11 @@ static int run_walk_batch(vs_index* idx, const vs_region* regions, uint64_t n, v
 static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, uint32_t sample_id, const uint32_t* sample_ids, int walk_mode,
                                bool speculate, bool* refused) {
   BatchCtx c(idx, r, n);
-  VS_TRY(batch_setup(c, regions, false, sample_ids));
+  // everything in front of the host wait on the handle's second stream, beside the previous batch's rows and expansion (PreStream)
+  const bool aside = idx->opts.async_submit && speculate && n > 0 && !idx->opts.force_fallbacks && !idx->opts.walk_stats && !idx->opts.lat_debug;
+  if (aside) VS_TRY(ensure_plan_stream(idx));
+  PreStream pre(idx, aside ? idx->plan_stream : nullptr);
+  VS_TRY(batch_setup(c, regions, false, sample_ids, idx->opts.force_fallbacks ? -1 : (walk_mode == 5 ? 1 : 0)));
   DevResult& d = r->d;
   ScratchBufs& scratch = c.scratch;
   const uint32_t* dsids = c.dsids;
@@ -1475,7 +1542,7 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   if (idx->opts.t4_walk == 0) dwalk.t4_events = nullptr;
   auto counting_walk = [&]() {
     if (walk_mode == 5) launch_walk_sc<0>(idx, d, n, dsids, WalkScratch{});
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, WalkScratch{});
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, work_stream(idx), dwalk, d, sample_id, dsids, WalkScratch{});
   };
   if (c.bad_ids && idx->opts.force_fallbacks) {   // (otherwise read with the capacities' total below: nothing before that looks at an id)
     uint64_t bad = 0;
@@ -1483,15 +1550,16 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
     if (bad) return bad_ids_error(idx);
   }
   if (n && !idx->opts.force_fallbacks) {
-    if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
-    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, d);
+    if (c.caps_done) {}   // (k_walk_setup)
+    else if (walk_mode == 5) hipLaunchKernelGGL(k_walk_caps_sc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, d);
+    else hipLaunchKernelGGL(k_region_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, d);
     uint64_t* cap_begin = nullptr;
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&cap_begin, &scratch.bufs));
     VS_TRY(exclusive_scan<uint64_t>(idx, d.q_nvar, n, cap_begin, &scratch.bufs));
     uint64_t cap_total = 0, bad = 0;
     uint64_t& hint = idx->walk_cap_hint[walk_mode == 5 ? 1 : 0];
     speculative = speculate && hint > 0 && idx->opts.async_submit;
-    if (speculative) cap_total = hint;   // (k_walk_admit, below, holds the batch to it)
+    if (speculative) cap_total = hint;   // (the walk itself holds the batch to it: WalkAdmit)
     else {
       VS_TRY(read_device_words(idx, cap_begin + n, &cap_total, c.bad_ids, &bad));
       if (bad) return bad_ids_error(idx);
@@ -1506,22 +1574,21 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.rl, &scratch.bufs));
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.ao, &scratch.bufs));
     VS_TRY(dev_alloc(idx, cap_total * 4 + 8, (void**)&ws.al, &scratch.bufs));
-    VS_TRY(dev_alloc(idx, 8, (void**)&ws.overflow, &scratch.bufs));
-    HIP_TRY(hipMemsetAsync(ws.overflow, 0, 8, idx->stream));
-    if (speculative) hipLaunchKernelGGL(k_walk_admit, dim3(1), dim3(1), 0, idx->stream, (const uint64_t*)cap_total_dev, cap_total, (const uint64_t*)c.bad_ids, ws.overflow);
+    ws.overflow = c.words + 1;   // (zero: batch_words)
+    if (speculative) ws.admit = WalkAdmit{cap_total_dev, cap_total, c.bad_ids};
 #ifdef VS_TUNING
     if (idx->opts.walk_stats) {
       VS_TRY(dev_alloc(idx, 128, (void**)&ws.stats, &scratch.bufs));
-      HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, idx->stream));
+      HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, work_stream(idx)));
     }
 #endif
     if (walk_mode == 5) launch_walk_sc<2>(idx, d, n, dsids, ws);
     else if (dwalk.t4_events && idx->opts.t4_walk == 2)   // 8 lanes per region: the episodes of a region run in parallel
     {
-      if (dwalk.t4_hold) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, false>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, true>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, idx->stream, dwalk, d, sample_id, dsids, ws);   // explicit ids
+      if (dwalk.t4_hold) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, false>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, work_stream(idx), dwalk, d, sample_id, dsids, ws);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk_coop<8, true>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, work_stream(idx), dwalk, d, sample_id, dsids, ws);   // explicit ids
     }
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, idx->stream, dwalk, d, sample_id, dsids, ws);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_walk<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, work_stream(idx), dwalk, d, sample_id, dsids, ws);
     HIP_TRY(hipGetLastError());
     single_walk = true;
   }
@@ -1529,8 +1596,8 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
 #ifdef VS_TUNING
   if (single_walk && ws.stats) {
     unsigned long long h[16];
-    HIP_TRY(hipMemcpyAsync(h, ws.stats, 128, hipMemcpyDeviceToHost, idx->stream));
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    HIP_TRY(hipMemcpyAsync(h, ws.stats, 128, hipMemcpyDeviceToHost, work_stream(idx)));
+    HIP_TRY(hipStreamSynchronize(work_stream(idx)));
     const double nr = h[0] ? (double)h[0] : 1.0;
     fprintf(stderr, "walk stats: %llu regions | per region: search iterations %.1f (literal %.2f), jumps %.1f, steps %.1f, variants %.1f | "
             "mean ticks(10ns): search %.0f walk %.0f head %.0f | max: search iters %llu steps %llu search ticks %llu walk ticks %llu\n",
@@ -1538,7 +1605,7 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   }
 #endif
   if (!single_walk && n) { counting_walk(); HIP_TRY(hipGetLastError()); }
-  HIP_TRY(hipEventRecord(idx->ev[1], idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[1], work_stream(idx)));
   c.resident = idx->opts.resident_lists && idx->res_arena && single_walk;
   ListClaims lc{};
   bool share_t4 = false;   // one carrier list per reported VERTEX, shared by the rows that report it
@@ -1551,7 +1618,7 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
     if (!idx->t4_claim) {
       HIP_TRY(hipMalloc((void**)&idx->t4_claim, (idx->d.V + 1) * 8));
       idx->image_allocs.push_back(idx->t4_claim);
-      HIP_TRY(hipMemsetAsync(idx->t4_claim, 0, (idx->d.V + 1) * 8, idx->stream));
+      HIP_TRY(hipMemsetAsync(idx->t4_claim, 0, (idx->d.V + 1) * 8, work_stream(idx)));
     }
     uint64_t* own_base = nullptr;
     VS_TRY(dev_alloc(idx, (cap_rows + 1) * 4, (void**)&lc.own_pad, &scratch.bufs));
@@ -1559,9 +1626,10 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&lc.q_own, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 2) * 8, (void**)&own_base, &scratch.bufs));
     lc.claim = idx->t4_claim; lc.gen = ++idx->t4_gen; lc.own_base = own_base; lc.rows_cap = cap_rows;
-    hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, idx->stream, idx->d, d, ws, lc);
+    if (idx->pre) HIP_TRY(hipStreamWaitEvent(idx->pre, idx->ev[3], 0));   // the handle's claim table: the emitter of the batch before reads it
+    hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, work_stream(idx), idx->d, d, ws, lc);
     VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
-    hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, d, lc);
+    hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), d, lc);
     share_t4 = true;
   }
   // the walk's overflow flag, the claims' arena total and what the capacities added up to (the scan's totals are in mapped memory
@@ -1569,6 +1637,8 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   uint64_t cap_seen = 0;
   VS_TRY(read_device_words(idx, single_walk ? ws.overflow : nullptr, &walk_overflow, share_t4 ? lc.own_base + n : nullptr, &t4_arena,
                            speculative ? cap_total_dev : nullptr, &cap_seen));
+  pre.done();   // (that part is over: the host has seen its last kernel's words; the rest goes on the handle's stream)
+  if (c.words) words_read_clean(idx, walk_overflow);   // (ids out of range: verdict 3 in the same word, or the early return above)
   if (speculative) {
     uint64_t& hint = idx->walk_cap_hint[walk_mode == 5 ? 1 : 0];
     if (walk_overflow == 3) return bad_ids_error(idx);
@@ -1704,6 +1774,10 @@ static int run_sample_seq(vs_index* idx, const vs_region* regions, uint64_t n, c
 }
 static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t n, const uint32_t* sample_ids, int mode, vs_result* r, bool speculate, bool* refused) {
   DevSeqResult& q = r->sq;
+  // everything in front of the host wait on the handle's second stream, beside the previous batch's k_copy_segments (PreStream)
+  const bool aside = idx->opts.async_submit && speculate && n > 0 && !idx->opts.force_fallbacks && !idx->opts.lat_debug;
+  if (aside) VS_TRY(ensure_plan_stream(idx));
+  PreStream pre(idx, aside ? idx->plan_stream : nullptr);
   if (idx->srv_alive) VS_TRY(server_stop(idx));
   idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;
   q.Q = n;
@@ -1718,13 +1792,24 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
   VS_TRY(ralloc(r, n, &q.q_nbytes));
   VS_TRY(ralloc(r, n + 1, &q.seg_begin));
   VS_TRY(ralloc(r, n + 1, &q.byte_begin));
-  uint64_t* bad_ids = nullptr;
+  uint64_t *bad_ids = nullptr, *words = nullptr;   // (the batch's flag words, batch_words: [0] ids out of range, [1] the walk's overflow word)
+  bool caps_done = false;
   if (n) {
-    HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyDefault, idx->stream));
-    HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyDefault, idx->stream));
-    if (is_device_ptr(sample_ids)) VS_TRY(check_device_ids(idx, r, dsids, n, &bad_ids));
+    const bool ids_on_device = is_device_ptr(sample_ids);
+    VS_TRY(batch_words(idx, &words));
+    if (ids_on_device) bad_ids = words;
+    if (ids_on_device && !idx->opts.force_fallbacks && is_device_ptr(regions)) {   // copies, id check and piece capacities in one launch
+      hipLaunchKernelGGL(k_seq_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, q, reinterpret_cast<const uint64_t*>(regions), sample_ids,
+                         idx->g.num_samples, words, (uint32_t)(mode == 3));
+      HIP_TRY(hipGetLastError());
+      caps_done = true;
+    } else {
+      HIP_TRY(hipMemcpyAsync(dreg, regions, n * 16, hipMemcpyDefault, work_stream(idx)));
+      HIP_TRY(hipMemcpyAsync(dsids, sample_ids, n * 4, hipMemcpyDefault, work_stream(idx)));
+      if (ids_on_device) VS_TRY(check_device_ids(idx, dsids, n, bad_ids));
+    }
   }
-  HIP_TRY(hipEventRecord(idx->ev[0], idx->stream));
+  HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));
   ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
   if (bad_ids && idx->opts.force_fallbacks) {
@@ -1736,16 +1821,16 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
   // offsets.  A region that outgrows its capacity sends the batch down the count-then-emit path.
   bool single_walk = n > 0 && !idx->opts.force_fallbacks;
   if (single_walk) {
-    VS_TRY(ralloc(r, 1, &q.overflow));
-    HIP_TRY(hipMemsetAsync(q.overflow, 0, 8, idx->stream));
-    hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, idx->d, q, (uint32_t)(mode == 3));
+    q.overflow = words + 1;
+    q.admit = WalkAdmit{};   // (a batch that is redone with the exact size keeps its result: nothing to admit then)
+    if (!caps_done) hipLaunchKernelGGL(k_seq_caps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), idx->d, q, (uint32_t)(mode == 3));
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nseg, n, q.seg_begin, &scratch.bufs));
     uint64_t bad = 0;
     uint64_t& hint = idx->seq_cap_hint[mode == 3 ? 1 : 0];
     const bool speculative = speculate && hint > 0 && idx->opts.async_submit;
     if (speculative) {
       totals[0] = hint;
-      hipLaunchKernelGGL(k_walk_admit, dim3(1), dim3(1), 0, idx->stream, (const uint64_t*)(q.seg_begin + n), hint, (const uint64_t*)bad_ids, q.overflow);
+      q.admit = WalkAdmit{q.seg_begin + n, hint, bad_ids};   // (the walk's first look: seq_void)
     } else {
       VS_TRY(read_device_words(idx, q.seg_begin + n, &totals[0], bad_ids, &bad));
       if (bad) return bad_ids_error(idx);
@@ -1761,6 +1846,8 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
     VS_TRY(exclusive_scan<uint64_t>(idx, q.q_nbytes, n, q.byte_begin, &scratch.bufs));
     uint64_t over = 0, cap_seen = 0;
     VS_TRY(read_device_words(idx, q.byte_begin + n, &totals[1], q.overflow, &over, speculative ? q.seg_begin + n : nullptr, &cap_seen));
+    pre.done();   // (the rest goes on the handle's stream)
+    words_read_clean(idx, over);
     if (speculative) {
       if (over == 3) return bad_ids_error(idx);
       if (over == 2) { hint = cap_seen + cap_seen / 8 + 1024; *refused = true; return VS_OK; }

@@ -207,14 +207,34 @@ __device__ __forceinline__ bool rewind_to_sample_pos_ev(const DevImage& im, uint
 
 // Capacities of the single recording walk of type 5: branch sites of the reference range [x, y) widened by the
 // region's own length (the sample's coordinates are shifted against the reference's by its net indel length).
-__global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= r.Q) return;
+__device__ __forceinline__ void walk_caps_sc_region(const DevImage& im, const DevResult& r, uint64_t q) {
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   const uint64_t margin = (y > x ? y - x : 0) + 256;
   const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
   const uint32_t s0 = slot_of_find(im, lo), s1 = slot_of_find(im, hi);
   r.q_nvar[q] = (s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0) + 8;
+}
+__global__ void __launch_bounds__(256) k_walk_caps_sc(DevImage im, DevResult r) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < r.Q) walk_caps_sc_region(im, r, q);
+}
+// The first kernel of a type-4 / type-5 batch whose regions and sample ids arrive in DEVICE memory: the result's copies of both,
+// the range check of the ids (`bad`: zero when the batch starts) and the capacities -- one launch where two copies, a
+// memset and two kernels stood.  src_ids NULL: one sample for the whole batch, checked by the host.
+template <bool SC>
+__global__ void __launch_bounds__(256) k_walk_setup(DevImage im, DevResult r, const uint64_t* __restrict__ src_regions, const uint32_t* __restrict__ src_ids,
+                                                    uint32_t* dsids, uint32_t num_samples, uint64_t* bad) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  uint64_t* reg = const_cast<uint64_t*>(r.regions);
+  reg[2 * q] = src_regions[2 * q]; reg[2 * q + 1] = src_regions[2 * q + 1];
+  if (src_ids) {
+    const uint32_t sid = src_ids[q];
+    dsids[q] = sid;
+    if (sid >= num_samples) *bad = 1;
+  }
+  if (SC) walk_caps_sc_region(im, r, q);
+  else region_bounds(im, r, q);
 }
 
 // Query type 5.  MODE as in k_sample_walk (0 count, 1 emit, 2 record once).
@@ -423,8 +443,9 @@ struct DevSeqResult {
   uint32_t *seg_src, *seg_len;      // [nseg]
   uint64_t* seg_dst;                // [nseg] byte offset in chars (relative to the region's first byte when `relative`)
   uint8_t* chars;
-  uint64_t* overflow;               // single-walk mode: set when a region outgrew its piece capacity
+  uint64_t* overflow;               // single-walk mode: set when a region outgrew its piece capacity (2 / 3: the batch was refused, seq_void)
   uint32_t relative, pad_;          // single-walk mode: pieces sit at seg_begin[q] .. + q_nseg[q], seg_begin = capacities' scan
+  WalkAdmit admit;                  // the piece list was sized from the previous batch: does this one fit (k_walk.hip.h)
 };
 
 // Per-region records of a SEQUENCE result (query types 2 / 3) for the collective, in the format of k_pack_regions:
@@ -438,11 +459,16 @@ __global__ void __launch_bounds__(256) k_pack_seq_regions(DevSeqResult r, uint64
   dst[4 * q + 3] = r.byte_begin[q + 1] - r.byte_begin[q];
 }
 
-// a batch whose piece list was sized from the previous batch and does not fit (k_walk_admit set overflow to 2, or 3 for a
-// sample id out of range) records nothing: no pieces, no bytes
+// a batch whose piece list was sized from the previous batch and does not fit (verdict 2, or 3 for a sample id out of range:
+// admit_verdict) records nothing: no pieces, no bytes
 __device__ __forceinline__ bool seq_void(const DevSeqResult& r, uint64_t q, bool writer) {
-  if (!r.overflow || *r.overflow < 2) return false;
-  if (writer && q < r.Q) { r.q_nseg[q] = 0; r.q_nbytes[q] = 0; }
+  if (!r.overflow) return false;
+  const uint32_t verdict = admit_verdict(r.admit);
+  if (!verdict) return false;
+  if (writer) {
+    if (q < r.Q) { r.q_nseg[q] = 0; r.q_nbytes[q] = 0; }
+    *r.overflow = verdict;
+  }
   return true;
 }
 
@@ -1058,9 +1084,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 
 // Piece capacity of a region for the single walk: twice the ref-path slots plus branch sites of the (for sample
 // coordinates: generously widened) reference range, plus slack.  Too small a guess only costs the fallback.
-__global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, uint32_t sample_coordinates) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= r.Q) return;
+__device__ __forceinline__ void seq_caps_region(const DevImage& im, const DevSeqResult& r, uint64_t q, uint32_t sample_coordinates) {
   const uint64_t x = r.regions[2 * q], y = r.regions[2 * q + 1];
   const uint64_t margin = sample_coordinates ? (y > x ? y - x : 0) + 256 : 0;
   const uint64_t lo = x > margin + 1 ? x - margin : 1, hi = (y > x ? y : x) + margin;
@@ -1068,6 +1092,24 @@ __global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, u
   const uint64_t slots = s1 >= s0 ? (uint64_t)(s1 - s0) + 1 : 1;
   const uint64_t sites = s1 >= s0 ? (uint64_t)(im.rp_cand_prefix[s1 + 1] - im.rp_cand_prefix[s0]) : 0;
   r.q_nseg[q] = 2 * (slots + sites) + 8;
+}
+__global__ void __launch_bounds__(256) k_seq_caps(DevImage im, DevSeqResult r, uint32_t sample_coordinates) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < r.Q) seq_caps_region(im, r, q, sample_coordinates);
+}
+// the same for a batch of query types 2 / 3 whose regions and sample ids arrive in device memory, fused with the copies and the
+// range check of the ids (k_walk_setup)
+__global__ void __launch_bounds__(256) k_seq_setup(DevImage im, DevSeqResult r, const uint64_t* __restrict__ src_regions, const uint32_t* __restrict__ src_ids,
+                                                   uint32_t num_samples, uint64_t* bad, uint32_t sample_coordinates) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= r.Q) return;
+  uint64_t* reg = const_cast<uint64_t*>(r.regions);
+  uint32_t* ids = const_cast<uint32_t*>(r.sids);
+  reg[2 * q] = src_regions[2 * q]; reg[2 * q + 1] = src_regions[2 * q + 1];
+  const uint32_t sid = src_ids[q];
+  ids[q] = sid;
+  if (sid >= num_samples) *bad = 1;
+  seq_caps_region(im, r, q, sample_coordinates);
 }
 
 // Decode the pieces into characters (map_int, util.cc:32-41: codes 0..4 -> "ACTGN", anything else -> char 5).  One wave

@@ -145,4 +145,94 @@ __global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const uint64_t* nvar
   }
 }
 
+// ---------------------------------------------------------------------------
+// Up to kScanSmallMax elements: ONE launch.  A walking batch of ten thousand regions is a string of a dozen dependent launches of a
+// few microseconds each, and its three scans were nine of them.  Up to four blocks of 1024 threads, a tile of 4096 elements each;
+// a block adds up the tiles in front of its own BY ITSELF (at most 12 coalesced loads per thread, all in flight at once) instead of
+// waiting for anybody -- the same trade as k_t6_mid's -- and scans its tile with one block scan.  in and out must not overlap.
+// (Measured before this form, round 5: one block for everything with 16 consecutive elements per thread -- its strided accesses
+//  took 8 - 21 us per launch -- and one wave per segment with a wave scan per 64 elements -- coalesced, but ten rounds of ~120
+//  dependent cross-lane moves each: 10 - 26 us.)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScanSmallBlock = 1024, kScanSmallItems = 4, kScanSmallTile = kScanSmallBlock * kScanSmallItems, kScanSmallMax = 4 * kScanSmallTile;
+constexpr uint32_t kScanSmallPre = (kScanSmallMax - kScanSmallTile) / kScanSmallBlock;   // loads per thread that cover every tile in front of the last
+
+// out[0..n) = exclusive prefix of in, out[n] = total
+template <typename T>
+__global__ void __launch_bounds__(kScanSmallBlock) k_scan_small(const T* __restrict__ in, uint32_t n, uint64_t* __restrict__ out) {
+  __shared__ uint64_t wsum[kScanSmallBlock / 64], wpre[kScanSmallBlock / 64];
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tile0 = blockIdx.x * kScanSmallTile, base = tile0 + threadIdx.x * kScanSmallItems;
+  uint64_t pre = 0, v[kScanSmallItems];
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallPre; ++k) {
+    const uint32_t i = k * kScanSmallBlock + threadIdx.x;
+    pre += i < tile0 ? (uint64_t)in[i] : 0;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) v[k] = base + k < n ? (uint64_t)in[base + k] : 0;
+  uint64_t own = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) own += v[k];
+  uint64_t incl = own;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(incl, d, 64);
+    pre += __shfl_xor(pre, d, 64);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+  if (lane == 63) { wsum[wid] = incl; wpre[wid] = pre; }
+  __syncthreads();
+  uint64_t ex = incl - own;
+  for (uint32_t w = 0; w < kScanSmallBlock / 64; ++w) ex += wpre[w] + (w < wid ? wsum[w] : 0);
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanSmallBlock - 1) out[n] = ex;   // (elements past n count as zero)
+}
+// both offset arrays of a batch (k_scan2_*): prefixes, the totals at [n] and in `totals` (mapped host memory; NULL: not wanted)
+__global__ void __launch_bounds__(kScanSmallBlock) k_scan2_small(const uint64_t* __restrict__ nvar, const uint64_t* __restrict__ ncar, uint32_t n,
+                                                                 uint64_t* __restrict__ var_begin, uint64_t* __restrict__ car_base, uint64_t* totals) {
+  __shared__ Scan2 wsum[kScanSmallBlock / 64], wpre[kScanSmallBlock / 64];
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tile0 = blockIdx.x * kScanSmallTile, base = tile0 + threadIdx.x * kScanSmallItems;
+  Scan2 pre{0, 0};
+  uint64_t va[kScanSmallItems], vc[kScanSmallItems];
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallPre; ++k) {
+    const uint32_t i = k * kScanSmallBlock + threadIdx.x;
+    const bool live = i < tile0;
+    pre.a += live ? nvar[i] : 0; pre.c += live ? ncar[i] : 0;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) {
+    const bool live = base + k < n;
+    va[k] = live ? nvar[base + k] : 0; vc[k] = live ? ncar[base + k] : 0;
+  }
+  Scan2 own{0, 0};
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) { own.a += va[k]; own.c += vc[k]; }
+  Scan2 incl = own;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t ta = __shfl_up(incl.a, d, 64), tc = __shfl_up(incl.c, d, 64);
+    pre.a += __shfl_xor(pre.a, d, 64); pre.c += __shfl_xor(pre.c, d, 64);
+    if (lane >= (uint32_t)d) { incl.a += ta; incl.c += tc; }
+  }
+  if (lane == 63) { wsum[wid] = incl; wpre[wid] = pre; }
+  __syncthreads();
+  Scan2 ex{incl.a - own.a, incl.c - own.c};
+  for (uint32_t w = 0; w < kScanSmallBlock / 64; ++w) {
+    const Scan2 p = wpre[w], t = wsum[w];
+    ex.a += p.a + (w < wid ? t.a : 0); ex.c += p.c + (w < wid ? t.c : 0);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) {
+    if (base + k < n) { var_begin[base + k] = ex.a; car_base[base + k] = ex.c; }
+    ex.a += va[k]; ex.c += vc[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanSmallBlock - 1) {
+    var_begin[n] = ex.a; car_base[n] = ex.c;
+    if (totals) { totals[0] = ex.a; totals[1] = ex.c; }
+  }
+}
+
 }  // namespace vsamd

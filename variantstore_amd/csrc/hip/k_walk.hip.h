@@ -147,14 +147,31 @@ __device__ __forceinline__ bool record_has_sample(const DevImage& im, uint32_t v
 // it records every reported vertex in a scratch list whose per-region capacity is the region's type-6 slot count
 // (a sample's variants are branches of the same ref-path range) and flags an overflow instead of writing past it;
 // k_emit_from_walk then lays the headers out without walking again.
+// Round 5: the walking query types wait for the host ONCE per batch.  The scratch of the recording walk is sized from what the
+// handle's previous batch of the kind needed (+ 1/8); the recording walk itself, first thing, compares the capacities' total (the
+// scan in front of it left it in device memory) with that allocation and refuses the batch (overflow = 2) when it does not fit --
+// or when an id that arrived in device memory is out of range (3: k_walk_setup / k_check_sample_ids left the word) -- and then
+// the walk, k_t4_claim and the emitters touch nothing beyond the per-region arrays: the host reads the word together with the
+// batch's sizes and redoes a refused batch with an exact allocation (one more wait, once).  (Until the end of round 5 a
+// one-thread kernel between scan and walk gave the verdict: one launch more in a string of dependent launches.)
+struct WalkAdmit {
+  const uint64_t* cap_total;   // the capacities' total, on the device; NULL: the allocation is exact, nothing to admit
+  uint64_t cap_alloc;          // what the scratch holds
+  const uint64_t* bad_ids;     // non-zero: a sample id of the batch is out of range (NULL: the host checked the ids)
+};
+__device__ __forceinline__ uint32_t admit_verdict(const WalkAdmit& a) {
+  if (!a.cap_total) return 0;
+  if (a.bad_ids && *a.bad_ids) return 3;
+  return *a.cap_total > a.cap_alloc ? 2u : 0u;
+}
 struct WalkScratch {
   const uint64_t* cap_begin;   // [Q+1] exclusive scan of the capacities
   uint64_t* pos;
   uint32_t *cur, *ro, *rl, *ao, *al;
-  uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path); 2 / 3 BEFORE the
-                               // walk starts (k_walk_admit): the scratch was sized from the previous batch and this one needs more / a
-                               // sample id of the batch is out of range -- the recording walks then record nothing (walk_void)
+  uint64_t* overflow;          // set to 1 when a region outgrew its capacity (the host then takes the two-walk path); 2 / 3: the batch
+                               // was refused before the walk started (walk_void)
   unsigned long long* stats;   // tuning builds (VS_TUNING): 16 counters of k_sample_walk (iteration counts, device-clock ticks); else NULL
+  WalkAdmit admit;
 };
 #ifdef VS_TUNING
 #define VS_WALK_STAT(i, v) do { if (ws.stats) atomicAdd(&ws.stats[i], (unsigned long long)(v)); } while (0)
@@ -166,19 +183,16 @@ struct WalkScratch {
 #define VS_WALK_CLOCK() 0ULL
 #endif
 
-// Round 5: the walking query types wait for the host ONCE per batch.  The scratch of the recording walk is sized from what the
-// handle's previous batch of the kind needed (+ 1/8); k_walk_admit, behind the capacities' scan, compares the scan's total with
-// that allocation and refuses the batch (overflow = 2) when it does not fit -- or when k_check_sample_ids found an id out of
-// range (3) -- and the recording walks, k_t4_claim and the emitters then touch nothing beyond the per-region arrays: the host
-// reads the word together with the batch's sizes and redoes a refused batch with an exact allocation (one more wait, once).
-__global__ void k_walk_admit(const uint64_t* cap_total, uint64_t cap_alloc, const uint64_t* bad_ids, uint64_t* overflow) {
-  if (bad_ids && *bad_ids) *overflow = 3;
-  else if (*cap_total > cap_alloc) *overflow = 2;
-}
-// first thing in a recording walk: a refused batch reports no rows (its regions' capacities are what the bounds left in q_nvar)
+// first thing in a recording walk: a refused batch reports no rows (its regions' capacities are what the bounds left in q_nvar;
+// every thread of the launch reaches the same verdict, the writers leave it for the host)
 __device__ __forceinline__ bool walk_void(const DevResult& r, const WalkScratch& ws, uint64_t q, bool writer) {
-  if (!ws.overflow || *ws.overflow < 2) return false;
-  if (writer && q < r.Q) { r.q_nvar[q] = 0; r.q_ncar[q] = 0; r.var_count[q] = 0; }
+  if (!ws.overflow) return false;
+  const uint32_t verdict = admit_verdict(ws.admit);
+  if (!verdict) return false;
+  if (writer) {
+    if (q < r.Q) { r.q_nvar[q] = 0; r.q_ncar[q] = 0; r.var_count[q] = 0; }
+    *ws.overflow = verdict;
+  }
   return true;
 }
 

@@ -40,7 +40,7 @@
 //                       pieces of the sequence pool; k_copy_segments decodes them;
 // k_sample_seq_coop      the cooperative form (window logic of query.h:160-177 / :236-247 at the hand-over)
 // k_sample_walk_coop    get_prev_vertex_with_sample + get_sample_var_in_ref (query.h:618-729, type 4), eight lanes per region;
-//  (k_sample_walk)       k_walk_admit holds a batch to the scratch its predecessor needed; k_t4_claim / _offsets: one carrier
+//  (k_sample_walk)       WalkAdmit holds a batch to the scratch its predecessor needed; k_t4_claim / _offsets: one carrier
 //                       list per reported vertex; k_emit_from_walk: the rows (query.h:680-704)
 // k_pack_regions /      what a sharded run gathers per region (the reference's loop, src/commands.cc:145-193, prints counts and
 //  k_pack_seq_regions    flags per region): site range + counts, or pieces + bytes of a sequence; k_bounds_from_records: the
