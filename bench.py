@@ -952,10 +952,12 @@ def main():
         #  result is closed one step late, so the host is not between the batches)
         dt4 = back_to_back(lambda: vs.get_sample_var_in_ref(regions4, per_region), 6)
         walk_ms = 0.0
+        vs.set_option("phase_events", 1)   # (the timed loop above ran without them: every event is a packet between two kernels)
         for _k in range(3):   # the walk phase by the handle's events (reading them waits for the batch: outside the timed loop)
             r4 = vs.get_sample_var_in_ref(regions4, per_region)
             walk_ms += vs.last_timing().ms_bounds
             r4.close()
+        vs.set_option("phase_events", 0)
         t4 = {"queries_per_s": nreg / dt4, "ms_per_batch": dt4 * 1e3, "regions_per_batch": nreg, "samples": 16, "inputs": "device memory",
               "variants_per_region": nv4 / nreg, "carriers_per_variant": nc4 / max(nv4, 1), "walk_phase_ms": walk_ms / 3}
         tw = (tj["kernels"].get("k_sample_walk_coop") or tj["kernels"].get("k_sample_walk")) if tj else None

@@ -331,7 +331,7 @@ void vs_comm_destroy(vs_comm* c);
 
 /* ---- switches of one handle ----
  * The environment is read once when a handle is opened; afterwards only this call changes a
- * switch.  The production library has NINE keys:
+ * switch.  The production library has TEN keys:
  *   "latency_server"  0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first small query
  *   "server_blocks"   1..64 blocks of the resident server
  *   "share_lists"     1 (default): a type-6 batch of more than 64 regions holds one row and one carrier list per covered
@@ -351,6 +351,9 @@ void vs_comm_destroy(vs_comm* c);
  *                     then visit every vertex, same answers), absent rows are built when they fit it and half of the free
  *                     memory.  Several handles on one GPU: the caller decides which of them keeps its rows.  Waits for the
  *                     device before it frees anything.
+ *   "phase_events"    1 = batches of query types 4 and 5 record all five phase events, so that vs_index_last_timing reports their
+ *                     phases (walk, sizes, rows, expansion); default 0: first and last event only -- ms_total, phases 0 -- because
+ *                     every event is a packet between two kernels of a string of dependent launches (~3 us each)
  *   "force_fallbacks" 1 = query types 2 - 5 take the count-then-emit pair of walks they fall back to when a region outgrows
  *                     the capacity of its recording walk (tests of that path)
  * Tuning builds (VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) add "lat_debug", "fill_fused", "fill_chunk",

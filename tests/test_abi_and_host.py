@@ -127,10 +127,10 @@ def test_handle_options_are_checked():
     vs = VariantStore.synthetic(device=-1, ref_length=20_000, num_variants=50, num_samples=4, seed=3, first_pos=10)
     for key, good in (("latency_server", 0), ("latency_server", 2), ("server_blocks", 8), ("t4_walk", 0), ("t4_walk", 1), ("t4_walk", 2),
                       ("share_lists", 0), ("share_lists", 1), ("force_fallbacks", 1), ("force_fallbacks", 0),
-                      ("async_fill", 1), ("async_fill", 0), ("async_submit", 0), ("async_submit", 1), ("resident_lists", 0)):
+                      ("async_fill", 1), ("async_fill", 0), ("async_submit", 0), ("async_submit", 1), ("resident_lists", 0), ("phase_events", 1), ("phase_events", 0)):
         vs.set_option(key, good)
     for key, bad in (("latency_server", 3), ("server_blocks", 0), ("server_blocks", 65), ("t4_walk", 3), ("no_such_switch", 1),
-                     ("fill_chunk", 16), ("fill_split", 0), ("lat_debug", 1), ("t4_coop", 8),   # tuning builds only / gone: the production library has nine keys
+                     ("fill_chunk", 16), ("fill_split", 0), ("lat_debug", 1), ("t4_coop", 8),   # tuning builds only / gone: the production library has ten keys
                      ("share_lists", 2), ("resident_lists", 2), ("resident_lists", 1),   # (resident lists need a device)
                      ("t4_rows_max_mb", -1), ("t4_rows_max_mb", 0), ("t4_rows_max_mb", 64)):   # (and so do the rows of query type 4)
         with pytest.raises(VariantStoreError):

@@ -18,6 +18,7 @@ kw["ref_length"] = max(200_000, w["ref_length"] * 2 // 25)
 kw["num_variants"] = max(1000, w["num_variants"] * 2 // 25)
 kw["first_pos"] = min(w["first_pos"], kw["ref_length"] // 10)
 vs = VariantStore.synthetic(device=0, sample_coordinates=True, **kw)
+vs.set_option("phase_events", 1)   # the phase times of walking batches are read below
 if os.environ.get("VS_SC_GROUP"):
     vs.set_option("sc_group", int(os.environ["VS_SC_GROUP"]))   # (tuning builds)
 n = int(os.environ.get("VS_SC_REGIONS", "100000"))

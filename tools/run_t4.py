@@ -12,6 +12,7 @@ from variantstore_amd import VariantStore
 
 w = dict(bench.WORKLOADS[os.environ.get("VS_BENCH_WORKLOAD", "chr1-2504")])
 vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
+vs.set_option("phase_events", 1)   # the phase times of walking batches are read below
 nreg = w["regions"]
 regions = bench.make_regions(w, 0, nreg)
 ns = vs.info().num_samples

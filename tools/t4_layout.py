@@ -4,6 +4,7 @@ import numpy as np, bench
 from variantstore_amd import VariantStore
 w = dict(bench.WORKLOADS["chr1-2504"])
 vs = VariantStore.synthetic(device=0, **bench.synth_kwargs(w))
+vs.set_option("phase_events", 1)   # the phase times of walking batches are read below
 nreg = w["regions"]; regions = bench.make_regions(w, 0, nreg)
 ns = vs.info().num_samples
 sids16 = [1 + (i * 157) % (ns - 1) for i in range(16)]

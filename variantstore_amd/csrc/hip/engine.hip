@@ -69,6 +69,7 @@ struct EngineOpts {
   bool force_fallbacks = false; // "force_fallbacks": the count-then-emit pairs of walks that query types 2 - 5 fall back to when a region
                                 // outgrows the capacity of its recording walk (tests of those paths)
   // ---- read from the environment when the handle is opened ----
+  bool phase_events = false;    // walking batches record all five phase events (vs_index_last_timing's phases); default: first and last only
   bool no_t4_events = false;    // VS_T4_NO_EVENTS: do not build the event bitmaps at all
   // ---- tuning builds only (VS_TUNING: VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) ----
   bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
@@ -99,7 +100,11 @@ struct vs_index {
   std::string seq_chars;
   std::unordered_map<std::string, uint32_t> sample_ids;
   std::vector<DevBuf> pool;
-  unsigned long long* t4_claim = nullptr;   // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped
+  // [V] list claims of the walking query types (kernels.hip.h: k_t4_claim), generation-stamped.  TWO tables, taken in turn: the claims of
+  // a batch are made in front of its host wait on the second stream while the emitter of the batch before may still be reading its own
+  // on the handle's stream; a table's next user (two batches on) waits for the completion event of its last (t4_claim_done).
+  unsigned long long* t4_claim[2] = {nullptr, nullptr};
+  hipEvent_t t4_claim_done[2] = {nullptr, nullptr};
   uint64_t t4_gen = 0;
   hipStream_t plan_stream = nullptr;        // the plan of an async_submit batch runs here, beside the previous batch's expansion on `stream`
   hipStream_t fill_stream = nullptr;        // second stream: the expansion of an async_fill batch
@@ -266,7 +271,7 @@ static int alloc_image(vs_index* idx, size_t n, T** dptr) {
 // expansion of the batch before, which are on the handle's stream; the host has seen that part's last kernel post its words before
 // it enqueues the rest, so no event links the two.  What the part reads is the caller's input and the index, what it writes is the
 // batch's own (a batch that returned when it was enqueued keeps its temporaries until its completion event) -- but for the claim
-// table of the type-4 lists, which belongs to the handle: k_t4_claim waits for the previous batch's emitter (ev[3]).
+// tables of the type-4 lists, which belong to the handle: two, taken in turn (vs_index::t4_claim).
 // The helpers below launch on work_stream(idx): the second stream while a PreStream guard is alive, else the handle's.
 static inline hipStream_t work_stream(const vs_index* idx) { return idx->pre ? idx->pre : idx->stream; }
 struct PreStream {
@@ -1266,6 +1271,7 @@ struct BatchCtx {
   uint64_t* bad_ids = nullptr;   // ids that arrived in device memory: set by k_walk_setup / k_check_sample_ids, read with the batch's first sizes
   uint64_t* words = nullptr;     // a walking batch's flag words (the handle's, zero when the batch starts: batch_words): [0] bad_ids, [1] the walk's overflow word
   bool caps_done = false;        // the capacities of the recording walk were written by the batch's first kernel (k_walk_setup)
+  bool lean_events = false;      // first and last event only (every event is a packet between two kernels of a string of dependent launches)
   bool resident = false;         // rows point into the index's resident arena: nothing is expanded
   bool async_fill = false;
   BatchCtx(vs_index* i, vs_result* res, uint64_t nn) : idx(i), r(res), n(nn), scratch(i) {}
@@ -1318,6 +1324,7 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
   VS_TRY(ralloc(r, n + 1, &d.car_base));
   VS_TRY(ralloc(r, n, &d.var_count));
   static_assert(sizeof(vs_region) == 16, "vs_region layout");
+  if (c.lean_events) HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));   // (in front of the first kernel, not between two)
   const bool ids_on_device = sample_ids && n && is_device_ptr(sample_ids);
   if (n && (walk_caps >= 0 || ids_on_device)) {
     VS_TRY(batch_words(idx, &c.words));
@@ -1340,7 +1347,7 @@ static int batch_setup(BatchCtx& c, const vs_region* regions, bool regions_on_de
       if (ids_on_device) VS_TRY(check_device_ids(idx, c.dsids, n, c.bad_ids));
     }
   }
-  HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));
+  if (!c.lean_events) HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));
   return VS_OK;
 }
 
@@ -1379,7 +1386,7 @@ static int batch_tables(BatchCtx& c, uint64_t rows, uint64_t arena, bool shared_
     VS_TRY(ralloc(r, d.S * d.car_width + 16, &a));
     d.carriers = a;
   }
-  HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
+  if (!c.lean_events) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   return VS_OK;
 }
 
@@ -1388,7 +1395,7 @@ static int batch_tables(BatchCtx& c, uint64_t rows, uint64_t arena, bool shared_
 static int batch_fill(BatchCtx& c, bool allow_async) {
   vs_index* idx = c.idx;
   vs_result* r = c.r;
-  HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
+  if (!c.lean_events) HIP_TRY(hipEventRecord(idx->ev[3], idx->stream));
   const uint64_t n_fill = c.resident ? 0 : r->d.A;
   c.async_fill = allow_async && idx->opts.async_fill && n_fill > 0;
   if (c.async_fill) {
@@ -1411,6 +1418,7 @@ static int batch_fill(BatchCtx& c, bool allow_async) {
 static int batch_finish(BatchCtx& c, bool enqueued = false) {
   vs_index* idx = c.idx;
   HIP_TRY(hipEventRecord(idx->ev[4], idx->stream));
+  if (c.lean_events) idx->timing_total_only = true;
   if (enqueued) {
     vs_result* r = c.r;
     VS_TRY(pooled_event(idx, &r->ev_done));
@@ -1530,6 +1538,7 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   const bool aside = idx->opts.async_submit && speculate && n > 0 && !idx->opts.force_fallbacks && !idx->opts.walk_stats && !idx->opts.lat_debug;
   if (aside) VS_TRY(ensure_plan_stream(idx));
   PreStream pre(idx, aside ? idx->plan_stream : nullptr);
+  c.lean_events = aside && !idx->opts.phase_events;
   VS_TRY(batch_setup(c, regions, false, sample_ids, idx->opts.force_fallbacks ? -1 : (walk_mode == 5 ? 1 : 0)));
   DevResult& d = r->d;
   ScratchBufs& scratch = c.scratch;
@@ -1605,28 +1614,35 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   }
 #endif
   if (!single_walk && n) { counting_walk(); HIP_TRY(hipGetLastError()); }
-  HIP_TRY(hipEventRecord(idx->ev[1], work_stream(idx)));
+  if (!c.lean_events) HIP_TRY(hipEventRecord(idx->ev[1], work_stream(idx)));
   c.resident = idx->opts.resident_lists && idx->res_arena && single_walk;
   ListClaims lc{};
   bool share_t4 = false;   // one carrier list per reported VERTEX, shared by the rows that report it
+  int claim_tab = -1;      // which of the handle's two claim tables the batch took
   uint64_t t4_arena = 0;
   VS_TRY(batch_sizes(c));
 
   if (single_walk && idx->opts.share_lists && n > 64 && !c.resident) {
     // (rows <= the scratch capacity the walk was given: the claim arrays can be sized before the row count is known)
     const uint64_t cap_rows = ws_capacity;
-    if (!idx->t4_claim) {
-      HIP_TRY(hipMalloc((void**)&idx->t4_claim, (idx->d.V + 1) * 8));
-      idx->image_allocs.push_back(idx->t4_claim);
-      HIP_TRY(hipMemsetAsync(idx->t4_claim, 0, (idx->d.V + 1) * 8, work_stream(idx)));
+    const uint64_t gen = ++idx->t4_gen;
+    const int tab = (int)(gen & 1);
+    if (!idx->t4_claim[tab]) {
+      HIP_TRY(hipMalloc((void**)&idx->t4_claim[tab], (idx->d.V + 1) * 8));
+      idx->image_allocs.push_back(idx->t4_claim[tab]);
+      HIP_TRY(hipMemsetAsync(idx->t4_claim[tab], 0, (idx->d.V + 1) * 8, work_stream(idx)));
     }
+    // the table's last user (two batches back) has to be through with it: its completion event, if it returned when it was enqueued
+    // (the event is the result's, pooled: should it have been recorded again since, this waits for something later -- never for less)
+    if (idx->pre && idx->t4_claim_done[tab]) HIP_TRY(hipStreamWaitEvent(idx->pre, idx->t4_claim_done[tab], 0));
+    idx->t4_claim_done[tab] = nullptr;
+    claim_tab = tab;
     uint64_t* own_base = nullptr;
     VS_TRY(dev_alloc(idx, (cap_rows + 1) * 4, (void**)&lc.own_pad, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (cap_rows + 1) * 8, (void**)&lc.own_off, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 1) * 8, (void**)&lc.q_own, &scratch.bufs));
     VS_TRY(dev_alloc(idx, (n + 2) * 8, (void**)&own_base, &scratch.bufs));
-    lc.claim = idx->t4_claim; lc.gen = ++idx->t4_gen; lc.own_base = own_base; lc.rows_cap = cap_rows;
-    if (idx->pre) HIP_TRY(hipStreamWaitEvent(idx->pre, idx->ev[3], 0));   // the handle's claim table: the emitter of the batch before reads it
+    lc.claim = idx->t4_claim[tab]; lc.gen = gen; lc.own_base = own_base; lc.rows_cap = cap_rows;
     hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, work_stream(idx), idx->d, d, ws, lc);
     VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
     hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), d, lc);
@@ -1677,7 +1693,10 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
   }
   VS_TRY(batch_fill(c, false));
   // the batch is enqueued: return (async_submit), unless a tuning aid wants the host in the loop
-  return batch_finish(c, idx->opts.async_submit && single_walk && !idx->opts.walk_stats && !idx->opts.lat_debug);
+  const bool enqueued = idx->opts.async_submit && single_walk && !idx->opts.walk_stats && !idx->opts.lat_debug;
+  VS_TRY(batch_finish(c, enqueued));
+  if (claim_tab >= 0 && enqueued) idx->t4_claim_done[claim_tab] = r->ev_done;   // (not enqueued: the stream has been synchronised)
+  return VS_OK;
 }
 
 template <typename T>
@@ -1792,6 +1811,7 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
   VS_TRY(ralloc(r, n, &q.q_nbytes));
   VS_TRY(ralloc(r, n + 1, &q.seg_begin));
   VS_TRY(ralloc(r, n + 1, &q.byte_begin));
+  HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));   // (in front of the first kernel, not between two)
   uint64_t *bad_ids = nullptr, *words = nullptr;   // (the batch's flag words, batch_words: [0] ids out of range, [1] the walk's overflow word)
   bool caps_done = false;
   if (n) {
@@ -1809,7 +1829,6 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
       if (ids_on_device) VS_TRY(check_device_ids(idx, dsids, n, bad_ids));
     }
   }
-  HIP_TRY(hipEventRecord(idx->ev[0], work_stream(idx)));
   ScratchBufs scratch(idx);
   uint64_t totals[2] = {0, 0};
   if (bad_ids && idx->opts.force_fallbacks) {
@@ -2368,7 +2387,8 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     const uint64_t cap = (uint64_t)value << 20;
     if (idx->d.t4_events && idx->t4_rows_bytes > cap) VS_TRY(drop_t4_rows(idx));
     else if (!idx->d.t4_events && cap) VS_TRY(build_t4_rows(idx, cap));
-  } else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
+  } else if (k == "phase_events") o.phase_events = value != 0;
+  else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
   else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_mode" || k == "fill_dense_k" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {
 #ifdef VS_TUNING

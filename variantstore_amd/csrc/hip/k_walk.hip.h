@@ -822,6 +822,9 @@ __device__ __forceinline__ GroupFound group_search_prev(const DevImage& im, BitR
 // EXPL: the cohort keeps explicit sample ids (coarse event rows, hold tests from the carrier lists).  The class-row
 // instantiation carries none of that code -- at the 128 registers this kernel is held to, the eight ids a hold test reads
 // at a time cost it 40 bytes of scratch per lane and 12 % of its time on the chr1 cohort, which never runs them.
+// (Registers: 4 waves per SIMD = 128 VGPRs; the explicit-id form spills 23 of them there.  Measured round 5 on the 10,000-sample cohort:
+//  3 waves -- 142 VGPRs, nothing spilled -- 143 M regions/s against 158; 5 waves -- 96 VGPRs, 120 spilled -- 118; class-row cohort
+//  (chr1-2504) at 5 waves 119 against 124.  The walk is a chain of dependent look-ups: occupancy is worth more than the spills cost.)
 template <uint32_t SUB, bool EXPL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_sample_walk_coop(DevImage im, DevResult r, uint32_t sid_all, const uint32_t* sid_per_region,
                                                           WalkScratch ws) {
