@@ -224,6 +224,32 @@ for c in range(n_cohorts):
                 bad += 1
                 print(f"MISMATCH t5 (per-region samples) cohort {seed} sample {per_sc[q]} region {x}:{y}")
         r5.close()
+        # the same per-region batches with regions and sample ids handed over in DEVICE memory (the first kernel of the batch then
+        # takes the copies, checks the ids and sizes the walk: k_walk_setup / k_seq_setup) -- same digests and texts as from host arrays
+        stage("device inputs")
+        import torch
+        from variantstore_amd import DeviceArray
+        for regs, who in ((regions[:100], per), (sc_regions, per_sc)):
+            if not len(regs):
+                continue
+            reg_t = torch.from_numpy(np.array(regs, dtype=np.uint64).view(np.int64)).cuda()
+            ids_t = torch.from_numpy(np.array([vs.sample_id(nm) for nm in who], dtype=np.uint32).view(np.int32)).cuda()
+            dreg, dids = DeviceArray(reg_t.data_ptr(), len(regs)), DeviceArray(ids_t.data_ptr(), len(regs))
+            for name, call in (("4", vs.get_sample_var_in_ref), ("5", vs.get_sample_var_in_sample)):
+                a, b = call(regs, who), call(dreg, dids)
+                checked += len(regs)
+                if a.digest() != b.digest() or a.totals() != b.totals() or any(a.region_text(q) != b.region_text(q) for q in range(0, len(regs), 5)):
+                    bad += 1
+                    print(f"MISMATCH t{name} device inputs against host inputs, cohort {seed}")
+                a.close(); b.close()
+            for coords in (False, True):
+                a, b = vs.query_sample_seq(regs, who, sample_coordinates=coords), vs.query_sample_seq(dreg, dids, sample_coordinates=coords)
+                (fa, sa), (fb, sb) = a.sequences(), b.sequences()
+                checked += len(regs)
+                if not np.array_equal(fa, fb) or sa != sb:
+                    bad += 1
+                    print(f"MISMATCH t{3 if coords else 2} device inputs against host inputs, cohort {seed}")
+                a.close(); b.close()
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
