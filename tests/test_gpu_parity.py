@@ -658,6 +658,39 @@ def test_type4_rows_can_be_dropped_and_rebuilt_on_an_open_handle(tmp_path):
     vs.close()
 
 
+def test_walking_batches_around_the_one_launch_scans_tile_sizes(tmp_path):
+    """Batches of 4095 ... 16385 regions: one launch of 1 - 4 blocks scans their offsets (k_scan_small, k_scan2_small: tiles of 4096,
+    at most 16384 elements), one more region takes the three-launch scan.  Query types 4, 5, 2 and 3 with inputs in device memory:
+    totals = the sum over the batch cut in two uneven parts, same digest as from host arrays, oracle text on a sample of regions."""
+    import torch
+    from variantstore_amd import DeviceArray
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 1733, n_samples=40, n_rows=220, ref_len=4000, p_near=0.4)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(1733)
+    for n in (4095, 4096, 4097, 8192, 12289, 16384, 16385):
+        regions = np.array(random_regions(rng, vs.info().ref_length, n, max_len=300), dtype=np.uint64)
+        ids = rng.integers(1, vs.info().num_samples, size=n).astype(np.uint32)
+        reg_t, ids_t = torch.from_numpy(regions.view(np.int64)).cuda(), torch.from_numpy(ids.view(np.int32)).cuda()
+        dreg, dids = DeviceArray(reg_t.data_ptr(), n), DeviceArray(ids_t.data_ptr(), n)
+        cut = n // 3
+        for call in (vs.get_sample_var_in_ref, vs.get_sample_var_in_sample):
+            whole, host = call(dreg, dids), call(regions, ids)
+            parts = [call(regions[:cut], ids[:cut]), call(regions[cut:], ids[cut:])]
+            assert whole.totals() == host.totals() == tuple(sum(p.totals()[k] for p in parts) for k in range(4)), n
+            assert whole.digest() == host.digest()
+            if call == vs.get_sample_var_in_ref:
+                for q in (0, cut - 1, cut, 4095, n - 1):
+                    assert whole.region_text(q) == orc.get_sample_var_in_ref(int(regions[q, 0]), int(regions[q, 1]), vs.sample_name(int(ids[q])))[2], (n, q)
+            for r in [whole, host] + parts:
+                r.close()
+        for coords in (False, True):
+            whole, host = vs.query_sample_seq(dreg, dids, sample_coordinates=coords), vs.query_sample_seq(regions, ids, sample_coordinates=coords)
+            (fa, sa), (fb, sb) = whole.sequences(), host.sequences()
+            assert np.array_equal(fa, fb) and sa == sb and whole.totals() == host.totals(), (n, coords)
+            whole.close(); host.close()
+    vs.close()
+
+
 def test_walking_queries_take_regions_and_sample_ids_in_device_memory(tmp_path):
     """Query types 4 (one sample per region), 2, 3 and 5 with their inputs already on the GPU (variantstore_hip.h:
     vs_query_samples_var_in_ref): the same answers as from host arrays, in both walk forms; an id out of range in a device
