@@ -692,6 +692,31 @@ def test_walking_batches_around_the_one_launch_scans_tile_sizes(tmp_path):
     vs.close()
 
 
+def test_walking_batches_report_their_phases_on_request(tmp_path):
+    """Option phase_events (variantstore_hip.h): a batch of query type 4 / 5 records its first and last event only -- ms_total, phases 0 --
+    unless the handle is asked for all five; the answers do not depend on it."""
+    fasta, vcf, names = write_random_cohort(str(tmp_path), 611, n_samples=30, n_rows=200, ref_len=4000, p_near=0.4)
+    vs, orc = _open_gpu(fasta, vcf, tmp_path)
+    rng = np.random.default_rng(611)
+    regions = np.array(random_regions(rng, vs.info().ref_length, 300, max_len=500), dtype=np.uint64)
+    ids = rng.integers(1, vs.info().num_samples, size=len(regions)).astype(np.uint32)
+    seen = {}
+    for on in (0, 1, 0):
+        vs.set_option("phase_events", on)
+        for _k in range(2):   # (the first batch of a handle sizes its scratch exactly and waits twice; the second is the steady state)
+            r = vs.get_sample_var_in_ref(regions, ids)
+        t = vs.last_timing()
+        assert t.ms_total > 0
+        if on:
+            assert t.ms_bounds > 0 and t.ms_fill > 0 and abs(t.ms_bounds + t.ms_scan + t.ms_emit + t.ms_fill - t.ms_total) < 0.05 * t.ms_total + 0.01
+        else:
+            assert t.ms_bounds == t.ms_scan == t.ms_emit == t.ms_fill == 0
+        seen[on] = (r.totals(), r.digest())
+        r.close()
+    assert seen[0] == seen[1]
+    vs.close()
+
+
 def test_walking_queries_take_regions_and_sample_ids_in_device_memory(tmp_path):
     """Query types 4 (one sample per region), 2, 3 and 5 with their inputs already on the GPU (variantstore_hip.h:
     vs_query_samples_var_in_ref): the same answers as from host arrays, in both walk forms; an id out of range in a device

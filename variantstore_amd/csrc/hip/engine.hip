@@ -277,7 +277,9 @@ static inline hipStream_t work_stream(const vs_index* idx) { return idx->pre ? i
 struct PreStream {
   vs_index* idx;
   PreStream(vs_index* i, hipStream_t s) : idx(i) { i->pre = s; }
-  ~PreStream() { idx->pre = nullptr; }
+  // (left without done(): an error on the way -- whatever was launched has to be over before the caller releases the result's buffers,
+  //  which nothing on the handle's own stream is ordered behind)
+  ~PreStream() { if (idx->pre) (void)hipStreamSynchronize(idx->pre); idx->pre = nullptr; }
   void done() { idx->pre = nullptr; }
 };
 
