@@ -5,12 +5,14 @@
 // that steady-state batches do no hipMalloc.  Mirrors the reference's seam
 // between query_main and query.h (reference src/commands.cc:114-215).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -683,6 +685,15 @@ static int ralloc(vs_result* r, size_t n, T** p) {
   return VS_OK;
 }
 
+// Several arrays out of ONE pooled buffer (every allocation is a search of the handle's pool, and a batch of a tenth of a
+// millisecond makes sixteen of them): sizes are added up, the buffer is taken once, the arrays are carved on 256-byte bounds.
+struct Slab {
+  size_t bytes = 0;
+  uint8_t* base = nullptr;
+  size_t add(size_t b) { const size_t at = bytes; bytes += (b + 255) & ~(size_t)255; return at; }
+  template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(base + off); }
+};
+
 // Strings of a type-7 batch (ref, alt per query) as one byte pool + [2n+1] offsets.
 struct PointStrings {
   const std::vector<uint8_t>* chars;
@@ -992,16 +1003,19 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   DevResult& d = r->d;
   d.Q = n;
   uint64_t* dreg = nullptr;
-  VS_TRY(ralloc(r, 2 * n, &dreg));
+  {   // the per-region arrays of the result: one buffer
+    Slab sl;
+    const size_t o_reg = sl.add(2 * n * 8), o_fl = sl.add(n * sizeof(*d.q_flags)), o_g0 = sl.add(n * sizeof(*d.q_g0)), o_nv = sl.add(n * sizeof(*d.q_nvar)),
+                 o_nc = sl.add(n * sizeof(*d.q_ncar)), o_vb = sl.add((n + 1) * sizeof(*d.var_begin)), o_cb = sl.add((n + 1) * sizeof(*d.car_base)),
+                 o_vc = sl.add(n * sizeof(*d.var_count)), o_cl = sl.add(n * sizeof(*d.q_car_len));
+    VS_TRY(ralloc(r, sl.bytes, &sl.base));
+    dreg = sl.at<uint64_t>(o_reg);
+    d.q_flags = sl.at<std::remove_pointer_t<decltype(d.q_flags)>>(o_fl); d.q_g0 = sl.at<std::remove_pointer_t<decltype(d.q_g0)>>(o_g0);
+    d.q_nvar = sl.at<std::remove_pointer_t<decltype(d.q_nvar)>>(o_nv); d.q_ncar = sl.at<std::remove_pointer_t<decltype(d.q_ncar)>>(o_nc);
+    d.var_begin = sl.at<std::remove_pointer_t<decltype(d.var_begin)>>(o_vb); d.car_base = sl.at<std::remove_pointer_t<decltype(d.car_base)>>(o_cb);
+    d.var_count = sl.at<std::remove_pointer_t<decltype(d.var_count)>>(o_vc); d.q_car_len = sl.at<std::remove_pointer_t<decltype(d.q_car_len)>>(o_cl);
+  }
   d.regions = dreg;
-  VS_TRY(ralloc(r, n, &d.q_flags));
-  VS_TRY(ralloc(r, n, &d.q_g0));
-  VS_TRY(ralloc(r, n, &d.q_nvar));
-  VS_TRY(ralloc(r, n, &d.q_ncar));
-  VS_TRY(ralloc(r, n + 1, &d.var_begin));
-  VS_TRY(ralloc(r, n + 1, &d.car_base));
-  VS_TRY(ralloc(r, n, &d.var_count));
-  VS_TRY(ralloc(r, n, &d.q_car_len));
   // async_submit: the PLAN of this batch runs on a stream of its own -- beside the expansion of the batch before it, which
   // is still on the handle's stream when the caller submits back to back.  The plan reads the regions and the index and
   // writes this batch's own arrays; nothing in the pool is referenced by work in flight (a batch that returned when it
@@ -1029,13 +1043,15 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   uint32_t *e_prev = nullptr, *status = nullptr, *slow_list = nullptr;
   RunRec* runs = nullptr;
   uint32_t* coarse = nullptr;
-  VS_TRY(dev_alloc(idx, (idx->d.G / kCoarseRows + 2) * 4, (void**)&coarse, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, ntiles * sizeof(ShareMax), (void**)&tile_max, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, (ntiles + 1) * sizeof(Scan5), (void**)&tile_sums, &scratch.bufs));   // (+ the totals: k_t6_totals)
-  VS_TRY(dev_alloc(idx, n * 4, (void**)&e_prev, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, 4, (void**)&status, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, n * 4, (void**)&slow_list, &scratch.bufs));
-  VS_TRY(dev_alloc(idx, (n + 1) * sizeof(RunRec), (void**)&runs, &scratch.bufs));
+  {   // the plan's temporaries: one buffer
+    Slab sl;
+    const size_t o_co = sl.add((idx->d.G / kCoarseRows + 2) * 4), o_tm = sl.add(ntiles * sizeof(ShareMax)),
+                 o_ts = sl.add((ntiles + 1) * sizeof(Scan5)),   // (+ the totals: k_t6_totals)
+                 o_ep = sl.add(n * 4), o_st = sl.add(4), o_sl = sl.add(n * 4), o_ru = sl.add((n + 1) * sizeof(RunRec));
+    VS_TRY(dev_alloc(idx, sl.bytes, (void**)&sl.base, &scratch.bufs));
+    coarse = sl.at<uint32_t>(o_co); tile_max = sl.at<ShareMax>(o_tm); tile_sums = sl.at<Scan5>(o_ts);
+    e_prev = sl.at<uint32_t>(o_ep); status = sl.at<uint32_t>(o_st); slow_list = sl.at<uint32_t>(o_sl); runs = sl.at<RunRec>(o_ru);
+  }
   PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
   auto launch_bounds = [&](int src) {
     if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, regions_dev, items, tile_max, status);
