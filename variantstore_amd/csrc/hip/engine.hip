@@ -1662,8 +1662,12 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
     VS_TRY(dev_alloc(idx, (n + 2) * 8, (void**)&own_base, &scratch.bufs));
     lc.claim = idx->t4_claim[tab]; lc.gen = gen; lc.own_base = own_base; lc.rows_cap = cap_rows;
     hipLaunchKernelGGL(k_t4_claim, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, work_stream(idx), idx->d, d, ws, lc);
-    VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
-    hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), d, lc);
+    if (n <= kScanSmallMax)   // the scan and the offsets in one launch
+      hipLaunchKernelGGL(k_t4_offsets_small, dim3((unsigned)((n + kScanSmallTile - 1) / kScanSmallTile)), dim3(kScanSmallBlock), 0, work_stream(idx), d, lc, own_base);
+    else {
+      VS_TRY(exclusive_scan<uint64_t>(idx, (const uint64_t*)lc.q_own, n, own_base, &scratch.bufs));
+      hipLaunchKernelGGL(k_t4_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, work_stream(idx), d, lc);
+    }
     share_t4 = true;
   }
   // the walk's overflow flag, the claims' arena total and what the capacities added up to (the scan's totals are in mapped memory

@@ -1078,6 +1078,51 @@ __global__ void __launch_bounds__(256) k_t4_offsets(DevResult r, ListClaims lc) 
   for (uint64_t i = 0; i < n; ++i) { lc.own_off[a0 + i] = at; at += lc.own_pad[a0 + i]; }
 }
 
+// The scan of q_own and k_t4_offsets as ONE launch for batches of up to kScanSmallMax regions (k_scan_small's scheme: <= 4 blocks, a
+// block adds up the tiles in front of its own by itself): a thread has its four regions' bases in registers when the scan is done and
+// walks their rows at once.  out_base[Q] = the arena the claimed lists take (the host reads it in the batch's wait).
+__global__ void __launch_bounds__(kScanSmallBlock) k_t4_offsets_small(DevResult r, ListClaims lc, uint64_t* __restrict__ out_base) {
+  __shared__ uint64_t wsum[kScanSmallBlock / 64], wpre[kScanSmallBlock / 64];
+  const uint32_t n = (uint32_t)r.Q, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t tile0 = blockIdx.x * kScanSmallTile, base = tile0 + threadIdx.x * kScanSmallItems;
+  const uint64_t* __restrict__ in = lc.q_own;
+  uint64_t pre = 0, v[kScanSmallItems];
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallPre; ++k) {
+    const uint32_t i = k * kScanSmallBlock + threadIdx.x;
+    pre += i < tile0 ? in[i] : 0;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
+  uint64_t own = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) own += v[k];
+  uint64_t incl = own;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(incl, d, 64);
+    pre += __shfl_xor(pre, d, 64);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+  if (lane == 63) { wsum[wid] = incl; wpre[wid] = pre; }
+  __syncthreads();
+  uint64_t ex = incl - own;
+  for (uint32_t w = 0; w < kScanSmallBlock / 64; ++w) ex += wpre[w] + (w < wid ? wsum[w] : 0);
+#pragma unroll
+  for (uint32_t k = 0; k < kScanSmallItems; ++k) {
+    const uint32_t q = base + k;
+    if (q < n) {
+      out_base[q] = ex;
+      const uint64_t nr = r.q_nvar[q], a0 = r.var_begin[q];
+      if (a0 + nr <= lc.rows_cap) {   // (else: overflowed batch, redone by the host)
+        uint64_t at = ex;
+        for (uint64_t i = 0; i < nr; ++i) { lc.own_off[a0 + i] = at; at += lc.own_pad[a0 + i]; }
+      }
+    }
+    ex += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanSmallBlock - 1) out_base[n] = ex;
+}
+
 // LISTS 0: private list per row, 1: the list of the vertex's owner row (claims), 2: the index's resident list of the vertex
 template <bool RESOLVE, int LISTS>
 __global__ void __launch_bounds__(256) k_emit_from_walk(DevImage im, DevResult r, WalkScratch ws, ListClaims lc) {

@@ -40,8 +40,13 @@
 //                       pieces of the sequence pool; k_copy_segments decodes them;
 // k_sample_seq_coop      the cooperative form (window logic of query.h:160-177 / :236-247 at the hand-over)
 // k_sample_walk_coop    get_prev_vertex_with_sample + get_sample_var_in_ref (query.h:618-729, type 4), eight lanes per region;
-//  (k_sample_walk)       WalkAdmit holds a batch to the scratch its predecessor needed; k_t4_claim / _offsets: one carrier
+//  (k_sample_walk)       WalkAdmit holds a batch to the scratch its predecessor needed; k_t4_claim / _offsets(_small): one carrier
 //                       list per reported vertex; k_emit_from_walk: the rows (query.h:680-704)
+// k_walk_setup /        the first kernel of a walking batch whose regions and sample ids are in device memory: the result's
+//  k_seq_setup           copies, the range check of the ids, the capacities of the recording walk (no reference counterpart:
+//                       the reference reads its regions from a file, src/commands.cc:100-140)
+// k_scan_*, k_scan2_*,  offsets of rows, arena and scratch (exclusive scans over the regions of a batch; up to 16 k regions: one launch)
+//  k_scan_small
 // k_pack_regions /      what a sharded run gathers per region (the reference's loop, src/commands.cc:145-193, prints counts and
 //  k_pack_seq_regions    flags per region): site range + counts, or pieces + bytes of a sequence; k_bounds_from_records: the
 //                       receiving side (vs_query_expand_site_ranges)
