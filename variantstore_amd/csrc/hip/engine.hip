@@ -1059,7 +1059,9 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<2>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint64_t*)nullptr, items, tile_max, status);
   };
   // the plan over the regions as they stand in `d`; the totals arrive in mapped host memory
+  bool plan_end_enqueued = false;   // ev[1] recorded behind the (last) plan and waited for by the handle's stream
   auto plan = [&](int src) -> int {
+    plan_end_enqueued = false;
     launch_bounds(src);   // (block 0 clears `status`)
     hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
@@ -1069,6 +1071,13 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                             ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, (uint64_t)0);
     HIP_TRY(hipGetLastError());
+    // the plan's end event, and the handle's stream waiting for it, are enqueued while the plan is still on its way to the totals:
+    // two calls less between "the totals are here" and "the expansion is launched" (a batch of a tenth of a millisecond is the host's)
+    if (plan_aside) {
+      HIP_TRY(hipEventRecord(idx->ev[1], ps));
+      HIP_TRY(hipStreamWaitEvent(idx->stream, idx->ev[1], 0));
+      plan_end_enqueued = true;
+    }
     return wait_posted(idx, &pt->seq, seq, 200);
   };
   // A batch that is not sorted by first site: counting sort of the regions over the site index (k_sort_*), the batch
@@ -1123,10 +1132,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     } else idx->sort_hint = false;
   }
   if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
-  HIP_TRY(hipEventRecord(idx->ev[1], ps));
-  if (plan_aside) {   // (the host has seen the totals block 0 posted; the handle's stream waits for the whole plan)
-    HIP_TRY(hipStreamWaitEvent(idx->stream, idx->ev[1], 0));
-  }
+  if (!plan_end_enqueued) HIP_TRY(hipEventRecord(idx->ev[1], ps));   // (a plan on the handle's own stream: the phase boundary only)
   const uint64_t U = pt->shared_rows, n_slow = pt->n_slow, n_runs = pt->n_runs;
   d.A = pt->rows;
   d.S = pt->arena;
