@@ -176,3 +176,21 @@ def window_oracle(outdir, k):
     w.close()
     orc = Oracle(plain)
     return orc
+
+
+# ---- two ranks on one GPU: the stand-in for RCCL (tests/native/fake_rccl.cpp), loaded by the engine through VS_RCCL_LIB ----
+_FAKE_RCCL = None
+
+
+def build_fake_rccl():
+    """Compile tests/native/fake_rccl.cpp (hipcc: it copies device buffers through the HIP runtime) and return the library's path."""
+    import subprocess
+    import tempfile
+    global _FAKE_RCCL
+    if _FAKE_RCCL is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lib = os.path.join(tempfile.mkdtemp(prefix="vs_native_"), "libfake_rccl.so")
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-fPIC", "-shared", "-o", lib,
+                               os.path.join(root, "tests", "native", "fake_rccl.cpp")])
+        _FAKE_RCCL = lib
+    return _FAKE_RCCL

@@ -21,6 +21,8 @@
 //                       --batch-out text is written per rank and concatenated in rank order, -o holds the last region's
 //                       text (the last FOUND position's for types 1 and 7).  A rank that fails ends the others.  --ngpus
 //                       (threads in one process, no collective) remains the fallback.
+//   --nprocs-same-device  TEST-ONLY: every rank of --nprocs opens GPU `--device` (real RCCL refuses two ranks on one device:
+//                       tests load tests/native/fake_rccl.cpp through VS_RCCL_LIB to run the multi-rank code on a one-GPU box)
 //   --ngpus N           shard the sorted region list over GPUs device .. device + N - 1 (query types 4, 5, 6): one handle
 //                       and one host thread per GPU, contiguous shards (the reference's serial loop, commands.cc:145,
 //                       carries no state between regions), results printed in region order
@@ -115,6 +117,7 @@ struct Args {
   bool have_type = false, have_mode = false, verbose = false;
   int device = 0, ngpus = 1, nprocs = 0;
   bool resident_lists = false;
+  bool nprocs_same_device = false;   // test-only (--nprocs-same-device): every rank of --nprocs opens GPU `device`
 };
 
 int usage() {
@@ -365,8 +368,10 @@ int query_multiproc_main(const Args& a) {
     struct timeval start, end;
     if (rank == 0) { info("Loading Index ..."); info("Loading variant graph ..."); info(a.mode == 0 ? "Read index only .." : "Read complete graph .."); }
     vs_index* idx = nullptr;
-    int rc = vs_index_open(a.prefix.c_str(), a.device + rank, &idx);
+    int rc = vs_index_open(a.prefix.c_str(), a.nprocs_same_device ? a.device : a.device + rank, &idx);
     if (rc != VS_OK) die(rc, "load");
+    if (const char* k = getenv("VS_NPROCS_TEST_KILL_RANK"))   // TEST-ONLY: this rank dies the hard way before it joins the communicator
+      if (*k && atoi(k) == rank) raise(SIGKILL);
     if (rank == 0) {
       vs_index_info inf;
       vs_index_get_info(idx, &inf);
@@ -705,6 +710,7 @@ int main(int argc, char** argv) {
       else if (f == "--device") a.device = atoi(need(i).c_str());
       else if (f == "--ngpus") a.ngpus = std::max(1, atoi(need(i).c_str()));
       else if (f == "--nprocs") a.nprocs = std::max(1, atoi(need(i).c_str()));
+      else if (f == "--nprocs-same-device") a.nprocs_same_device = true;
       else if (f == "--resident-lists") a.resident_lists = true;
       else { std::cerr << "unknown option " << f << "\n"; return EXIT_FAILURE; }
     }

@@ -30,10 +30,20 @@ static RcclApi* rccl_api() {
   if (tried) return api.lib ? &api : nullptr;
   tried = true;
   std::vector<std::string> names;
-  if (const char* p = getenv("VS_RCCL_LIB")) names.push_back(p);
-  for (const char* n : {"librccl.so", "librccl.so.1"}) {   // a copy the process already carries (torch's) first
-    if (void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) { api.lib = h; api.path = n; break; }
+  const char* forced = getenv("VS_RCCL_LIB");   // an explicit library wins over everything, and nothing else is tried (tests: tests/native/fake_rccl.cpp)
+  if (forced && *forced) {
+    if (void* h = dlopen(forced, RTLD_NOW | RTLD_LOCAL)) { api.lib = h; api.path = forced; }
+    else {
+      const char* de = dlerror();
+      api.error = std::string("cannot load VS_RCCL_LIB=") + forced + ": " + (de ? de : "not found");
+      rccl_error() = api.error;
+      return nullptr;
+    }
   }
+  if (!api.lib)
+    for (const char* n : {"librccl.so", "librccl.so.1"}) {   // a copy the process already carries (torch's) first
+      if (void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) { api.lib = h; api.path = n; break; }
+    }
   if (!api.lib) {
     names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"});
     for (auto& n : names)

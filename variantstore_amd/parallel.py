@@ -66,12 +66,20 @@ def allgather_hit_lists(result, region_base, device, compact=False, counts=None,
     return out.view(world, max_n, 4), counts
 
 
+COMM_ID_BYTES = 128   # VS_COMM_ID_BYTES of include/variantstore_hip.h (sizeof(ncclUniqueId))
+
+
 def _launch_nonce():
     """What tells one launch's id file from another's: VS_COMM_NONCE, else what torchrun gives every rank of a launch."""
     import os
     n = os.environ.get("VS_COMM_NONCE")
     if n is None:
-        n = ":".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+        parts = [os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")]
+        if not any(parts):
+            # nothing tells this launch from an earlier one: a rank could take the id file an earlier launch left at the same path
+            raise ValueError("make_comm(id_file=...) outside torchrun needs a launch nonce: pass nonce= or set VS_COMM_NONCE "
+                             "(the same value on every rank, a new one per launch)")
+        n = ":".join(parts)
     return n
 
 
@@ -97,7 +105,7 @@ def exchange_id_file(rank, world, id_file, make_id, nonce=None, timeout=120.0):
                 blob = f.read()
         except OSError:
             blob = b""
-        if len(blob) > 16 and blob[:16] == tag:
+        if len(blob) == 16 + COMM_ID_BYTES and blob[:16] == tag:
             return blob[16:]
         if time.time() - t0 > timeout:
             raise TimeoutError(f"no unique id of this launch at {id_file}")
