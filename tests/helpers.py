@@ -194,3 +194,21 @@ def build_fake_rccl():
                                os.path.join(root, "tests", "native", "fake_rccl.cpp")])
         _FAKE_RCCL = lib
     return _FAKE_RCCL
+
+
+def vcf_truth_cases(outdir, k, lo, edge=60):
+    """Expected type-6 rows of window k's ISOLATED records, derived from the window's VCF TEXT alone (tests/vcf_truth.py: no
+    from_vcf, no oracle), in the coordinates of the whole cohort: [(abs_pos, 'pos\\tref\\talt\\tsamples\\n'), ...].  Records within
+    `edge` bases of the window's ends are left out (a neighbour outside the window could touch them)."""
+    import vcf_truth as vt
+    names, recs = vt.read_vcf(os.path.join(outdir, f"w{k}.vcf"))
+    assert names == sorted(names)
+    length = max(r[0] + len(r[1]) for r in recs) if recs else 0
+    out = []
+    for i, text in vt.expected_type6_rows(names, recs):
+        pos, ref, _alts, _g = recs[i]
+        if pos <= edge or pos + len(ref) >= length - edge:
+            continue
+        p, rest = text.split("\t", 1)
+        out.append((int(p) + lo - 1, f"{int(p) + lo - 1}\t{rest}", recs[i]))
+    return names, out

@@ -334,3 +334,45 @@ def test_oracle_spot_checks_through_windows(big, tmp_path):
     res6.close()
     res4.close()
     assert n6 == 102 and n4 == 24 and rows6 > 15_000 and rows4 > 0
+
+
+def test_vcf_text_truth_at_full_size(big, tmp_path):
+    """The one check that bypasses the product's constructor, at FULL size: the generator's records inside six
+    windows are written as VCF text (tests/native/synth_windows.cpp), the expected type-6 rows of the ISOLATED records follow from
+    that text alone (tests/vcf_truth.py: VCF semantics + the reference's reporting convention; no from_vcf, no oracle), and they are
+    compared with what the GPU answers on the whole 5 M-site index: every such row is reported, with exactly that carrier text, by a
+    small region around it and by the 10 kb region that holds it; query type 4 for one of its carriers reports a substitution's row."""
+    from helpers import synth_windows, vcf_truth_cases
+    vs, _regions = big
+    rng = np.random.default_rng(99)
+    wins = [(int(c), int(c) + 30_000) for c in np.sort(rng.integers(1_000_000, KW["ref_length"] - 1_000_000, size=6))]
+    synth_windows(KW, wins, tmp_path)
+    cases = []
+    for k, (lo, _hi) in enumerate(wins):
+        _names, rows = vcf_truth_cases(tmp_path, k, lo)
+        cases += rows
+    assert len(cases) >= 2000, len(cases)
+    cases.sort(key=lambda c: c[0])
+    small = np.array([(p - 3, p + 4) for p, _t, _r in cases], dtype=np.uint64)
+    res = vs.get_var_in_ref(small)
+    wide = np.array([(p - 5_000, p + 5_000) for p, _t, _r in cases[::25]], dtype=np.uint64)
+    resw = vs.get_var_in_ref(wide)
+    assert res.layout()[4] and resw.layout()[4]
+    for q, (p, text, _rec) in enumerate(cases):
+        assert text in res.region_text(q), (p, text[:60])
+    for q, (p, text, _rec) in enumerate(cases[::25]):
+        assert text in resw.region_text(q), (p, "inside its 10 kb region")
+    res.close()
+    resw.close()
+    # query type 4: a carrier of a substitution reports the record's row (indels follow type 4's own rule, query.h:682-698)
+    subs = [(p, t, r) for p, t, r in cases if len(r[1]) == len(r[2][0])]
+    pick = [subs[i] for i in rng.choice(len(subs), size=200, replace=False)]
+    pick.sort(key=lambda c: c[0])
+    carriers = []
+    for _p, t, _r in pick:
+        cs = t.split("\t")[3].split()
+        carriers.append(cs[len(cs) // 2].split("(")[0])
+    r4 = vs.get_sample_var_in_ref(np.array([(p - 3, p + 4) for p, _t, _r in pick], dtype=np.uint64), carriers)
+    for q, (p, text, _rec) in enumerate(pick):
+        assert text in r4.region_text(q), (p, carriers[q])
+    r4.close()

@@ -261,3 +261,58 @@ def test_one_fiftieth_slice_against_the_oracle_mixed_types(tmp_path):
     r3.close()
     orc.close()
     vs.close()
+
+
+def test_vcf_text_truth_at_full_size(tcga, tmp_path):
+    """As tests/test_gpu_full_size.py::test_vcf_text_truth_at_full_size, on the 20 M-site explicit-id cohort: expected rows of the
+    isolated records of four windows, from the windows' VCF TEXT alone (no from_vcf, no oracle), against the FULL-size GPU answer --
+    type 6 around every such record, type 4 for a carrier of a substitution, and the carrier's type-2 sequence over a window that
+    holds only isolated records (the reference with the sample's alleles applied)."""
+    import vcf_truth as vt
+    from helpers import synth_windows, vcf_truth_cases
+    vs, _regions = tcga
+    kw = bench.synth_kwargs(W)
+    rng = np.random.default_rng(98)
+    wins = [(int(c), int(c) + 16_000) for c in np.sort(rng.integers(1_000_000, W["ref_length"] - 1_000_000, size=4))]
+    synth_windows(kw, wins, tmp_path)
+    cases, per_window = [], []
+    for k, (lo, _hi) in enumerate(wins):
+        names, rows = vcf_truth_cases(tmp_path, k, lo)
+        cases += rows
+        per_window.append((k, lo, names))
+    assert len(cases) >= 2000, len(cases)
+    cases.sort(key=lambda c: c[0])
+    res = vs.get_var_in_ref(np.array([(p - 3, p + 4) for p, _t, _r in cases], dtype=np.uint64))
+    for q, (p, text, _rec) in enumerate(cases):
+        assert text in res.region_text(q), (p, text[:60])
+    res.close()
+    subs = [(p, t, r) for p, t, r in cases if len(r[1]) == len(r[2][0])]
+    pick = [subs[i] for i in rng.choice(len(subs), size=200, replace=False)]
+    pick.sort(key=lambda c: c[0])
+    carriers = [t.split("\t")[3].split()[0].split("(")[0] for _p, t, _r in pick]
+    r4 = vs.get_sample_var_in_ref(np.array([(p - 3, p + 4) for p, _t, _r in pick], dtype=np.uint64), carriers)
+    for q, (p, text, _rec) in enumerate(pick):
+        assert text in r4.region_text(q), (p, carriers[q])
+    r4.close()
+    # type 2: sequences of carriers over short intervals of the first window, from the FASTA + VCF text
+    k, lo, names = per_window[0]
+    _n, ref = vt.read_fasta(os.path.join(tmp_path, f"w{k}.fa"))
+    _names, recs = vt.read_vcf(os.path.join(tmp_path, f"w{k}.vcf"))
+    seq_cases = []
+    import random
+    r = random.Random(7)
+    for p, t, rec in cases:   # an interval around a record of the first window, for one of the record's carriers
+        if not (lo <= p < lo + 16_000):
+            continue
+        smp = t.split("\t")[3].split()[0].split("(")[0]
+        x = rec[0] - r.randint(4, 30)
+        y = rec[0] + len(rec[1]) + r.randint(4, 30)
+        want = vt.sample_sequence(ref, names, recs, smp, x, y) if x > 10 and y < len(ref) - 10 else None
+        if want is not None:
+            seq_cases.append((x + lo - 1, y + lo - 1, smp, want))
+    assert len(seq_cases) >= 200, len(seq_cases)
+    seq_cases.sort()
+    rs = vs.query_sample_seq(np.array([(x, y) for x, y, _s, _w in seq_cases], dtype=np.uint64), [s for _x, _y, s, _w in seq_cases])
+    flags, seqs = rs.sequences()
+    assert not flags.any() and seqs == [w_ for _x, _y, _s, w_ in seq_cases]
+    rs.close()

@@ -115,6 +115,11 @@ struct vs_index {
   uint32_t sort_probe_in = 0;
   uint64_t seq_cap_hint[2] = {0, 0};        // the same for the piece lists of query types 2 / 3
   uint64_t walk_cap_hint[2] = {0, 0};       // scratch entries the last type-4 / type-5 batch's recording walk needed (+ 1/8): the next batch's allocation
+  // A hint shrinks only after kHintShrinkAfter CONSECUTIVE batches that needed less than a quarter of it, and then to the largest of
+  // those: a handle that alternates large and small batches keeps the large scratch (one host wait per batch) instead of having every
+  // large batch refused on the device and redone.  [0 / 1]: walk hints, [2 / 3]: sequence hints.
+  uint32_t hint_small_runs[4] = {0, 0, 0, 0};
+  uint64_t hint_small_max[4] = {0, 0, 0, 0};
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
   uint64_t* walk_words = nullptr;           // the flag words of the walking batches (batch_words): zero between batches
@@ -402,6 +407,16 @@ static void free_image_alloc(vs_index* idx, const void* p) {
   if (it != idx->image_allocs.end()) idx->image_allocs.erase(it);
   (void)hipFree(const_cast<void*>(p));
 }
+constexpr uint32_t kHintShrinkAfter = 8;
+static void hint_after_batch(vs_index* idx, int which, uint64_t& hint, uint64_t cap_seen) {
+  if (cap_seen >= hint / 4) { idx->hint_small_runs[which] = 0; idx->hint_small_max[which] = 0; return; }
+  idx->hint_small_max[which] = std::max(idx->hint_small_max[which], cap_seen);
+  if (++idx->hint_small_runs[which] >= kHintShrinkAfter) {
+    const uint64_t m = idx->hint_small_max[which];
+    hint = m + m / 8 + 1024;
+    idx->hint_small_runs[which] = 0; idx->hint_small_max[which] = 0;
+  }
+}
 static int drop_t4_rows(vs_index* idx) {
   DevImage& d = idx->d;
   if (!d.t4_events) return VS_OK;
@@ -429,28 +444,43 @@ static int build_t4_rows(vs_index* idx, uint64_t cap) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
-      idx->t4_rows_bytes = bytes + hbytes;
       const uint64_t bytes_before = idx->device_bytes;
       uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
-      VS_TRY(alloc_image(idx, (size_t)istride, &irr));
-      HIP_TRY(hipMemsetAsync(irr, 0, istride * 8, idx->stream));
-      VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
-      HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
-      if (hstride) {
-        VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
-        HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
+      // every allocation and launch first, the handle's fields last: a failure half way (the check against the free memory is not atomic with
+      // the allocations) gives back what it took and leaves the handle without rows, as if none had been asked for
+      auto build = [&]() -> int {
+        VS_TRY(alloc_image(idx, (size_t)istride, &irr));
+        HIP_TRY(hipMemsetAsync(irr, 0, istride * 8, idx->stream));
+        VS_TRY(alloc_image(idx, (size_t)d.num_samples * stride, &events));
+        HIP_TRY(hipMemsetAsync(events, 0, bytes, idx->stream));
+        if (hstride) {
+          VS_TRY(alloc_image(idx, (size_t)d.num_samples * hstride, &hold));
+          HIP_TRY(hipMemsetAsync(hold, 0, hbytes, idx->stream));
+        }
+        DevImage dd = d;   // (the build kernels read the strides from their copy of the image)
+        dd.t4_stride = stride; dd.t4_hold_stride = hstride; dd.t4_ev_shift = shift;
+        const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
+        if (d.use_bv) {
+          hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, dd, events, irr);
+          hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, dd, hold);
+        } else {
+          hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, dd, irr);
+          hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, dd, events);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(idx->stream));
+        return VS_OK;
+      };
+      const int rc = build();
+      if (rc != VS_OK) {
+        (void)hipStreamSynchronize(idx->stream);
+        free_image_alloc(idx, events); free_image_alloc(idx, hold); free_image_alloc(idx, irr);
+        idx->device_bytes = bytes_before;
+        return rc;
       }
       d.t4_stride = stride; d.t4_hold_stride = hstride; d.t4_ev_shift = shift;
-      const unsigned tiles = (unsigned)((im.P + 63) / 64), vtiles = (unsigned)((im.V + 63) / 64);
-      if (d.use_bv) {
-        hipLaunchKernelGGL(k_build_events, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, events, irr);
-        hipLaunchKernelGGL(k_build_hold, dim3((vtiles + 3) / 4), dim3(256), 0, idx->stream, d, hold);
-      } else {
-        hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, d, irr);
-        hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, d, events);
-      }
-      HIP_TRY(hipGetLastError());
       d.t4_events = events; d.t4_hold = hold; d.t4_irr = irr; d.t4_irr_reach = im.irr_reach;
+      idx->t4_rows_bytes = bytes + hbytes;
       idx->t4_alloc_bytes = idx->device_bytes - bytes_before;
     }
   }
@@ -1691,7 +1721,7 @@ static int run_walk_batch_once(vs_index* idx, const vs_region* regions, uint64_t
       *refused = true;
       return VS_OK;
     }
-    if (cap_seen < hint / 4) hint = cap_seen + cap_seen / 8 + 1024;   // (batches have become much smaller: so does the scratch)
+    hint_after_batch(idx, walk_mode == 5 ? 1 : 0, hint, cap_seen);   // (batches that have become much smaller for a while: so does the scratch)
   }
   uint64_t rows = 0, arena = 0;
   batch_totals(c, &rows, &arena);
@@ -1898,7 +1928,7 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
     if (speculative) {
       if (over == 3) return bad_ids_error(idx);
       if (over == 2) { hint = cap_seen + cap_seen / 8 + 1024; *refused = true; return VS_OK; }
-      if (cap_seen < hint / 4) hint = cap_seen + cap_seen / 8 + 1024;
+      hint_after_batch(idx, mode == 3 ? 3 : 2, hint, cap_seen);
     }
     if (over) { single_walk = false; q.relative = 0; }
     else {
@@ -2408,7 +2438,8 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     o.t4_walk = (int)value;
   } else if (k == "t4_rows_max_mb") {
     // the per-sample rows of query type 4 on an open handle: dropped when they take more than `value` MiB (0: always), built
-    // when they are absent and fit it (and half of the free memory); vs_index_get_info().t4_rows_bytes says what is there
+    // when they are absent and fit it (and half of the free memory); vs_index_get_info().t4_rows_bytes says what is there.
+    // An explicit request on the open handle overrides VS_T4_NO_EVENTS of the environment (that switch only decides what open builds).
     if (value < 0) return fail(VS_ERR_ARG, "t4_rows_max_mb takes a size in MiB (0: drop the rows)");
     if (idx->device < 0) return fail(VS_ERR_ARG, "the handle has no device image");
     HIP_TRY(hipSetDevice(idx->device));
