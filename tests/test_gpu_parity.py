@@ -145,6 +145,38 @@ def test_synthetic_midsize_all_regions(tmp_path):
     assert n == 2000 and orc.ub_events() == 0
 
 
+@pytest.mark.parametrize("length", [7, 30, 120])
+def test_many_short_scattered_regions_many_runs(length, tmp_path):
+    """Round 6: thousands of SHORT regions far apart -- the shared table then consists of hundreds of RUNS of one or two rows (a run: a
+    maximal stretch of covered sites), and a wave task of k_fill_sites2 looks its rows' runs up in a window of 64 run records
+    (shared_row_run).  A row that was the last of 63 single-row runs took the 64th run's site: the window's 64th record was fetched by a
+    shuffle under a divergent condition, with its source lane switched off.  Batches of long overlapping regions (the bench, every
+    earlier test) have a handful of runs and never reached that code; the VCF-text check at full size did.  Every region against the
+    oracle, shared against private rows, 300 to 4000 regions."""
+    vs = VariantStore.synthetic(device=0, ref_length=10_000_000, num_variants=200_000, num_samples=200, seed=3, first_pos=10_000,
+                                frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6, af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(5)
+    for n in (300, 1000, 4000):
+        starts = np.sort(rng.integers(20_000, 9_980_000, size=n))
+        regions = [(int(x), int(x) + length) for x in starts]
+        res = vs.get_var_in_ref(regions)
+        assert res.layout()[4]
+        for q, (x, y) in enumerate(regions):
+            c, _, text = orc.get_var_in_ref(x, y)
+            if c >= 0:
+                assert res.region_text(q) == text, (n, q, x, y)
+        vs.set_option("share_lists", 0)
+        private = vs.get_var_in_ref(regions)
+        vs.set_option("share_lists", 1)
+        assert (private.totals(), private.digest()) == (res.totals(), res.digest()), n
+        private.close()
+        res.close()
+    vs.close()
+
+
 def test_digest_properties(tmp_path):
     """Size-independent properties used at full scale: the device digest is a function of the result
     only (same batch twice, and any permutation of the batch re-indexed, give the same per-region

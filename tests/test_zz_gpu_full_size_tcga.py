@@ -265,7 +265,7 @@ def test_one_fiftieth_slice_against_the_oracle_mixed_types(tmp_path):
 
 def test_vcf_text_truth_at_full_size(tcga, tmp_path):
     """As tests/test_gpu_full_size.py::test_vcf_text_truth_at_full_size, on the 20 M-site explicit-id cohort: expected rows of the
-    isolated records of four windows, from the windows' VCF TEXT alone (no from_vcf, no oracle), against the FULL-size GPU answer --
+    isolated records of three windows, from the windows' VCF TEXT alone (no from_vcf, no oracle), against the FULL-size GPU answer --
     type 6 around every such record, type 4 for a carrier of a substitution, and the carrier's type-2 sequence over a window that
     holds only isolated records (the reference with the sample's alleles applied)."""
     import vcf_truth as vt
@@ -273,7 +273,7 @@ def test_vcf_text_truth_at_full_size(tcga, tmp_path):
     vs, _regions = tcga
     kw = bench.synth_kwargs(W)
     rng = np.random.default_rng(98)
-    wins = [(int(c), int(c) + 16_000) for c in np.sort(rng.integers(1_000_000, W["ref_length"] - 1_000_000, size=4))]
+    wins = [(int(c), int(c) + 12_000) for c in np.sort(rng.integers(1_000_000, W["ref_length"] - 1_000_000, size=3))]
     synth_windows(kw, wins, tmp_path)
     cases, per_window = [], []
     for k, (lo, _hi) in enumerate(wins):
@@ -302,7 +302,7 @@ def test_vcf_text_truth_at_full_size(tcga, tmp_path):
     import random
     r = random.Random(7)
     for p, t, rec in cases:   # an interval around a record of the first window, for one of the record's carriers
-        if not (lo <= p < lo + 16_000):
+        if not (lo <= p < lo + 12_000):
             continue
         smp = t.split("\t")[3].split()[0].split("(")[0]
         x = rec[0] - r.randint(4, 30)

@@ -16,7 +16,7 @@ from variantstore_amd import VariantStore  # noqa: E402
 
 n_cohorts = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-bad = hang = ub = checked = slow_regions = shared_batches = 0
+bad = hang = ub = checked = slow_regions = shared_batches = many_runs = 0
 VERBOSE = bool(os.environ.get("VS_STRESS_VERBOSE"))
 
 
@@ -81,6 +81,37 @@ for c in range(n_cohorts):
             bad += 1
             print(f"MISMATCH digest of the shared batch, cohort {seed}")
         rsh.close()
+        # many SHORT regions in position order: a shared table of many short runs (round 6: a row that closed 63 single-row runs took the
+        # 64th run's site -- shared_row_run; batches of long regions have a handful of runs); each region against its single-region answer
+        # (the latency path: checked against the oracle above and below) and the whole batch against private rows
+        stage("many short regions")
+        L = vs.info().ref_length
+        short = sorted((int(x), int(x) + int(rng.integers(1, 9))) for x in rng.integers(1, max(2, L - 10), size=700))
+        rsr = vs.get_var_in_ref(short)
+        many_runs += int(rsr.layout()[1] > 64)
+        for k in range(0, len(short), 64):
+            one = vs.get_var_in_ref(short[k:k + 64])
+            for j in range(min(64, len(short) - k)):
+                checked += 1
+                if rsr.region_text(k + j) != one.region_text(j):
+                    bad += 1
+                    print(f"MISMATCH t6 many short regions, cohort {seed} region {short[k + j]}")
+            one.close()
+        for (x, y), k in [(short[k], k) for k in range(0, len(short), 9)]:
+            n, _e, text = orc.get_var_in_ref(x, y)
+            if n >= 0:
+                checked += 1
+                if rsr.region_text(k) != text:
+                    bad += 1
+                    print(f"MISMATCH t6 many short regions against the oracle, cohort {seed} region {x}:{y}")
+        vs.set_option("share_lists", 0)
+        prv = vs.get_var_in_ref(short)
+        vs.set_option("share_lists", 1)
+        if (prv.totals(), prv.digest()) != (rsr.totals(), rsr.digest()):
+            bad += 1
+            print(f"MISMATCH many short regions: shared against private rows, cohort {seed}")
+        prv.close()
+        rsr.close()
         # the same regions again through the single-launch latency path (up to 64 regions: kernel-argument forms of 8
         # and 64 regions) and a 70-region batch through the general path
         for lo, hi in ((0, 1), (1, 4), (4, 12), (12, 76), (20, 21), (30, 100)):
@@ -253,5 +284,5 @@ for c in range(n_cohorts):
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
-      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions} batches with shared rows/lists {shared_batches}")
+      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions} batches with shared rows/lists {shared_batches} short-region batches with more than 64 table rows {many_runs}")
 sys.exit(1 if bad else 0)

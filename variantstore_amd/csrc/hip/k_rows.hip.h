@@ -438,7 +438,12 @@ __device__ __forceinline__ RowDelta shared_row_run(const RunRec* __restrict__ ru
     const uint64_t v = __shfl(u_start, (int)(cnt + step - 1), 64);
     if (v <= me) cnt += step;
   }
-  if (cnt == 63 && __shfl(u_start, 63, 64) <= me) cnt = 64;
+  // (the 64th record is fetched by EVERY lane before the test: a shuffle under `cnt == 63 && ...` runs with only those lanes active, and a
+  //  lane that is switched off -- lane 63 itself, whose row in a task of fewer than 64 rows is the task's first -- hands over 0, which made
+  //  the 64th run "start at or below" any row: rows of the 64th run's site for the last row of 63 single-row runs.  Found in round 6 by the
+  //  VCF-text check on thousands of 7-base regions; batches of long overlapping regions have a handful of runs and never came here.)
+  const uint64_t u_start_63 = __shfl(u_start, 63, 64);
+  if (cnt == 63 && u_start_63 <= me) cnt = 64;
   const int src = cnt ? (int)cnt - 1 : 0;
   RowDelta d;
   d.dg = ((uint64_t)(uint32_t)__shfl((int)a.w, src, 64) << 32) | (uint32_t)__shfl((int)a.z, src, 64);
