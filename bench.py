@@ -853,14 +853,20 @@ def main():
     # launched inside the timed region has completed when it ends (fence: device-wide synchronisation).
     pipelined = args.async_fill
     vs.set_option("async_fill", 1 if pipelined else 0)
-    prev = None
-    for _i in range(args.warmup):   # (in the timed loop's own form -- a result is closed one step late -- so that the handle's
-        res, _g = step()            #  buffer pool holds what two batches alive at a time need before the clock starts)
-        if prev is not None:
-            prev.close()
-        prev = res
-    if prev is not None:
-        prev.close()
+    # A batch call returns when the batch is enqueued (async_submit) and, since round 6, without waiting for its plan's totals either
+    # (t6_speculate): the host runs ahead of the GPU by as many batches as it keeps results alive.  The loop keeps THREE -- the one being
+    # enqueued, the one the GPU is working on, and the one before it, whose completion the host waits for (reading its kernel time, then
+    # closing it): the plan of batch k + 1 is then on the GPU a whole batch before its expansion can start, also when a batch takes less than
+    # the ~0.05 ms the host needs to enqueue one (an eighth of the 1 M-region batch, config #2).  VS_BENCH_DEPTH=2: rounds 2-5's loop.
+    depth = max(2, int(os.environ.get("VS_BENCH_DEPTH", "3")))
+    alive = []
+    for _i in range(args.warmup):   # (in the timed loop's own form, so that the handle's buffer pool holds what `depth` batches alive at a
+        res, _g = step()            #  time need before the clock starts)
+        alive.append(res)
+        if len(alive) >= depth:
+            alive.pop(0).close()
+    while alive:
+        alive.pop(0).close()
     fence()
     fill_ms = tot_ms = emit_ms = 0.0
 
@@ -868,27 +874,31 @@ def main():
         ms = done.fill_ms()
         return ms if ms >= 0 else None
 
-    # A batch call returns when the batch is enqueued (engine option async_submit, the default): its timing is read one step
-    # late, from the result's OWN pair of HIP events around the expansion kernel on the stream it ran on -- reading the
-    # handle's events right after the call would wait for the batch and put the host back between the batches.
-    prev = None
+    # The timing of a batch is read late, from the result's OWN pair of HIP events around the expansion kernel on the stream it ran on --
+    # reading the handle's events right after the call would wait for the batch and put the host back between the batches.
     fill_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         res, _g = step()
-        if prev is not None:
-            f = account(prev)
+        alive.append(res)
+        if len(alive) >= depth:
+            old = alive.pop(0)
+            f = account(old)
             if f is not None:
                 fill_ms += f
                 fill_steps += 1
-            prev.close()
-        prev = res
+            old.close()
     fence()
     elapsed = time.perf_counter() - t0
-    f = account(res)
-    if f is not None:
-        fill_ms += f
-        fill_steps += 1
+    while alive:
+        old = alive.pop(0)
+        f = account(old)
+        if f is not None:
+            fill_ms += f
+            fill_steps += 1
+        if alive:
+            old.close()
+    res = old   # (the last step's result stays alive: the figures below are read from it)
     if fill_steps == 0:   # (a form without per-result events: private rows -- the handle's events of one more batch)
         res2, _g = step()
         fill_ms, fill_steps = vs.last_timing().ms_fill * args.steps, args.steps

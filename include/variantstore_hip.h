@@ -104,6 +104,9 @@ typedef struct {
                               * then visit every vertex) */
   uint64_t pool_mallocs;     /* hipMalloc / hipFree calls the handle's pool of batch buffers has made since it was opened: a loop */
   uint64_t pool_frees;       /* of like batches makes none once it is warm (hipFree waits for the whole device)                  */
+  uint64_t t6_speculated;    /* type-6 batches submitted without waiting for their plan's totals (option "t6_speculate") ...       */
+  uint64_t t6_refused;       /* ... and those of them the device refused (did not fit what was allocated, or unsorted) and the host  */
+                             /* ran again with the exact sizes when the result was first asked for anything                          */
 } vs_index_info;
 int vs_index_get_info(const vs_index* idx, vs_index_info* info);
 /* sampleid_map / idsample_map lookups (variant_graph.h:1230-1236, 1327-1339) */
@@ -331,7 +334,7 @@ void vs_comm_destroy(vs_comm* c);
 
 /* ---- switches of one handle ----
  * The environment is read once when a handle is opened; afterwards only this call changes a
- * switch.  The production library has TEN keys:
+ * switch.  The production library has ELEVEN keys:
  *   "latency_server"  0 never / 1 for back-to-back streaks of small queries (default) / 2 from the first small query
  *   "server_blocks"   1..64 blocks of the resident server
  *   "share_lists"     1 (default): a type-6 batch of more than 64 regions holds one row and one carrier list per covered
@@ -343,6 +346,13 @@ void vs_comm_destroy(vs_comm* c);
  *                     (default 0; VS_RESIDENT_LISTS=1 in the environment builds it when the handle is opened)
  *   "async_submit"    see vs_result_fill_ms (default 1)
  *   "async_fill"      see vs_result_fill_ms (default 0)
+ *   "t6_speculate"    1 (default): a type-6 batch that returns when it is enqueued (async_submit) does not wait for its plan's totals
+ *                     either when the handle's previous shared batch had about as many regions (4/5 .. 5/4): variant table and arena
+ *                     are sized from that batch (+ 1/8), the kernels behind the plan read the totals in device memory, and a batch
+ *                     that does not fit (or whose regions are not sorted) is refused on the device and run again with the exact
+ *                     sizes the first time its result is asked for anything -- vs_index_info.t6_speculated / t6_refused count
+ *                     them.  Same answers; the host never waits between two batches of a stream of like batches.  0: every batch
+ *                     waits for its totals (rounds 1-5)
  *   "t4_walk"         the walk of the query types that follow one sample's path: 2 cooperative (8 lanes per region, a region's
  *                     events walked in parallel: types 4, 2 and 3; default), 1 one lane per region jumping over uneventful
  *                     ref-path runs, 0 literal (type 4: every vertex of the sample's path; types 2 / 3 / 5 as 1)

@@ -177,6 +177,88 @@ def test_many_short_scattered_regions_many_runs(length, tmp_path):
     vs.close()
 
 
+def test_type6_batches_that_outgrow_the_previous_batch_are_redone(tmp_path):
+    """Round 6 (option t6_speculate, default on): a type-6 batch of more than 64 regions on a handle whose previous shared batch had about
+    as many regions is SUBMITTED without waiting for its plan's totals -- table and arena are sized from that batch (+ 1/8), the kernels
+    read the totals in device memory, and a batch that does not fit (or is not sorted) is refused on the device and run again with the
+    exact sizes when its result is first asked for anything.  Short regions, then as many long ones (refused, redone), the same again
+    (fits), an unsorted batch (refused: the device-side sort runs in the redo), results freed unread, eight and more batches in flight --
+    every answer against the oracle and against the same handle with the option off."""
+    vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6, af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(9)
+    n = 1500
+    starts = np.sort(rng.integers(1, 1_980_000, size=n))
+    short = np.stack([starts, starts + 300], axis=1).astype(np.uint64)
+    long_ = np.stack([starts, starts + 9000], axis=1).astype(np.uint64)
+    shuffled = long_[rng.permutation(n)]
+
+    def check(res, regions, step=7):
+        for q in range(0, len(regions), step):
+            c, _, text = orc.get_var_in_ref(int(regions[q, 0]), int(regions[q, 1]))
+            if c >= 0:
+                assert res.region_text(q) == text, (q, regions[q])
+
+    vs.set_option("t6_speculate", 0)
+    want = {}
+    for name, regs in (("short", short), ("long", long_)):   # (an unsorted batch would make the handle sort first for its next 32 batches)
+        r = vs.get_var_in_ref(regs)
+        want[name] = (r.totals(), r.digest(), r.layout())
+        r.close()
+    assert vs.info().t6_speculated == 0
+    vs.set_option("t6_speculate", 1)
+    a = vs.get_var_in_ref(short)            # (the first batch after the switch sets the handle's expectation: it has one already, from the runs above)
+    a.close()
+    s0 = vs.info()
+    b = vs.get_var_in_ref(short)            # speculative, fits
+    assert vs.info().t6_speculated == s0.t6_speculated + 1
+    assert (b.totals(), b.digest(), b.layout()) == want["short"]
+    check(b, short)
+    b.close()
+    # the handle expects the long batches' sizes now only if the short ones shrank it -- they did not (eight small batches in a row would):
+    # force the small expectation with a fresh handle state: nine short batches, unread
+    for _ in range(9):
+        vs.get_var_in_ref(short).close()
+    r0 = vs.info().t6_refused
+    c = vs.get_var_in_ref(long_)            # as many regions, thirty times the rows: refused on the device, redone at first use
+    assert (c.totals(), c.digest(), c.layout()) == want["long"]
+    assert vs.info().t6_refused == r0 + 1
+    check(c, long_)
+    d = vs.get_var_in_ref(long_)            # fits now
+    assert (d.totals(), d.digest(), d.layout()) == want["long"] and vs.info().t6_refused == r0 + 1
+    check(d, long_, step=11)
+    c.close(); d.close()
+    e = vs.get_var_in_ref(shuffled)         # not sorted: the device refuses, the redo sorts on the device
+    shuffled_answer = (e.totals(), e.digest())
+    assert e.totals() == want["long"][0] and vs.info().t6_refused == r0 + 2
+    check(e, shuffled, step=11)
+    e.close()
+    f = vs.get_var_in_ref(long_)            # (a handle that has just sorted sorts first: not speculative; still the same answer)
+    assert (f.totals(), f.digest(), f.layout()) == want["long"]
+    f.close()
+    # many batches in flight, results read in another order than they were submitted, some never read
+    for _ in range(40):
+        vs.get_var_in_ref(long_).close()    # (until the handle looks at the order as given again and finds it sorted)
+    flight = [vs.get_var_in_ref(long_) for _ in range(12)]
+    for k in (11, 0, 5):
+        assert (flight[k].totals(), flight[k].digest(), flight[k].layout()) == want["long"], k
+    for r in flight:
+        r.close()
+    g = vs.get_var_in_ref(long_)
+    assert (g.totals(), g.digest()) == want["long"][:2]
+    check(g, long_, step=13)
+    g.close()
+    assert vs.info().t6_speculated >= s0.t6_speculated + 10
+    vs.set_option("t6_speculate", 0)
+    h = vs.get_var_in_ref(shuffled)
+    assert (h.totals(), h.digest()) == shuffled_answer
+    h.close()
+    vs.close()
+
+
 def test_digest_properties(tmp_path):
     """Size-independent properties used at full scale: the device digest is a function of the result
     only (same batch twice, and any permutation of the batch re-indexed, give the same per-region

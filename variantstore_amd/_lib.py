@@ -34,7 +34,8 @@ class IndexInfo(C.Structure):
                 ("num_sites", C.c_uint64), ("num_carriers", C.c_uint64), ("seq_length", C.c_uint64),
                 ("num_samples", C.c_uint32), ("use_bit_vector", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("device", C.c_int), ("num_topology_keys", C.c_uint64), ("list_max", C.c_uint32), ("reserved_", C.c_uint32),
-                ("t4_rows_bytes", C.c_uint64), ("pool_mallocs", C.c_uint64), ("pool_frees", C.c_uint64)]
+                ("t4_rows_bytes", C.c_uint64), ("pool_mallocs", C.c_uint64), ("pool_frees", C.c_uint64),
+                ("t6_speculated", C.c_uint64), ("t6_refused", C.c_uint64)]
 
 
 class ResultView(C.Structure):

@@ -68,6 +68,9 @@ struct EngineOpts {
                                 // is in flight (every accessor of the result waits for it): the next batch's plan and rows run beside it
   int t4_walk = 2;              // "t4_walk": the walk of query type 4 -- 2 cooperative (8 lanes per region, episodes in parallel; default),
                                 // 1 one lane per region jumping over uneventful ref-path runs, 0 literal (every vertex of the sample's path)
+  bool t6_speculate = true;     // "t6_speculate": a type-6 batch that returns when it is enqueued does not wait for its plan's totals either -- table and
+                                // arena are sized from the handle's previous batch (+ 1/8), the kernels read the totals on the device, and a batch
+                                // that does not fit is refused there and redone with the exact sizes when its result is first asked for anything
   bool force_fallbacks = false; // "force_fallbacks": the count-then-emit pairs of walks that query types 2 - 5 fall back to when a region
                                 // outgrows the capacity of its recording walk (tests of those paths)
   // ---- read from the environment when the handle is opened ----
@@ -120,6 +123,15 @@ struct vs_index {
   // large batch refused on the device and redone.  [0 / 1]: walk hints, [2 / 3]: sequence hints.
   uint32_t hint_small_runs[4] = {0, 0, 0, 0};
   uint64_t hint_small_max[4] = {0, 0, 0, 0};
+  // speculative type-6 batches (run_type6_shared, result_sizes): what the last shared batch needed (+ 1/8) and how many regions it had;
+  // a ring of totals mailboxes in mapped host memory (kPinPlanRing), one per batch in flight, and who is still to read which
+  uint64_t t6_hint_rows = 0, t6_hint_arena = 0, t6_hint_n = 0;
+  uint32_t t6_small_runs = 0;
+  uint64_t t6_small_rows = 0, t6_small_arena = 0;
+  static constexpr int kPlanSlots = 8;
+  vs_result* plan_slot_owner[kPlanSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t plan_slot_next = 0;
+  uint64_t t6_speculated = 0, t6_refused = 0;   // batches submitted without a host wait / of those, refused on the device and redone (vs_index_info)
   uint64_t share_seq = 0;                   // sequence number of the plan's totals mailbox
   uint64_t done_seq = 0;                    // sequence number of the batch completion word
   uint64_t* walk_words = nullptr;           // the flag words of the walking batches (batch_words): zero between batches
@@ -167,6 +179,7 @@ struct vs_index {
   static constexpr size_t kPinPlan = 1056;    // [1056..1063] throughput path, shared rows: PlanTotals of the batch (k_t6_apply), sequence word last
   static constexpr size_t kPinDone = 1072;    // completion word of a batch (k_post_done)
   static constexpr size_t kPinWords = 1080;   // [1080..1083] three device words + sequence (k_post_words: read_device_words)
+  static constexpr size_t kPinPlanRing = 1104;   // [1104 .. 1104 + 8 x 8) PlanTotals of the speculative batches in flight (kPlanSlots mailboxes)
 };
 
 struct vs_result {
@@ -196,6 +209,11 @@ struct vs_result {
   hipEvent_t ev_done = nullptr;       // behind the LAST kernel of a batch that returned when it was enqueued (async_submit): nothing of the result
                                       // -- its buffers, the call's temporaries it keeps -- goes back to the pool before this has happened
   float fill_ms = -1.0f;
+  // a SPECULATIVE type-6 batch: d.A / d.S hold what was ALLOCATED until somebody asks for the result's sizes (result_sizes)
+  bool sizes_pending = false, totals_captured = false;
+  int plan_slot = -1;
+  uint64_t plan_seq = 0, cap_rows = 0, cap_arena = 0;
+  PlanTotals plan_copy{};
   bool resident = false;              // the carrier arena is the index's (vs_index::res_arena), not this result's
   bool scattered_lists = false;       // lists shared per vertex (walking query types): a region's carriers are not one arena range
   std::vector<uint64_t> h_car_len;
@@ -982,18 +1000,80 @@ static int read_device_words(vs_index* idx, const uint64_t* a, uint64_t* va, con
   return VS_OK;
 }
 
+// ---- speculative type-6 batches: hints, the totals mailbox, the result's sizes on first use ----
+static void t6_hint_update(vs_index* idx, uint64_t n, uint64_t rows, uint64_t arena) {
+  const uint64_t need_rows = rows + rows / 8 + 1024, need_arena = arena + arena / 8 + 4096;
+  idx->t6_hint_n = n;
+  if (need_rows > idx->t6_hint_rows || need_arena > idx->t6_hint_arena || idx->t6_hint_rows == 0) {   // grows at once (both: they belong to one shape of batch)
+    idx->t6_hint_rows = std::max(idx->t6_hint_rows, need_rows); idx->t6_hint_arena = std::max(idx->t6_hint_arena, need_arena);
+    idx->t6_small_runs = 0; idx->t6_small_rows = idx->t6_small_arena = 0;
+    return;
+  }
+  if (need_rows >= idx->t6_hint_rows / 2 && need_arena >= idx->t6_hint_arena / 2) { idx->t6_small_runs = 0; idx->t6_small_rows = idx->t6_small_arena = 0; return; }
+  // shrinks after kHintShrinkAfter consecutive batches that needed less than half of it, to the largest of those
+  idx->t6_small_rows = std::max(idx->t6_small_rows, need_rows); idx->t6_small_arena = std::max(idx->t6_small_arena, need_arena);
+  if (++idx->t6_small_runs >= kHintShrinkAfter) {
+    idx->t6_hint_rows = idx->t6_small_rows; idx->t6_hint_arena = idx->t6_small_arena;
+    idx->t6_small_runs = 0; idx->t6_small_rows = idx->t6_small_arena = 0;
+  }
+}
+// The totals of a speculative batch move from its mailbox into the result (and the handle's hints follow them).  The plan is four short
+// kernels in front of everything else of the batch: by the time anybody asks, the word is there.
+static int capture_totals(vs_result* r) {
+  if (!r->sizes_pending || r->totals_captured) return VS_OK;
+  vs_index* idx = r->idx;
+  volatile PlanTotals* pt = reinterpret_cast<volatile PlanTotals*>(idx->pinned + vs_index::kPinPlanRing + (size_t)r->plan_slot * 8);
+  VS_TRY(wait_posted(idx, &pt->seq, r->plan_seq, 2000));
+  r->plan_copy.rows = pt->rows; r->plan_copy.arena = pt->arena; r->plan_copy.shared_rows = pt->shared_rows; r->plan_copy.not_sorted = pt->not_sorted;
+  r->plan_copy.reported = pt->reported; r->plan_copy.n_slow = pt->n_slow; r->plan_copy.n_runs = pt->n_runs; r->plan_copy.seq = r->plan_seq;
+  r->totals_captured = true;
+  if (idx->plan_slot_owner[r->plan_slot] == r) idx->plan_slot_owner[r->plan_slot] = nullptr;
+  if (!r->plan_copy.not_sorted) t6_hint_update(idx, r->d.Q, r->plan_copy.rows, r->plan_copy.arena);
+  return VS_OK;
+}
+static int result_ready(vs_result* r);
+static void release_bufs(vs_index* idx, std::vector<DevBuf>& bufs);
+static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
+                            bool allow_async, bool may_speculate);
+// Every accessor of a result calls this first: a speculative batch's sizes become the plan's totals here -- or, when the plan refused the
+// batch on the device (more rows or arena entries than were allocated, or regions that were not sorted), the batch is run again from the
+// result's own copy of the regions, with the exact sizes, before anything is read.
+static int result_sizes(vs_result* r) {
+  if (!r->sizes_pending) return VS_OK;
+  vs_index* idx = r->idx;
+  VS_TRY(capture_totals(r));
+  r->sizes_pending = false;
+  const PlanTotals& t = r->plan_copy;
+  if (!t.not_sorted && t.rows <= r->cap_rows && t.arena <= r->cap_arena) {
+    r->d.A = t.rows; r->d.S = t.arena;
+    r->n_rows_reported = t.reported; r->n_unique_sites = t.shared_rows;
+    return VS_OK;
+  }
+  idx->t6_refused++;
+  VS_TRY(result_ready(r));                         // (its kernels returned at once; nothing was written behind the plan)
+  if (idx->timing_owner == r) { idx->timing_owner = nullptr; idx->timing_pending = false; }
+  std::vector<DevBuf> old;
+  old.swap(r->bufs);                               // (the result's copy of the regions lives in there: released when the redo has read it)
+  const uint64_t n = r->d.Q;
+  const vs_region* dreg = reinterpret_cast<const vs_region*>(r->d.regions);
+  r->d = DevResult{};
+  const int rc = run_type6_shared(idx, dreg, n, r, /*regions_on_device=*/true, nullptr, /*allow_async=*/false, /*may_speculate=*/false);
+  release_bufs(idx, old);
+  return rc;
+}
+
 // The expansion of a shared batch that writes the shared rows as well (k_fill_sites2).  mode 2 (tuning builds): split -- rows +
 // listed variants here, the dense sites of the index the batch covers in k_fill_dense behind it.
 template <bool WIDE, bool TUNE>
 static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, const uint32_t* coarse, uint64_t n_runs, uint64_t U, uint32_t chunk,
-                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, int mode) {
+                         size_t lds_bytes, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, int mode, const PlanDev* pd = nullptr) {
   const unsigned blocks = (unsigned)(((U + chunk - 1) / chunk + 3) / 4);
 #ifdef VS_TUNING
   if (mode == 2) {
     switch (chunk) {
-      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
-      case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
-      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, (const PlanDev*)nullptr); break;
+      case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, (const PlanDev*)nullptr); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE, false>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, (const PlanDev*)nullptr); break;
     }
     const uint64_t nd = idx->d.n_dense;
     if (nd) {
@@ -1010,10 +1090,10 @@ static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, 
   }
 #endif
   switch (chunk) {
-    case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
-    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat); break;
+    case 8:  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 8, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, pd); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 32, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, pd); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 64, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, pd); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill_sites2<WIDE, 16, TUNE>), dim3(blocks), dim3(256), lds_bytes, idx->stream, idx->d, d, runs, coarse, n_runs, U, ablate, gt_words, tstat, pd); break;
   }
 }
 
@@ -1027,7 +1107,7 @@ static void launch_fill2(vs_index* idx, const DevResult& d, const RunRec* runs, 
 //          with async_fill k_share_rows2 here and k_fill_sites on the second stream
 //   done   k_post_done: a word in mapped host memory, the host spins on it
 static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n, vs_result* r, bool regions_on_device, const uint64_t* site_records,
-                            bool allow_async) {
+                            bool allow_async, bool may_speculate = true) {
   if (idx->srv_alive) VS_TRY(server_stop(idx));   // a throughput batch does not share the GPU with a polling server
   idx->timing_pending = false; idx->timing_owner = nullptr; idx->timing_total_only = false;   // (an earlier lean batch's event pair is not this batch's)
   DevResult& d = r->d;
@@ -1073,16 +1153,38 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   uint32_t *e_prev = nullptr, *status = nullptr, *slow_list = nullptr;
   RunRec* runs = nullptr;
   uint32_t* coarse = nullptr;
+  PlanDev* plan_dev = nullptr;
   {   // the plan's temporaries: one buffer
     Slab sl;
     const size_t o_co = sl.add((idx->d.G / kCoarseRows + 2) * 4), o_tm = sl.add(ntiles * sizeof(ShareMax)),
                  o_ts = sl.add((ntiles + 1) * sizeof(Scan5)),   // (+ the totals: k_t6_totals)
-                 o_ep = sl.add(n * 4), o_st = sl.add(4), o_sl = sl.add(n * 4), o_ru = sl.add((n + 1) * sizeof(RunRec));
+                 o_ep = sl.add(n * 4), o_st = sl.add(4), o_sl = sl.add(n * 4), o_ru = sl.add((n + 1) * sizeof(RunRec)), o_pd = sl.add(sizeof(PlanDev));
     VS_TRY(dev_alloc(idx, sl.bytes, (void**)&sl.base, &scratch.bufs));
     coarse = sl.at<uint32_t>(o_co); tile_max = sl.at<ShareMax>(o_tm); tile_sums = sl.at<Scan5>(o_ts);
     e_prev = sl.at<uint32_t>(o_ep); status = sl.at<uint32_t>(o_st); slow_list = sl.at<uint32_t>(o_sl); runs = sl.at<RunRec>(o_ru);
+    plan_dev = sl.at<PlanDev>(o_pd);
   }
-  PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + vs_index::kPinPlan);
+  // SPECULATIVE (round 6, option t6_speculate): the default batch -- async_submit, rows and lists in one launch, regions given as regions --
+  // on a handle whose previous shared batch was about this size does not wait for the plan's totals: table and arena are sized from that
+  // batch (+ 1/8), k_t6_totals leaves the totals and its verdict in device memory for the kernels behind it (PlanDev) and in this batch's
+  // own mailbox for the host, which reads it when the result is first asked for anything (result_sizes) -- and redoes a refused batch.
+  const uint64_t want_rows = idx->t6_hint_rows, want_arena = idx->t6_hint_arena;
+  const bool spec = may_speculate && idx->opts.t6_speculate && plan_aside && regions && !site_records && !resident && idx->opts.fill_fused && !idx->opts.fill_mode &&
+                    !idx->opts.fill_stats && !idx->opts.lat_debug && want_rows > 0 && idx->t6_hint_n > 0 && n * 4 <= idx->t6_hint_n * 5 && n * 5 >= idx->t6_hint_n * 4;
+  int slot = -1;
+  if (spec) {
+    slot = (int)(idx->plan_slot_next++ % vs_index::kPlanSlots);
+    if (idx->plan_slot_owner[slot]) VS_TRY(capture_totals(idx->plan_slot_owner[slot]));   // (eight batches back: long done; its totals move into the result)
+  }
+  PlanTotals* pt = reinterpret_cast<PlanTotals*>(idx->pinned + (spec ? vs_index::kPinPlanRing + (size_t)slot * 8 : vs_index::kPinPlan));
+  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
+  if (spec) {   // table and arena BEFORE the plan: the rows of the regions under the duplicate rule are written on the plan's stream (k_t6_slow below)
+    d.A = want_rows; d.S = want_arena;
+    VS_TRY(ralloc(r, d.A, &d.rows));
+    uint8_t* arena = nullptr;
+    VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
+    d.carriers = arena;
+  }
   auto launch_bounds = [&](int src) {
     if (src == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<0>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, regions_dev, items, tile_max, status);
     else if (src == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_bounds<1>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, site_records, items, tile_max, status);
@@ -1090,16 +1192,23 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   };
   // the plan over the regions as they stand in `d`; the totals arrive in mapped host memory
   bool plan_end_enqueued = false;   // ev[1] recorded behind the (last) plan and waited for by the handle's stream
+  uint64_t plan_seq = 0;
   auto plan = [&](int src) -> int {
     plan_end_enqueued = false;
     launch_bounds(src);   // (block 0 clears `status`)
     hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
-    hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u);
+    hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u,
+                       spec ? plan_dev : (PlanDev*)nullptr, want_rows, want_arena);
+    plan_seq = seq;
     if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                                      ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, idx->res_entries);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
                             ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, (uint64_t)0);
+    // speculative: the private rows of the regions under the duplicate rule (count and verdict from the plan's record) on the PLAN's stream,
+    // beside the previous batch's expansion like the rest of the plan -- the handle's stream then carries the expansion alone
+    if (spec) hipLaunchKernelGGL(k_t6_slow, dim3((unsigned)((std::min<uint64_t>(n, 1024) + 3) / 4)), dim3(256), 0, ps, idx->d, d, (const uint32_t*)slow_list, (uint64_t)0,
+                                 (const PlanDev*)plan_dev);
     HIP_TRY(hipGetLastError());
     // the plan's end event, and the handle's stream waiting for it, are enqueued while the plan is still on its way to the totals:
     // two calls less between "the totals are here" and "the expansion is launched" (a batch of a tenth of a millisecond is the host's)
@@ -1108,7 +1217,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
       HIP_TRY(hipStreamWaitEvent(idx->stream, idx->ev[1], 0));
       plan_end_enqueued = true;
     }
-    return wait_posted(idx, &pt->seq, seq, 200);
+    return spec ? VS_OK : wait_posted(idx, &pt->seq, seq, 200);   // (a speculative batch: nobody waits here)
   };
   // A batch that is not sorted by first site: counting sort of the regions over the site index (k_sort_*), the batch
   // then works on sorted copies of its per-region arrays (`d` points at them from here on, `d_user` keeps the
@@ -1149,6 +1258,8 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     launch_bounds(src);
     VS_TRY(sort_batch());
     VS_TRY(plan(2));
+  } else if (spec) {
+    VS_TRY(plan(src));   // (sorted or not is the device's verdict)
   } else {
     VS_TRY(plan(src));
     if (pt->not_sorted) {
@@ -1161,23 +1272,29 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
       idx->sort_hint = true; idx->sort_probe_in = 32;
     } else idx->sort_hint = false;
   }
-  if (pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
+  if (!spec && pt->not_sorted) return fail(VS_ERR_INTERNAL, "the batch is not sorted by first site after the device-side sort");
   if (!plan_end_enqueued) HIP_TRY(hipEventRecord(idx->ev[1], ps));   // (a plan on the handle's own stream: the phase boundary only)
-  const uint64_t U = pt->shared_rows, n_slow = pt->n_slow, n_runs = pt->n_runs;
-  d.A = pt->rows;
-  d.S = pt->arena;
-  r->n_rows_reported = pt->reported;
+  // (speculative: every size below is what was ALLOCATED -- an upper bound the launches are made for; the kernels take the real ones from PlanDev)
+  const uint64_t U = spec ? want_rows : pt->shared_rows, n_slow = spec ? 0 : pt->n_slow, n_runs = spec ? 0 : pt->n_runs;
+  if (!spec) { d.A = pt->rows; d.S = pt->arena; }
+  r->n_rows_reported = spec ? 0 : pt->reported;
+  if (spec) {
+    r->sizes_pending = true; r->totals_captured = false; r->plan_slot = slot; r->plan_seq = plan_seq; r->cap_rows = want_rows; r->cap_arena = want_arena;
+    idx->plan_slot_owner[slot] = r;
+    idx->t6_speculated++;
+  } else t6_hint_update(idx, n, pt->rows, pt->arena);
   r->shared_lists = true;
   r->resident = resident;
   r->scattered_lists = false;
   r->n_unique_sites = resident ? 0 : U;
-  d.car_width = idx->d.wpc <= 63 ? 2 : 4;
-  VS_TRY(ralloc(r, d.A, &d.rows));
-  if (resident) d.carriers = idx->res_arena;
-  else {
-    uint8_t* arena = nullptr;
-    VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
-    d.carriers = arena;
+  if (!spec) {
+    VS_TRY(ralloc(r, d.A, &d.rows));
+    if (resident) d.carriers = idx->res_arena;
+    else {
+      uint8_t* arena = nullptr;
+      VS_TRY(ralloc(r, d.S * d.car_width + 16, &arena));
+      d.carriers = arena;
+    }
   }
   // ---- shared rows + carrier lists: which form ----
   const uint64_t n_fill = resident ? 0 : U;
@@ -1189,9 +1306,9 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   const bool lean = async_submit && fused && n_fill > 0 && !perm;
   if (!lean) HIP_TRY(hipEventRecord(idx->ev[2], idx->stream));
   // ---- rows of the regions under the duplicate rule ----
-  if (n_slow) {
+  if (n_slow) {   // (a speculative batch launched the kernel behind its plan, with the count from the plan's record)
     const uint64_t waves = std::min<uint64_t>(n_slow, 16384);
-    hipLaunchKernelGGL(k_t6_slow, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)slow_list, n_slow);
+    hipLaunchKernelGGL(k_t6_slow, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, idx->stream, idx->d, d, (const uint32_t*)slow_list, n_slow, (const PlanDev*)nullptr);
   }
   // ---- shared rows + carrier lists ----
   uint32_t* u_site = nullptr;
@@ -1240,8 +1357,9 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     const int mode = idx->opts.fill_mode;
     VS_TRY(result_events(r));   // the kernel's own duration, whenever the result is asked for it (vs_result_fill_ms)
     HIP_TRY(hipEventRecord(r->ev_fill[0], idx->stream));
-    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode);
-    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode);
+    const PlanDev* pd = spec ? plan_dev : nullptr;
+    if (idx->d.wpc > 63) launch_fill2<true, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, pd);
+    else launch_fill2<false, kTune>(idx, d, runs, coarse, n_runs, U, chunk, lds_bytes, ablate, gt_words, tstat, mode, pd);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(r->ev_fill[1], idx->stream));
     r->pending = true;
@@ -1766,6 +1884,7 @@ static int fetch(vs_index* idx, std::vector<T>& h, const T* dptr, size_t n) {
 
 // carriers [first, first + n) of the arena as 32-bit words (id | gt << 29), whatever the arena's width
 static int fetch_carriers(vs_result* r, uint64_t first, uint64_t n, std::vector<uint32_t>& out) {
+  VS_TRY(result_sizes(r));
   vs_index* idx = r->idx;
   VS_TRY(result_ready(r));
   out.resize(n);
@@ -1788,6 +1907,7 @@ static int fetch_carriers(vs_result* r, uint64_t first, uint64_t n, std::vector<
 
 // the per-region arrays (Q-sized: a few MB for the largest batches)
 static int fetch_region_meta(vs_result* r) {
+  VS_TRY(result_sizes(r));
   if (r->have_meta) return VS_OK;
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
@@ -1811,6 +1931,7 @@ static int fetch_region_meta(vs_result* r) {
 // The whole variant table on the host, and the VIEW built from it: every region's rows expanded back to back (shared
 // rows once per region that reports them) as the structure-of-arrays vs_result_view promises.
 static int fetch_headers(vs_result* r) {
+  VS_TRY(result_sizes(r));
   if (r->have_headers) return VS_OK;
   vs_index* idx = r->idx;
   VS_TRY(fetch_region_meta(r));
@@ -1982,6 +2103,7 @@ static int run_sample_seq_once(vs_index* idx, const vs_region* regions, uint64_t
 // the per-region records of any result on the handle's stream: site ranges + counts (k_pack_regions: query types 6, 4, 5, 1, 7)
 // or pieces + bytes (k_pack_seq_regions: types 2, 3)
 static int launch_pack_regions(vs_result* r, uint64_t* dst, uint64_t region_base) {
+  VS_TRY(result_sizes(r));
   vs_index* idx = r->idx;
   const uint64_t n = r->d.Q;
   if (!n) return VS_OK;
@@ -2379,6 +2501,8 @@ int vs_index_get_info(const vs_index* idx, vs_index_info* info) {
   info->t4_rows_bytes = idx->t4_rows_bytes;
   info->pool_mallocs = idx->pool_mallocs;
   info->pool_frees = idx->pool_frees;
+  info->t6_speculated = idx->t6_speculated;
+  info->t6_refused = idx->t6_refused;
   return VS_OK;
 }
 
@@ -2448,6 +2572,7 @@ int vs_index_set_option(vs_index* idx, const char* key, int64_t value) {
     else if (!idx->d.t4_events && cap) VS_TRY(build_t4_rows(idx, cap));
   } else if (k == "phase_events") o.phase_events = value != 0;
   else if (k == "force_fallbacks") o.force_fallbacks = value != 0;
+  else if (k == "t6_speculate") o.t6_speculate = value != 0;
   else if (k == "lat_debug" || k == "sc_group" || k == "fill_fused" || k == "fill_chunk" || k == "fill_mode" || k == "fill_dense_k" || k == "fill_stats" || k == "walk_stats" || k == "fill_ablate" ||
            k == "fill_lds_pad") {
 #ifdef VS_TUNING
@@ -2489,6 +2614,11 @@ void vs_result_free(vs_result* r) {
   if (r->idx) {
     (void)hipSetDevice(r->idx->device);
     (void)result_ready(r);
+    if (r->sizes_pending) {   // a speculative batch nobody asked anything of: its totals still feed the handle's hints, its mailbox goes back
+      (void)capture_totals(r);
+      if (r->idx->plan_slot_owner[r->plan_slot] == r) r->idx->plan_slot_owner[r->plan_slot] = nullptr;
+      r->sizes_pending = false;
+    }
     if (r->idx->timing_owner == r) (void)collect_timing(r->idx);   // (its events go back to the pool below)
     for (auto& e : r->ev_fill) if (e) { r->idx->ev_pool.push_back(e); e = nullptr; }
     if (r->ev_done) { r->idx->ev_pool.push_back(r->ev_done); r->ev_done = nullptr; }
@@ -2717,6 +2847,7 @@ int vs_index_find(vs_index* idx, const uint64_t* pos, uint64_t n, uint32_t* vert
 // ---------------------------------------------------------------- result access
 // Start (stream) the raw copy of a result: rows and -- on request -- the arena go into one page-locked block.
 static int raw_copy_begin(vs_result* r, bool with_carriers, hipStream_t stream) {
+  VS_TRY(result_sizes(r));
   vs_index* idx = r->idx;
   const DevResult& d = r->d;
   const size_t row_bytes = (size_t)d.A * sizeof(VariantRow), arena_bytes = with_carriers && !r->resident ? (size_t)d.S * d.car_width : 0;
@@ -2868,6 +2999,7 @@ int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_varia
   if (!r->have_totals) {   // reduced on the device: nothing but three words crosses PCIe
     vs_index* idx = r->idx;
     HIP_TRY(hipSetDevice(idx->device));
+    VS_TRY(result_sizes(r));
     ScratchBufs tmp(idx);
     void* dt = nullptr;
     VS_TRY(dev_alloc(idx, 24, &dt, &tmp.bufs));
@@ -2891,6 +3023,7 @@ int vs_result_totals(const vs_result* cr, uint64_t* n_regions, uint64_t* n_varia
 
 int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_t* len) {
   if (!r || !text) return fail(VS_ERR_ARG, "null argument");
+  VS_TRY(result_sizes(r));
   if (r->kind == 2 || r->kind == 3) {  // `out << seq << std::endl`, query.h:182-187 / :252-257
     VS_TRY(fetch_sequences(r));
     if (q >= r->sq.Q) return fail(VS_ERR_ARG, "region %llu out of range", (unsigned long long)q);
@@ -3009,6 +3142,7 @@ int vs_result_fill_ms(vs_result* r, float* ms) {
 int vs_result_layout(const vs_result* r, uint64_t* n_slots, uint64_t* table_rows, uint64_t* arena_entries, uint64_t* lists_expanded, int* shared) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
+  if (r->sizes_pending) { if (r->idx && r->idx->device >= 0) HIP_TRY(hipSetDevice(r->idx->device)); VS_TRY(result_sizes(const_cast<vs_result*>(r))); }
   if (n_slots) *n_slots = r->n_rows_reported;
   if (table_rows) *table_rows = r->d.A;
   if (arena_entries) *arena_entries = r->resident ? 0 : r->d.S;   // (a result over resident lists owns no arena)
@@ -3022,6 +3156,7 @@ int vs_result_digest(vs_result* r, uint64_t* digest) {
   VS_NOT_SEQ(r);
   vs_index* idx = r->idx;
   HIP_TRY(hipSetDevice(idx->device));
+  VS_TRY(result_sizes(r));
   VS_TRY(result_ready(r));
   ScratchBufs tmp(idx);
   void* dd = nullptr;
@@ -3045,6 +3180,7 @@ int vs_result_pack_headers(vs_result* r, void* device_dst, uint64_t capacity_rec
                            uint64_t* n_records) {
   if (!r) return fail(VS_ERR_ARG, "null argument");
   VS_NOT_SEQ(r);
+  if (r->sizes_pending) { HIP_TRY(hipSetDevice(r->idx->device)); VS_TRY(result_sizes(r)); }
   if (n_records) *n_records = r->n_rows_reported;   // rows over all regions (a shared row once per region reporting it)
   if (!device_dst) return VS_OK;  // size query
   if (capacity_records < r->n_rows_reported) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
@@ -3071,6 +3207,7 @@ int vs_result_pack_regions(vs_result* r, void* device_dst, uint64_t capacity_rec
   if (!r) return fail(VS_ERR_ARG, "null argument");
   if (n_records) *n_records = r->d.Q;
   if (!device_dst) return VS_OK;
+  if (r->sizes_pending) { HIP_TRY(hipSetDevice(r->idx->device)); VS_TRY(result_sizes(r)); }   // (a refused batch is redone before its records travel)
   if (capacity_records < r->d.Q) return fail(VS_ERR_ARG, "destination holds %llu records, %llu needed",
                                              (unsigned long long)capacity_records, (unsigned long long)r->d.Q);
   vs_index* idx = r->idx;

@@ -662,7 +662,11 @@ __device__ __forceinline__ void fill_sites_task(const DevImage& im, const DevRes
 
 template <bool WIDE, uint32_t CH, bool TUNE, bool DENSE = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fill_sites2(DevImage im, DevResult r, const RunRec* __restrict__ runs, const uint32_t* __restrict__ coarse, uint64_t n_runs,
-                                                     uint64_t U, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat) {
+                                                     uint64_t U, uint32_t ablate, uint32_t gt_words, unsigned long long* tstat, const PlanDev* pd) {
+  if (pd) {   // speculative batch (k_rows.hip.h: PlanDev): the launch covers the rows that were ALLOCATED; the plan's record says how many exist
+    if (pd->refused) return;
+    U = pd->U; n_runs = pd->n_runs;
+  }
   const uint64_t t_start = (TUNE && tstat) ? wall_clock64() : 0;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;

@@ -154,6 +154,13 @@ struct PlanTotals {
   uint64_t seq;         // written last, system-scope release: the host spins on it
 };
 
+// A SPECULATIVE batch (round 6: its table and arena were sized from the handle's previous batch and nothing waits for the plan's totals
+// on the host) hands the totals to the kernels behind the plan in device memory: k_t6_totals writes this record, k_t6_slow and
+// k_fill_sites2 read it instead of kernel arguments -- and return at once when the plan REFUSED the batch (not sorted, or rows or arena
+// beyond what was allocated): the host learns that from the mailbox the first time it asks for the result's sizes and redoes the batch
+// with the exact sizes (engine.hip: result_sizes), as the walking batches do (WalkAdmit).
+struct PlanDev { uint64_t U, n_runs, n_slow; uint32_t refused, pad_; };
+
 // SRC 0: bounds from (x, y); 1: from gathered records (k_bounds_from_records); 2: the per-region arrays are already there
 // (a batch sorted on the device works on permuted copies of them)
 struct RecordBounds { uint32_t g0, nv; uint8_t fl; uint64_t npad; };
@@ -329,7 +336,7 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
 // [ntiles]) and the totals go to the host, which sizes table and arena and enqueues the expansion while k_t6_apply writes the
 // per-region arrays nobody on the host is waiting for.
 __global__ void __launch_bounds__(kPlanBlock) k_t6_totals(Scan5* tile_sums, uint32_t ntiles, const uint32_t* status, PlanTotals* totals_host, uint64_t seq,
-                                                          uint64_t resident_entries, uint32_t resident) {
+                                                          uint64_t resident_entries, uint32_t resident, PlanDev* pd, uint64_t cap_rows, uint64_t cap_arena) {
   Scan5 carry{0, 0, 0, 0, 0, 0};
   for (uint32_t t0 = 0; t0 < ntiles; t0 += kPlanBlock) {
     const uint32_t t = t0 + threadIdx.x;
@@ -344,6 +351,11 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_totals(Scan5* tile_sums, uint
     totals_host->rows = carry.u + carry.p; totals_host->arena = resident ? resident_entries : carry.c; totals_host->shared_rows = carry.u;
     totals_host->not_sorted = *status;
     totals_host->reported = carry.a; totals_host->n_slow = carry.s; totals_host->n_runs = carry.r;
+    if (pd) {   // speculative batch: the verdict and what the kernels behind the plan need, on the device
+      const uint64_t arena = resident ? resident_entries : carry.c;
+      pd->U = carry.u; pd->n_runs = carry.r; pd->n_slow = carry.s;
+      pd->refused = (*status || carry.u + carry.p > cap_rows || arena > cap_arena) ? 1u : 0u;
+    }
     __hip_atomic_store(&totals_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -517,7 +529,11 @@ __global__ void __launch_bounds__(64) k_dedup_slow(DevImage im, DevResult r) {
 
 // Regions under the duplicate rule: a private copy of their rows behind the shared table (their drops are their own),
 // then the literal rule.  One wave per such region, from the list k_t6_apply left.
-__global__ void __launch_bounds__(256) k_t6_slow(DevImage im, DevResult r, const uint32_t* slow_list, uint64_t n) {
+__global__ void __launch_bounds__(256) k_t6_slow(DevImage im, DevResult r, const uint32_t* slow_list, uint64_t n, const PlanDev* pd) {
+  if (pd) {   // speculative batch: the count from the plan's record; nothing to do for a batch the plan refused
+    if (pd->refused) return;
+    n = pd->n_slow;
+  }
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   for (uint64_t i = wave; i < n; i += nwaves) {
