@@ -539,8 +539,9 @@ def distributed_legs(args, w, vs, comm, rank, world, local_rank, regions_dev, nr
         recs, c = gather_sync(res, base, cnts)
         tot = res.totals()
         mine = torch.tensor([int(tot[1]), int(tot[2])], dtype=torch.int64, device=dev)
-        allt = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        allt = torch.zeros(world * 2, dtype=torch.int64, device=dev)   # (flat: the form every backend takes)
         dist.all_gather_into_tensor(allt, mine)
+        allt = allt.view(world, 2)
         ok = 1
         if rank == 0:
             for fault in verify_gathered_regions(unpack_region_records(recs, c), cnts, bases, allt.cpu().numpy()):
@@ -742,6 +743,12 @@ def main():
     ceil = box_ceilings() if int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # VS_BENCH_SAME_DEVICE=1 (a REHEARSAL of the N > 1 code on a one-GPU box, not a measurement): every rank uses GPU 0, torch.distributed runs
+    # over gloo (barrier, timing reduction, unique id) and the engine's collective over the stand-in tests/native/fake_rccl.cpp (VS_RCCL_LIB):
+    # real RCCL refuses two ranks on one device.  The line says so ("rehearsal_same_device": true).
+    same_device = os.environ.get("VS_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world > 1 and args.gpus == 1:
@@ -755,7 +762,12 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if same_device:
+            if world > 1 and not os.environ.get("VS_RCCL_LIB"):
+                raise SystemExit("VS_BENCH_SAME_DEVICE=1 needs VS_RCCL_LIB (tests/native/fake_rccl.cpp): real RCCL refuses two ranks on one device")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from variantstore_amd import DeviceArray, VariantStore
     from variantstore_amd.parallel import allgather_hit_lists, allgather_region_records, make_comm, shard_bounds
@@ -1275,6 +1287,8 @@ def main():
             "value": total_regions * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
+            **({"rehearsal_same_device": True, "rehearsal_note": "every rank on GPU 0 through tests/native/fake_rccl.cpp and gloo: the N > 1 code paths, not a measurement"}
+               if same_device else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
