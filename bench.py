@@ -422,24 +422,30 @@ def spawn_ranks(ngpus):
     print(lines[-1], flush=True)
 
 
-def back_to_back(call, reps):
-    """Seconds per batch of `call` submitted back to back: a result is closed one step late (closing waits for its batch), the
-    clock stops when the device is idle."""
+def back_to_back(call, reps, vs=None):
+    """Seconds per batch of `call` submitted back to back: a result is closed `depth - 1` steps late (closing waits for its batch; depth =
+    VS_BENCH_DEPTH, default 3 as in the headline's loop), the clock stops when the device is idle.  `vs`: the handle -- a type-6 batch
+    that the device REFUSED (speculative sizes: vs_index_info.t6_refused) did no work unless its result is read, so a measurement
+    during which the counter moved is thrown away and repeated (the handle's expectation has adapted by then)."""
     import torch
-    prev = call()      # warm-up (also: the handle's pool holds what two batches alive at a time need)
-    nxt = call()
-    prev.close()
-    prev = nxt
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _k in range(reps):
-        nxt = call()
-        prev.close()
-        prev = nxt
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    prev.close()
-    return dt
+    depth = max(2, int(os.environ.get("VS_BENCH_DEPTH", "3")))
+    for _attempt in range(4):
+        refused0 = vs.info().t6_refused if vs is not None else 0
+        alive = [call() for _k in range(depth - 1)]      # warm-up (also: the handle's pool holds what `depth` batches alive at a time need)
+        alive.append(call())
+        alive.pop(0).close()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _k in range(reps):
+            alive.append(call())
+            alive.pop(0).close()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        while alive:
+            alive.pop(0).close()
+        if vs is None or vs.info().t6_refused == refused0:
+            return dt
+    raise SystemExit("bench.py: type-6 batches kept being refused on the device inside a timed loop")
 
 
 def mixed_types_leg(types, vs, comm, rank, world, local_rank, regions, regions_dev, nreg, region_base, counts, num_samples, use_dist):
@@ -889,6 +895,7 @@ def main():
     # The timing of a batch is read late, from the result's OWN pair of HIP events around the expansion kernel on the stream it ran on --
     # reading the handle's events right after the call would wait for the batch and put the host back between the batches.
     fill_steps = 0
+    refused_before = vs.info().t6_refused
     t0 = time.perf_counter()
     for i in range(args.steps):
         res, _g = step()
@@ -911,6 +918,8 @@ def main():
         if alive:
             old.close()
     res = old   # (the last step's result stays alive: the figures below are read from it)
+    if vs.info().t6_refused != refused_before:   # (a refused batch does its work only when its result is read: a timed loop must not hold one)
+        raise SystemExit("bench.py: a batch of the timed loop was refused on the device (speculative sizes): the warm-up did not settle the handle's expectation")
     if fill_steps == 0:   # (a form without per-result events: private rows -- the handle's events of one more batch)
         res2, _g = step()
         fill_ms, fill_steps = vs.last_timing().ms_fill * args.steps, args.steps
@@ -1050,15 +1059,20 @@ def main():
     unsorted = None
     if lists_shared:
         shuffled = torch.from_numpy(np.ascontiguousarray(regions[np.random.default_rng(5).permutation(nreg)]).astype(np.int64)).to(regions_dev.device)
-        for _i in range(2):
-            vs.get_var_in_ref_device(shuffled.data_ptr(), nreg).close()
+        for _i in range(3):   # (the first one is refused on the device -- a speculative batch that turns out unsorted -- and the handle sorts first from then on)
+            wu = vs.get_var_in_ref_device(shuffled.data_ptr(), nreg)
+            wu.totals()
+            wu.close()
         torch.cuda.synchronize()
+        refused0 = vs.info().t6_refused
         a = time.perf_counter()
         for _i in range(5):
             ru = vs.get_var_in_ref_device(shuffled.data_ptr(), nreg)
             ru.close()
         torch.cuda.synchronize()
         dtu = (time.perf_counter() - a) / 5
+        if vs.info().t6_refused != refused0:
+            raise SystemExit("bench.py: an unsorted batch was refused inside its timed loop")
         ru = vs.get_var_in_ref_device(shuffled.data_ptr(), nreg)
         unsorted = {"queries_per_s": nreg / dtu, "ms_per_step": dtu * 1e3, "shares_rows_and_lists": bool(ru.layout()[4]), "same_totals": tuple(ru.totals()) == (nq, nvar, ncar, nbases)}
         ru.close()
@@ -1113,6 +1127,18 @@ def main():
         if tw and walk_ms > 0:   # the walk kernel's own pin traffic (PMC) over the walk phase (capacity bounds + scan + walk) timed here
             t4["walk_traffic_bytes"] = tw["traffic_bytes_per_launch"]
             t4["walk_traffic_GBps"] = tw["traffic_bytes_per_launch"] / (walk_ms / 3 * 1e-3) / 1e9
+            # the roofline of the type-4 leg's own dominant kernels: the recording walk -- dependent look-ups, bound by
+            # memory latency, priced against the same 8 TB/s -- and the carrier expansion of its lists (k_fill_carriers: all dense variants)
+            t4["roofline"] = {"bound": "hbm", "kernel": "k_sample_walk_coop", "traffic": tw["traffic_bytes_per_launch"], "achieved": t4["walk_traffic_GBps"],
+                              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": t4["walk_traffic_GBps"] / HBM_PEAK_GBPS, "basis": "pmc_traffic",
+                              "launch_ms": walk_ms / 3, "wait_any_frac_of_wave_cycles": (tw.get("SQ_WAIT_ANY") / tw["SQ_WAVE_CYCLES"]) if tw.get("SQ_WAVE_CYCLES") else None,
+                              "note": "walk phase by the handle's events (capacity bounds + scan + walk); latency-bound: most wave cycles wait on memory"}
+            tf = tj["kernels"].get("k_fill_carriers")
+            if tf and tf.get("avg_us_under_pmc"):
+                gbps = tf["traffic_bytes_per_launch"] / (tf["avg_us_under_pmc"] * 1e-6) / 1e9
+                t4["list_fill_roofline"] = {"bound": "hbm", "kernel": "k_fill_carriers", "traffic": tf["traffic_bytes_per_launch"], "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                                            "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "basis": "pmc_traffic", "launch_ms": tf["avg_us_under_pmc"] / 1e3,
+                                            "note": "duration from the same PMC passes as the traffic (profiles/traffic_<workload>.json)"}
 
     # ---- point queries (types 1 and 7) on the same index, outside the timed region:
     #      1M random positions; type 7 asks for an A>C substitution everywhere (nearly always "no such variant",
@@ -1381,6 +1407,10 @@ def main():
             "sample_coordinate_queries": tsc,
             "delivery": delivery, "resident_lists": resident, "unsorted_batch": unsorted, "pipelined": pipe,
             "result_digest": f"{digest:016x}",
+            # type-6 batches of this process submitted without a host wait (table and arena sized from the batch before, totals read on the
+            # device) and how many of those the device refused and the host reran (none inside a timed loop: the loops check)
+            "speculative_batches": {"submitted": int(vs.info().t6_speculated), "refused_and_redone": int(vs.info().t6_refused),
+                                    "results_alive_in_the_timed_loop": max(2, int(os.environ.get("VS_BENCH_DEPTH", "3")))},
         }
         if not args.no_cpu_baseline:
             # rank 0, at every N (the other ranks wait in the barrier below): the oracle on one host thread and the parity

@@ -1029,6 +1029,7 @@ static int capture_totals(vs_result* r) {
   r->totals_captured = true;
   if (idx->plan_slot_owner[r->plan_slot] == r) idx->plan_slot_owner[r->plan_slot] = nullptr;
   if (!r->plan_copy.not_sorted) t6_hint_update(idx, r->d.Q, r->plan_copy.rows, r->plan_copy.arena);
+  else { idx->sort_hint = true; idx->sort_probe_in = 32; }   // (as after a batch that was sorted on the device: the next ones sort first -- also when nobody reads this one)
   return VS_OK;
 }
 static int result_ready(vs_result* r);
@@ -1151,6 +1152,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   ShareMax* tile_max = nullptr;
   Scan5* tile_sums = nullptr;
   uint32_t *e_prev = nullptr, *status = nullptr, *slow_list = nullptr;
+  uint64_t* e_prev_c = nullptr;   // the arena prefix at E_prev, carried by the same scan (k_rows.hip.h: ShareMax)
   RunRec* runs = nullptr;
   uint32_t* coarse = nullptr;
   PlanDev* plan_dev = nullptr;
@@ -1158,11 +1160,12 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
     Slab sl;
     const size_t o_co = sl.add((idx->d.G / kCoarseRows + 2) * 4), o_tm = sl.add(ntiles * sizeof(ShareMax)),
                  o_ts = sl.add((ntiles + 1) * sizeof(Scan5)),   // (+ the totals: k_t6_totals)
-                 o_ep = sl.add(n * 4), o_st = sl.add(4), o_sl = sl.add(n * 4), o_ru = sl.add((n + 1) * sizeof(RunRec)), o_pd = sl.add(sizeof(PlanDev));
+                 o_ep = sl.add(n * 4), o_st = sl.add(4), o_sl = sl.add(n * 4), o_ru = sl.add((n + 1) * sizeof(RunRec)), o_pd = sl.add(sizeof(PlanDev)),
+                 o_ec = sl.add(n * 8);
     VS_TRY(dev_alloc(idx, sl.bytes, (void**)&sl.base, &scratch.bufs));
     coarse = sl.at<uint32_t>(o_co); tile_max = sl.at<ShareMax>(o_tm); tile_sums = sl.at<Scan5>(o_ts);
     e_prev = sl.at<uint32_t>(o_ep); status = sl.at<uint32_t>(o_st); slow_list = sl.at<uint32_t>(o_sl); runs = sl.at<RunRec>(o_ru);
-    plan_dev = sl.at<PlanDev>(o_pd);
+    plan_dev = sl.at<PlanDev>(o_pd); e_prev_c = sl.at<uint64_t>(o_ec);
   }
   // SPECULATIVE (round 6, option t6_speculate): the default batch -- async_submit, rows and lists in one launch, regions given as regions --
   // on a handle whose previous shared batch was about this size does not wait for the plan's totals: table and arena are sized from that
@@ -1196,14 +1199,14 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   auto plan = [&](int src) -> int {
     plan_end_enqueued = false;
     launch_bounds(src);   // (block 0 clears `status`)
-    hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, tile_sums, status);
+    hipLaunchKernelGGL(k_t6_mid, dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const ShareMax*)tile_max, items, e_prev, e_prev_c, tile_sums, status);
     const uint64_t seq = ++idx->share_seq;
     hipLaunchKernelGGL(k_t6_totals, dim3(1), dim3(kPlanBlock), 0, ps, tile_sums, ntiles, (const uint32_t*)status, pt, seq, idx->res_entries, resident ? 1u : 0u,
                        spec ? plan_dev : (PlanDev*)nullptr, want_rows, want_arena);
     plan_seq = seq;
-    if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+    if (resident) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<true>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const uint64_t*)e_prev_c, (const Scan5*)tile_sums,
                                      ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, idx->res_entries);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const Scan5*)tile_sums,
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_t6_apply<false>), dim3(ntiles), dim3(kPlanBlock), 0, ps, idx->d, d, (const uint32_t*)e_prev, (const uint64_t*)e_prev_c, (const Scan5*)tile_sums,
                             ntiles, items, runs, coarse, slow_list, (const uint32_t*)status, (uint64_t)0);
     // speculative: the private rows of the regions under the duplicate rule (count and verdict from the plan's record) on the PLAN's stream,
     // beside the previous batch's expansion like the rest of the plan -- the handle's stream then carries the expansion alone
@@ -3134,6 +3137,7 @@ int vs_result_format_region(vs_result* r, uint64_t q, const char** text, uint64_
 int vs_result_fill_ms(vs_result* r, float* ms) {
   if (!r || !ms) return fail(VS_ERR_ARG, "null argument");
   if (r->idx && r->idx->device >= 0) HIP_TRY(hipSetDevice(r->idx->device));
+  VS_TRY(result_sizes(r));   // (a refused speculative batch is run now: the time asked for is that of the expansion that produced the result)
   VS_TRY(result_ready(r));
   *ms = r->fill_ms;
   return VS_OK;

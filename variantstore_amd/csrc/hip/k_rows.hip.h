@@ -71,19 +71,26 @@ __global__ void __launch_bounds__(256) k_emit_headers(DevImage im, DevResult r) 
 // ---------------------------------------------------------------------------
 constexpr int kPlanBlock = 256;
 constexpr uint32_t kPlanMaxTiles = 4096;
-struct ShareMax { uint32_t g1, g0; };
-__device__ __forceinline__ ShareMax smax(ShareMax a, ShareMax b) { return ShareMax{a.g1 > b.g1 ? a.g1 : b.g1, a.g0 > b.g0 ? a.g0 : b.g0}; }
+// Round 6: the prefix maximum carries the ARENA PREFIX at the largest site end with it (c1 = s_carpre[g1], which the bounds kernel has from
+// the slot record anyway): E_prev and s_carpre[E_prev] then come out of the same scan, and what a region adds to the batch (share_new)
+// follows from three numbers the plan already holds -- k_t6_mid and k_t6_apply no longer look anything up in the site table (57 MB of
+// scattered 128-byte lines per 100 k regions in round 5: four s_carpre / s_kpre look-ups per region and pass), they stream their arrays.
+struct ShareMax { uint32_t g1, g0; uint64_t c1; };
+__device__ __forceinline__ ShareMax smax(ShareMax a, ShareMax b) {
+  return ShareMax{a.g1 >= b.g1 ? a.g1 : b.g1, a.g0 > b.g0 ? a.g0 : b.g0, a.g1 >= b.g1 ? a.c1 : b.c1};
+}
 __device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* total) {
   __shared__ ShareMax wmx[kPlanBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   ShareMax incl = v;
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t a = __shfl_up(incl.g1, d, 64), b = __shfl_up(incl.g0, d, 64);
-    if (lane >= d) incl = smax(incl, ShareMax{a, b});
+    const uint64_t c = __shfl_up(incl.c1, d, 64);
+    if (lane >= d) incl = smax(incl, ShareMax{a, b, c});
   }
   if (lane == 63) wmx[wid] = incl;
   __syncthreads();
-  ShareMax woff{0, 0}, tot{0, 0};
+  ShareMax woff{0, 0, 0}, tot{0, 0, 0};
   for (int w = 0; w < kPlanBlock / 64; ++w) {
     if (w < wid) woff = smax(woff, wmx[w]);
     tot = smax(tot, wmx[w]);
@@ -91,11 +98,16 @@ __device__ __forceinline__ ShareMax block_exclusive_max(ShareMax v, ShareMax* to
   __syncthreads();
   *total = tot;
   const uint32_t pa = __shfl_up(incl.g1, 1, 64), pb = __shfl_up(incl.g0, 1, 64);
-  return lane ? smax(woff, ShareMax{pa, pb}) : woff;
+  const uint64_t pc = __shfl_up(incl.c1, 1, 64);
+  return lane ? smax(woff, ShareMax{pa, pb, pc}) : woff;
 }
-__device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {   // {end, start} of a region's site range; {0, 0} without sites
+// What the bounds kernel leaves per region for the rest of the plan, in arrays the plan's last pass overwrites with their final content:
+//   q_ncar[q]    padded arena entries of the region's site range (final in q_car_len)
+//   car_base[q]  arena prefix at its first site, s_carpre[g0]     (final: the region's arena offset)
+//   q_car_len[q] carriers its rows report, s_kpre[g1] - s_kpre[g0] (final in q_ncar)
+__device__ __forceinline__ ShareMax share_elem(const DevResult& r, uint64_t q) {   // {end, start, arena prefix at the end}; zeros without sites
   const uint32_t nv = (uint32_t)r.q_nvar[q];
-  return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q]} : ShareMax{0, 0};
+  return nv ? ShareMax{r.q_g0[q] + nv, r.q_g0[q], r.car_base[q] + r.q_ncar[q]} : ShareMax{0, 0, 0};
 }
 // rows reported (all regions), newly covered sites, their arena entries, private rows (regions under the duplicate rule), such
 // regions, runs (maximal stretches of covered sites: a region starts one when no earlier region reaches its first site)
@@ -128,17 +140,19 @@ __device__ __forceinline__ Scan5 block_exclusive_scan5(Scan5 v, Scan5* total) {
 }
 // what region q adds to the batch, given the largest site end before it
 struct ShareNew { uint32_t ns; uint64_t n_new, arena_new, back, rback, pre_ns; };
-__device__ __forceinline__ ShareNew share_new(const DevImage& im, uint32_t g0, uint32_t nv, uint32_t e_prev) {
-  ShareNew o{g0, 0, 0, 0, 0, 0};
+// c0 = s_carpre[g0], npad = s_carpre[g1] - c0, ce = s_carpre[e_prev]: the first site the region is the first to cover is g0, e_prev or g1
+__device__ __forceinline__ ShareNew share_new(uint32_t g0, uint32_t nv, uint32_t e_prev, uint64_t c0, uint64_t npad, uint64_t ce) {
+  ShareNew o{g0, 0, 0, 0, 0, c0};
   if (!nv) return o;
   const uint32_t g1 = g0 + nv;
-  o.ns = e_prev > g0 ? (e_prev < g1 ? e_prev : g1) : g0;
+  const uint64_t c1 = c0 + npad;
+  if (e_prev <= g0) { o.ns = g0; o.pre_ns = c0; }
+  else if (e_prev < g1) { o.ns = e_prev; o.pre_ns = ce; }
+  else { o.ns = g1; o.pre_ns = c1; }
   o.n_new = g1 - o.ns;
-  const uint64_t c0 = im.s_carpre[g0];
-  o.pre_ns = im.s_carpre[o.ns];
-  o.arena_new = im.s_carpre[g1] - o.pre_ns;
-  o.back = e_prev > g0 ? im.s_carpre[e_prev] - c0 : 0;   // arena distance from site g0 to where the covered ground ends
-  o.rback = e_prev > g0 ? e_prev - g0 : 0;               // the same in rows
+  o.arena_new = c1 - o.pre_ns;
+  o.back = e_prev > g0 ? ce - c0 : 0;        // arena distance from site g0 to where the covered ground ends
+  o.rback = e_prev > g0 ? e_prev - g0 : 0;   // the same in rows
   return o;
 }
 
@@ -163,14 +177,15 @@ struct PlanDev { uint64_t U, n_runs, n_slow; uint32_t refused, pad_; };
 
 // SRC 0: bounds from (x, y); 1: from gathered records (k_bounds_from_records); 2: the per-region arrays are already there
 // (a batch sorted on the device works on permuted copies of them)
-struct RecordBounds { uint32_t g0, nv; uint8_t fl; uint64_t npad; };
+struct RecordBounds { uint32_t g0, nv; uint8_t fl; uint64_t npad, pre0, nkept; };
 __device__ __forceinline__ RecordBounds record_bounds(const DevImage& im, const uint64_t* recs, uint64_t q) {
   const uint64_t w1 = recs[4 * q + 1], w2 = recs[4 * q + 2];
   uint32_t g0 = (uint32_t)w1, nsites = (uint32_t)w2;
   uint8_t fl = (uint8_t)((w1 >> 32) & (kRegionEmpty | kRegionInvalid | kRegionNotFound | kRegionEndless));
   if ((uint64_t)g0 + nsites > im.G) { g0 = 0; nsites = 0; fl = kRegionInvalid; }
   if ((w1 >> 40) & 1) fl |= kRegionSlow;   // the producing rank dropped rows: the literal rule runs again here
-  return RecordBounds{g0, nsites, fl, im.s_carpre[g0 + nsites] - im.s_carpre[g0]};
+  const uint64_t pre0 = im.s_carpre[g0];
+  return RecordBounds{g0, nsites, fl, im.s_carpre[g0 + nsites] - pre0, pre0, im.s_kpre[g0 + nsites] - im.s_kpre[g0]};
 }
 // `recs`: SRC 1 the gathered records; SRC 0 the caller's regions when they are in device memory (NULL: already copied into
 // the result) -- the kernel that reads them anyway keeps the result's copy, and block 0 clears the plan's status word:
@@ -179,11 +194,12 @@ template <int SRC>
 __device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult& r, const uint64_t* recs, uint32_t items, ShareMax* tile_max, uint32_t* status) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
-  ShareMax m{0, 0};
+  ShareMax m{0, 0, 0};
   for (uint32_t i = 0; i < items; ++i) {
     const uint64_t q = base + i;
     if (q >= r.Q) break;
     uint32_t g0, nv;
+    uint64_t c1;
     if (SRC == 0) {
       uint64_t x, y;
       if (recs) {
@@ -192,16 +208,16 @@ __device__ __forceinline__ void plan_bounds(const DevImage& im, const DevResult&
         *reinterpret_cast<ulonglong2*>(const_cast<uint64_t*>(r.regions) + 2 * q) = xy;
       } else { x = r.regions[2 * q]; y = r.regions[2 * q + 1]; }
       const RegionBounds b = region_bounds_of(im, x, y);
-      g0 = b.g0; nv = b.g1 - b.g0;
-      r.q_flags[q] = b.flags; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad;
+      g0 = b.g0; nv = b.g1 - b.g0; c1 = b.pre0 + b.npad;
+      r.q_flags[q] = b.flags; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad; r.car_base[q] = b.pre0; r.q_car_len[q] = b.nkept;
     } else if (SRC == 1) {
       const RecordBounds b = record_bounds(im, recs, q);
-      g0 = b.g0; nv = b.nv;
-      r.q_flags[q] = b.fl; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad;
+      g0 = b.g0; nv = b.nv; c1 = b.pre0 + b.npad;
+      r.q_flags[q] = b.fl; r.q_g0[q] = g0; r.q_nvar[q] = nv; r.q_ncar[q] = b.npad; r.car_base[q] = b.pre0; r.q_car_len[q] = b.nkept;
     } else {
-      g0 = r.q_g0[q]; nv = (uint32_t)r.q_nvar[q];
+      g0 = r.q_g0[q]; nv = (uint32_t)r.q_nvar[q]; c1 = r.car_base[q] + r.q_ncar[q];
     }
-    if (nv) m = smax(m, ShareMax{g0 + nv, g0});
+    if (nv) m = smax(m, ShareMax{g0 + nv, g0, c1});
   }
   ShareMax tot;
   block_exclusive_max(m, &tot);
@@ -212,17 +228,17 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_bounds(DevImage im, DevResult
   plan_bounds<SRC>(im, r, recs, items, tile_max, status);
 }
 // per region: E_prev (kept for the last pass); per tile: the sums
-__device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
-                                         uint32_t* status) {
+__device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, uint64_t* e_prev_c,
+                                         Scan5* tile_sums, uint32_t* status) {
   __shared__ ShareMax red[kPlanBlock / 64];
-  ShareMax pm{0, 0};   // the tiles before this one
+  ShareMax pm{0, 0, 0};   // the tiles before this one
   for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kPlanBlock) pm = smax(pm, tile_max[t]);
-  for (int d = 32; d >= 1; d >>= 1) pm = smax(pm, ShareMax{(uint32_t)__shfl_xor(pm.g1, d, 64), (uint32_t)__shfl_xor(pm.g0, d, 64)});
+  for (int d = 32; d >= 1; d >>= 1) pm = smax(pm, ShareMax{(uint32_t)__shfl_xor(pm.g1, d, 64), (uint32_t)__shfl_xor(pm.g0, d, 64), (uint64_t)__shfl_xor(pm.c1, d, 64)});
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pm;
   __syncthreads();
   pm = smax(smax(red[0], red[1]), smax(red[2], red[3]));
   const uint64_t base = ((uint64_t)blockIdx.x * kPlanBlock + threadIdx.x) * items;
-  ShareMax m{0, 0};
+  ShareMax m{0, 0, 0};
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) m = smax(m, share_elem(r, base + i));
   ShareMax tot;
   ShareMax ex = smax(block_exclusive_max(m, &tot), pm);
@@ -232,8 +248,8 @@ __device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r,
     const ShareMax el = share_elem(r, q);
     const uint32_t nv = el.g1 - el.g0;
     if (nv && el.g0 < ex.g0) *status = 1;          // a region that starts before an earlier one: not sorted
-    e_prev[q] = ex.g1;
-    const ShareNew w = share_new(im, el.g0, nv, ex.g1);
+    e_prev[q] = ex.g1; e_prev_c[q] = ex.c1;
+    const ShareNew w = share_new(el.g0, nv, ex.g1, el.c1 - r.q_ncar[q], r.q_ncar[q], ex.c1);
     s.a += nv; s.u += w.n_new; s.c += w.arena_new;
     if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
     if (nv && ex.g1 <= el.g0) s.r += 1;           // no earlier region reaches its first site: a run of covered sites starts here
@@ -243,9 +259,9 @@ __device__ __forceinline__ void plan_mid(const DevImage& im, const DevResult& r,
   block_exclusive_scan5(s, &t5);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = t5;
 }
-__global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, Scan5* tile_sums,
-                                                       uint32_t* status) {
-  plan_mid(im, r, tile_max, items, e_prev, tile_sums, status);
+__global__ void __launch_bounds__(kPlanBlock) k_t6_mid(DevImage im, DevResult r, const ShareMax* tile_max, uint32_t items, uint32_t* e_prev, uint64_t* e_prev_c,
+                                                       Scan5* tile_sums, uint32_t* status) {
+  plan_mid(im, r, tile_max, items, e_prev, e_prev_c, tile_sums, status);
 }
 // Rows of the shared table are in site order, so inside a RUN -- a maximal stretch of covered sites -- row number and
 // site index differ by a constant, and so do a list's arena offset and the site table's arena prefix: one record per
@@ -276,7 +292,7 @@ __device__ __forceinline__ Scan4 block_exclusive_scan4(Scan4 v) {
 // tile_pre: k_t6_totals' exclusive prefix of the tile sums, the batch's totals at [ntiles] -- a block reads its own entry and the
 // last one (two uniform loads) where round 4's kernel reduced all the tiles by itself in twenty-four registers.
 template <bool RESIDENT>
-__device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const Scan5* tile_pre, uint32_t ntiles, uint32_t items,
+__device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& r, const uint32_t* e_prev, const uint64_t* e_prev_c, const Scan5* tile_pre, uint32_t ntiles, uint32_t items,
                                            RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                            const uint32_t* status, uint64_t resident_entries) {
   const uint64_t U = tile_pre[ntiles].u, all_p = tile_pre[ntiles].p, all_c = tile_pre[ntiles].c;
@@ -286,7 +302,7 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
   for (uint32_t i = 0; i < items && base + i < r.Q; ++i) {
     const uint64_t q = base + i;
     const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q], ep = e_prev[q];
-    const ShareNew w = share_new(im, g0, nv, ep);
+    const ShareNew w = share_new(g0, nv, ep, r.car_base[q], r.q_ncar[q], e_prev_c[q]);
     s.u += w.n_new; s.c += w.arena_new;
     if (r.q_flags[q] & kRegionSlow) { s.p += nv; s.s += 1; }
     if (nv && ep <= g0) s.r += 1;
@@ -301,7 +317,8 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
     const uint64_t q = base + i;
     const uint32_t nv = (uint32_t)r.q_nvar[q], g0 = r.q_g0[q], ep = e_prev[q];
     const bool slow = (r.q_flags[q] & kRegionSlow) != 0;
-    const ShareNew w = share_new(im, g0, nv, ep);   // (worked out again: the site table's prefixes are in cache, registers held across the scan are not free)
+    const uint64_t c0 = r.car_base[q], npad = r.q_ncar[q], nkept = r.q_car_len[q];   // (what the bounds left: overwritten with the final values below)
+    const ShareNew w = share_new(g0, nv, ep, c0, npad, e_prev_c[q]);   // (worked out again: registers held across the scan are not free)
     const bool run_start = nv && ep <= g0;
     if (run_start) runs[ex.r] = RunRec{ex.u, (uint64_t)g0 - ex.u, RESIDENT ? 0 : ex.c - w.pre_ns, 0};   // (a run starts at the region's first site: ns == g0)
     if (many_runs && w.n_new) {   // the region's own run, for every kCoarseRows-th row it is the first to cover
@@ -310,18 +327,17 @@ __device__ __forceinline__ void plan_apply(const DevImage& im, const DevResult& 
     }
     // a region's rows: its range of the shared table -- or, under the duplicate rule (its drops are its own), a private copy behind it
     r.var_begin[q] = slow ? U + ex.p : ex.u - w.rback;
-    if (RESIDENT) {   // the lists ARE the index's arena: a site's list lies at s_carpre[g]
-      const uint64_t pre0 = nv ? im.s_carpre[g0] : im.s_carpre[0];
-      r.car_base[q] = pre0;
-      r.q_car_len[q] = im.s_carpre[(nv ? g0 : 0u) + nv] - pre0;
+    if (RESIDENT) {   // the lists ARE the index's arena: a site's list lies at s_carpre[g] (s_carpre[0] == 0: a region without sites)
+      r.car_base[q] = nv ? c0 : 0;
+      r.q_car_len[q] = nv ? npad : 0;
     } else {
       r.car_base[q] = ex.c - w.back;
-      r.q_car_len[q] = r.q_ncar[q];                  // the region's own padded arena extent
+      r.q_car_len[q] = npad;                         // the region's own padded arena extent
     }
     if (slow) slow_list[ex.s] = (uint32_t)q;
     else {                                           // (dedup_region sets these for the others)
       r.var_count[q] = nv;
-      r.q_ncar[q] = im.s_kpre[g0 + nv] - im.s_kpre[g0];
+      r.q_ncar[q] = nkept;
     }
     ex.u += w.n_new; ex.c += w.arena_new;
     if (slow) { ex.p += nv; ex.s += 1; }
@@ -360,10 +376,10 @@ __global__ void __launch_bounds__(kPlanBlock) k_t6_totals(Scan5* tile_sums, uint
   }
 }
 template <bool RESIDENT>
-__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const Scan5* tile_pre, uint32_t ntiles, uint32_t items,
-                                                         RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
+__global__ void __launch_bounds__(kPlanBlock) k_t6_apply(DevImage im, DevResult r, const uint32_t* e_prev, const uint64_t* e_prev_c, const Scan5* tile_pre, uint32_t ntiles,
+                                                         uint32_t items, RunRec* runs, uint32_t* coarse, uint32_t* slow_list,
                                                          const uint32_t* status, uint64_t resident_entries) {
-  plan_apply<RESIDENT>(im, r, e_prev, tile_pre, ntiles, items, runs, coarse, slow_list, status, resident_entries);
+  plan_apply<RESIDENT>(im, r, e_prev, e_prev_c, tile_pre, ntiles, items, runs, coarse, slow_list, status, resident_entries);
 }
 // (The three steps as ONE launch with hand-made grid barriers between them -- 512 resident blocks, a growing counter,
 //  agent-scope release / acquire around it -- was built and measured in round 4: 0.19 ms against 0.05 ms for the three
@@ -401,6 +417,7 @@ __global__ void __launch_bounds__(256) k_permute_in(DevResult r, DevResult s, co
   const uint32_t q = perm[i];
   s_regions[2 * i] = r.regions[2 * q]; s_regions[2 * i + 1] = r.regions[2 * q + 1];
   s.q_flags[i] = r.q_flags[q]; s.q_g0[i] = r.q_g0[q]; s.q_nvar[i] = r.q_nvar[q]; s.q_ncar[i] = r.q_ncar[q];
+  s.car_base[i] = r.car_base[q]; s.q_car_len[i] = r.q_car_len[q];   // (what the bounds left for the plan: share_elem)
 }
 // r.X[perm[i]] = s.X[i] for what the batch computed per region (s: the sorted working copy, r: the caller's order)
 __global__ void __launch_bounds__(256) k_permute_out(DevResult s, DevResult r, const uint32_t* perm) {
