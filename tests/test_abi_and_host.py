@@ -174,3 +174,18 @@ def test_image_labels_against_brute_force(golden_dir, tmp_path):
         ranks, slots, tested, breaks = (int(x) for x in out.stdout.split()[1:5])
         assert ranks > 100 and slots >= ranks and tested > 200 and breaks >= 1
         assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_rccl_stand_in_exports_what_the_engine_binds():
+    """tests/native/fake_rccl.cpp (two ranks on one GPU: tests/test_gpu_two_ranks.py) compiles without a GPU and exports exactly the six
+    entry points variantstore_amd/csrc/hip/comm.hip.h resolves by dlsym -- a symbol the engine starts to need and the stand-in lacks
+    would otherwise only show on the GPU box."""
+    import re
+    import subprocess
+    from helpers import build_fake_rccl
+    lib = build_fake_rccl()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    have = {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("nccl")}
+    src = open(os.path.join(ROOT, "variantstore_amd", "csrc", "hip", "comm.hip.h")).read()
+    want = set(re.findall(r'dlsym\(api\.lib, "(nccl\w+)"\)', src))
+    assert len(want) == 6 and want <= have, (sorted(want), sorted(have))

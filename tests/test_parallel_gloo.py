@@ -179,3 +179,23 @@ def test_id_file_rendezvous_ignores_a_stale_file(tmp_path):
     assert got.get("uid") == new == b"N" * 128
     with pytest.raises(TimeoutError):
         exchange_id_file(1, 2, path, None, nonce="launch-3", timeout=0.2)
+
+
+def test_id_file_rendezvous_needs_a_launch_nonce(tmp_path, monkeypatch):
+    """outside torchrun and without a nonce nothing tells this launch's id file from one an earlier launch left at the same
+    path -- the rendezvous refuses to guess; and an id of the wrong length (a file somebody else wrote under this launch's tag) is not an id."""
+    import hashlib
+    import threading
+    from variantstore_amd.parallel import COMM_ID_BYTES, exchange_id_file
+    for k in ("VS_COMM_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    path = str(tmp_path / "uid")
+    with pytest.raises(ValueError):
+        exchange_id_file(0, 2, path, lambda: b"I" * COMM_ID_BYTES)
+    monkeypatch.setenv("VS_COMM_NONCE", "launch-env")
+    assert exchange_id_file(0, 2, path, lambda: b"E" * COMM_ID_BYTES) == b"E" * COMM_ID_BYTES
+    assert exchange_id_file(1, 2, path, None, timeout=5) == b"E" * COMM_ID_BYTES
+    with open(path, "wb") as f:   # this launch's tag in front of 100 bytes: not a unique id
+        f.write(hashlib.sha256(b"launch-env").digest()[:16] + b"x" * 100)
+    with pytest.raises(TimeoutError):
+        exchange_id_file(1, 2, path, None, timeout=0.3)
