@@ -16,7 +16,7 @@ from variantstore_amd import VariantStore  # noqa: E402
 
 n_cohorts = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-bad = hang = ub = checked = slow_regions = shared_batches = many_runs = 0
+bad = hang = ub = checked = slow_regions = shared_batches = many_runs = speculated = refused = 0
 VERBOSE = bool(os.environ.get("VS_STRESS_VERBOSE"))
 
 
@@ -51,6 +51,28 @@ for c in range(n_cohorts):
         plain = os.path.join(td, "p.bin")
         vs.export_plain(plain)
         orc = Oracle(plain)
+        # SPECULATIVE type-6 batches first, on the fresh handle (round 6: a sorted batch after a sorted batch of about as many regions is
+        # submitted without waiting for its sizes; one that does not fit what the batch before needed is refused on the device and redone
+        # when it is first read): short regions set the expectation, long ones outgrow it, then both fit
+        stage(f"cohort {seed} {kw} list_max {os.environ['VS_LIST_MAX']}: speculative batches")
+        L0 = vs.info().ref_length
+        short_b = sorted(random_regions(rng, L0, 160, max_len=40)[:160])   # (without the whole-reference shapes: few rows)
+        long_b = sorted(random_regions(rng, L0, 150, max_len=5000))          # (with them: every site)
+        vs.get_var_in_ref(short_b).close()
+        for regs in (short_b, long_b, long_b, short_b):
+            rs = vs.get_var_in_ref(regs)
+            for q, (x, y) in enumerate(regs):
+                n, early, text = orc.get_var_in_ref(x, y)
+                if n < 0:
+                    continue
+                checked += 1
+                if rs.region_text(q) != text:
+                    bad += 1
+                    print(f"MISMATCH t6 speculative batch cohort {seed} region {x}:{y}")
+            rs.close()
+        inf = vs.info()
+        speculated += int(inf.t6_speculated)
+        refused += int(inf.t6_refused)
         regions = random_regions(rng, vs.info().ref_length, 150, max_len=int(rng.choice([5, 60, 600, 5000])))
         stage(f"cohort {seed} {kw} list_max {os.environ['VS_LIST_MAX']}: type 6")
         res = vs.get_var_in_ref(regions)
@@ -284,5 +306,5 @@ for c in range(n_cohorts):
         ub += orc.ub_events()
         res.close(); r4.close(); vs.close()
 print(f"cohorts {n_cohorts} regions checked {checked} mismatches {bad} non-terminating-in-reference {hang} "
-      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions} batches with shared rows/lists {shared_batches} short-region batches with more than 64 table rows {many_runs}")
+      f"oracle ub_events {ub} regions with dropped duplicates {slow_regions} batches with shared rows/lists {shared_batches} short-region batches with more than 64 table rows {many_runs} speculative batches {speculated} of which refused and redone {refused}")
 sys.exit(1 if bad else 0)
