@@ -422,13 +422,13 @@ def spawn_ranks(ngpus):
     print(lines[-1], flush=True)
 
 
-def back_to_back(call, reps, vs=None):
+def back_to_back(call, reps, vs=None, depth=None):
     """Seconds per batch of `call` submitted back to back: a result is closed `depth - 1` steps late (closing waits for its batch; depth =
     VS_BENCH_DEPTH, default 3 as in the headline's loop), the clock stops when the device is idle.  `vs`: the handle -- a type-6 batch
     that the device REFUSED (speculative sizes: vs_index_info.t6_refused) did no work unless its result is read, so a measurement
     during which the counter moved is thrown away and repeated (the handle's expectation has adapted by then)."""
     import torch
-    depth = max(2, int(os.environ.get("VS_BENCH_DEPTH", "3")))
+    depth = depth or max(2, int(os.environ.get("VS_BENCH_DEPTH", "3")))
     for _attempt in range(4):
         refused0 = vs.info().t6_refused if vs is not None else 0
         alive = [call() for _k in range(depth - 1)]      # warm-up (also: the handle's pool holds what `depth` batches alive at a time need)
@@ -1115,7 +1115,9 @@ def main():
         r4.close()
         # (as the headline loop: a batch call returns when the batch is enqueued -- one host wait inside it, for the sizes -- and a
         #  result is closed one step late, so the host is not between the batches)
-        dt4 = back_to_back(lambda: vs.get_sample_var_in_ref(regions4, per_region), 6)
+        # (two results alive, as in rounds 2-5: a walking batch waits for the host once inside the call, a third result alive changes nothing
+        #  -- profiles/r06_exp_depth.txt -- and a sequence result's piece capacity is gigabytes)
+        dt4 = back_to_back(lambda: vs.get_sample_var_in_ref(regions4, per_region), 6, depth=2)
         walk_ms = 0.0
         vs.set_option("phase_events", 1)   # (the timed loop above ran without them: every event is a packet between two kernels)
         for _k in range(3):   # the walk phase by the handle's events (reading them waits for the batch: outside the timed loop)
@@ -1196,7 +1198,7 @@ def main():
             rr = call()
             tot = rr.totals()      # (a reduction kernel over the rows for type 5: outside the timed calls, as in the headline loop)
             rr.close()
-            dt = back_to_back(call, 4)
+            dt = back_to_back(call, 4, depth=2)
             tsc[name + "_queries_per_s"] = nsc / dt
             if name != "type5":
                 tsc[name + "_bases_per_s"] = tot[3] / dt

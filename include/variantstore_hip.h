@@ -101,7 +101,8 @@ typedef struct {
   uint64_t t4_rows_bytes;    /* of device_bytes: the per-sample event and hold rows of query type 4 (O(samples x ref-path slots):
                               * taken when they fit half of the free HBM and 176 GB -- VS_T4_ROWS_MAX_GB in the environment
                               * lowers the cap, option "t4_rows_max_mb" drops / rebuilds them on the open handle; 0: not built, the walks
-                              * then visit every vertex) */
+                              * then visit every vertex).  Explicit-id cohorts keep coarse event rows (a bit per 8 slots) and no hold rows;
+                              * VS_T4_EXACT_ROWS=1 in the environment gives them the exact form when it fits the same budget */
   uint64_t pool_mallocs;     /* hipMalloc / hipFree calls the handle's pool of batch buffers has made since it was opened: a loop */
   uint64_t pool_frees;       /* of like batches makes none once it is warm (hipFree waits for the whole device)                  */
   uint64_t t6_speculated;    /* type-6 batches submitted without waiting for their plan's totals (option "t6_speculate") ...       */

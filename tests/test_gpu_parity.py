@@ -963,14 +963,25 @@ def test_sample_coordinate_queries_need_the_indexes(tmp_path):
         vs.get_sample_var_in_sample([(100, 200)], "S00001")
 
 
-def test_tcga_shaped_cohort_mixed_types(tmp_path):
+@pytest.mark.parametrize("rows", ["exact", "coarse"])
+def test_tcga_shaped_cohort_mixed_types(rows, tmp_path, monkeypatch):
     """BASELINE config #5's shape at reduced scale: 10,000 samples, somatic-like sparse carriers (explicit sample ids,
-    not class bit vectors), 10 % indels; mixed query types 3 / 6 / 7 / 4 / 5 (the code's numbering) against the oracle."""
+    not class bit vectors), 10 % indels; mixed query types 3 / 6 / 7 / 4 / 5 (the code's numbering) against the oracle.
+    Both forms of the per-sample rows of an explicit-id cohort: COARSE (round 4, the default: a bit per eight slots, hold tests from the
+    carrier lists) and EXACT (round 6, VS_T4_EXACT_ROWS: a bit per slot and sample and a hold row from the carrier records, when they fit
+    the HBM budget -- the walks then take the class-row cohort's kernels)."""
+    if rows == "exact":
+        monkeypatch.setenv("VS_T4_EXACT_ROWS", "1")
+    else:
+        monkeypatch.delenv("VS_T4_EXACT_ROWS", raising=False)
     vs = VariantStore.synthetic(device=0, ref_length=3_000_000, num_variants=30_000, num_samples=10_000, seed=55,
                                 first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6,
                                 af_exponent=2.0, max_af=0.0004, sample_coordinates=True)
     info = vs.info()
     assert not info.use_bit_vector and info.num_samples == 10_001
+    # (exact rows: 10,001 samples x (slots + vertices) bits; coarse: an eighth of the slots' part and no hold rows)
+    exact_bytes = 10_001 * ((info.ref_path_nodes + 63) // 64 + 1 + (info.num_vertices + 63) // 64 + 1) * 8
+    assert (info.t4_rows_bytes == exact_bytes) == (rows == "exact"), (info.t4_rows_bytes, exact_bytes)
     plain = os.path.join(tmp_path, "p.bin")
     vs.export_plain(plain)
     orc = Oracle(plain)

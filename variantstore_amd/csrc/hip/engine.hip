@@ -76,6 +76,8 @@ struct EngineOpts {
   // ---- read from the environment when the handle is opened ----
   bool phase_events = false;    // walking batches record all five phase events (vs_index_last_timing's phases); default: first and last only
   bool no_t4_events = false;    // VS_T4_NO_EVENTS: do not build the event bitmaps at all
+  bool t4_exact_rows = false;   // VS_T4_EXACT_ROWS: an explicit-id cohort gets exact per-sample rows (a bit per slot and a hold row) instead of round 4's
+                                // coarse event rows (a bit per 8 slots, hold tests from the carrier lists) when they fit the budget
   // ---- tuning builds only (VS_TUNING: VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) ----
   bool lat_debug = false;       // device-clock stamps of the latency kernels on stderr
   bool fill_fused = true;       // shared batches: the expansion writes the shared rows as well (k_fill_sites2); false: k_share_rows2 + k_fill_sites
@@ -455,12 +457,18 @@ static int build_t4_rows(vs_index* idx, uint64_t cap) {
     // events is exact, a coarse bit costs a few literal steps where the sample does have an event, and those are rare -- and
     // no hold rows at all: "does v hold the sample" is read from v's carrier list (k_walk.hip.h: BitRow).  10,000 samples x
     // 20 M variants: 6.3 GB instead of round 3's 125 GB.
-    const uint32_t shift = d.use_bv ? 0u : 3u;
     const uint64_t istride = (im.P + 63) / 64 + 1;                                   // the global irregular row: a bit per slot
-    const uint64_t stride = d.use_bv ? istride : ((im.P >> shift) + 64) / 64 + 1, hstride = d.use_bv ? (im.V + 63) / 64 + 1 : 0;
-    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    // Round 6, opt-in (VS_T4_EXACT_ROWS=1 when the handle is opened): an explicit-id cohort takes the EXACT rows too when they fit the
+    // budget (10,000 samples x 20 M variants: 48 + 73 GB of the part's 288): hold tests become one bit, the spill-free type-4 walk and the
+    // cooperative kernels of types 2 / 3 / 5 apply.  Measured on that cohort: type 4 160 -> 172 M regions/s, types 2 / 3 / 5 unchanged
+    // (82 / 83 / 101 -> 84 / 84 / 109) for 116 GB more image -- not the default.
+    const uint64_t exact_bytes = (uint64_t)d.num_samples * (istride + (im.V + 63) / 64 + 1) * 8;
+    const bool exact = d.use_bv || (idx->opts.t4_exact_rows && exact_bytes <= cap && exact_bytes <= free_b / 2);
+    const uint32_t shift = exact ? 0u : 3u;
+    const uint64_t stride = exact ? istride : ((im.P >> shift) + 64) / 64 + 1, hstride = exact ? (im.V + 63) / 64 + 1 : 0;
+    const uint64_t bytes = (uint64_t)d.num_samples * stride * 8, hbytes = (uint64_t)d.num_samples * hstride * 8;
     if (bytes + hbytes <= cap && bytes + hbytes <= free_b / 2) {
       const uint64_t bytes_before = idx->device_bytes;
       uint64_t *events = nullptr, *hold = nullptr, *irr = nullptr;
@@ -484,6 +492,7 @@ static int build_t4_rows(vs_index* idx, uint64_t cap) {
         } else {
           hipLaunchKernelGGL(k_events_irregular_rows, dim3((tiles + 3) / 4), dim3(256), 0, idx->stream, dd, irr);
           hipLaunchKernelGGL(k_events_explicit, dim3((unsigned)((im.P + 255) / 256)), dim3(256), 0, idx->stream, dd, events);
+          if (hstride) hipLaunchKernelGGL(k_hold_explicit, dim3((unsigned)((im.V + 255) / 256)), dim3(256), 0, idx->stream, dd, hold);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(idx->stream));
@@ -695,6 +704,7 @@ static void read_env_opts(vs_index* idx) {
   if (getenv("VS_SYNC_SUBMIT")) o.async_submit = false;
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
+  o.t4_exact_rows = getenv("VS_T4_EXACT_ROWS") != nullptr;
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 #ifdef VS_TUNING
   o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;

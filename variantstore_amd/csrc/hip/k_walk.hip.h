@@ -95,6 +95,22 @@ __global__ void __launch_bounds__(256) k_events_explicit(DevImage im, uint64_t* 
   }
 }
 
+// Round 6, opt-in (VS_T4_EXACT_ROWS): an explicit-id cohort whose EXACT rows fit the part's HBM gets them (engine.hip: build_t4_rows) -- a bit
+// per slot and sample and this hold row, a bit per vertex and sample, set from the carrier records (10,000 samples x 20 M variants: 48 + 73 GB
+// of the 288 GB).  The walks then take the class-row cohort's kernels: hold tests are one bit, the cooperative kernels of query types
+// 2 / 3 / 5 and the spill-free form of type 4 apply.  The default stays round 4's coarse rows + list look-ups.
+__global__ void __launch_bounds__(256) k_hold_explicit(DevImage im, uint64_t* hold) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= im.V) return;
+  const uint64_t b = im.v_car_begin[v];
+  const uint32_t n = im.v_ncar[v];
+  const unsigned long long bit = 1ULL << (v & 63);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t sid = im.car_sid[b + i];
+    if (sid >= 1 && sid < im.num_samples) atomicOr((unsigned long long*)&hold[(uint64_t)sid * im.t4_hold_stride + (v >> 6)], bit);
+  }
+}
+
 // Hold rows (DevImage::t4_hold): one wave per tile of 64 consecutive vertex ids, the same transpose as k_build_events.
 __global__ void __launch_bounds__(256) k_build_hold(DevImage im, uint64_t* hold) {
   const uint32_t lane = threadIdx.x & 63;
