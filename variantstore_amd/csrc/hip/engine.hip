@@ -76,6 +76,8 @@ struct EngineOpts {
   // ---- read from the environment when the handle is opened ----
   bool phase_events = false;    // walking batches record all five phase events (vs_index_last_timing's phases); default: first and last only
   bool no_t4_events = false;    // VS_T4_NO_EVENTS: do not build the event bitmaps at all
+  uint32_t plan_items = 1;      // VS_PLAN_ITEMS: regions per thread of the plan's kernels for batches of 64 k regions and more (fewer, longer waves beside
+                                // the previous batch's expansion: what the plan costs the expansion is the wave slots its waves hold)
   bool t4_exact_rows = false;   // VS_T4_EXACT_ROWS: an explicit-id cohort gets exact per-sample rows (a bit per slot and a hold row) instead of round 4's
                                 // coarse event rows (a bit per 8 slots, hold tests from the carrier lists) when they fit the budget
   // ---- tuning builds only (VS_TUNING: VS_BUILD_TUNING=1 python -m variantstore_amd.build --force) ----
@@ -705,6 +707,7 @@ static void read_env_opts(vs_index* idx) {
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   o.t4_exact_rows = getenv("VS_T4_EXACT_ROWS") != nullptr;
+  if (const char* pi = getenv("VS_PLAN_ITEMS")) o.plan_items = (uint32_t)std::max(1, std::min(64, atoi(pi)));
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 #ifdef VS_TUNING
   o.lat_debug = getenv("VS_LAT_DEBUG") != nullptr;
@@ -1157,7 +1160,8 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   ScratchBufs scratch(idx);
   const bool resident = idx->opts.resident_lists && idx->res_arena;
   // ---- plan ----
-  const uint32_t items = (uint32_t)((n + (uint64_t)kPlanBlock * kPlanMaxTiles - 1) / ((uint64_t)kPlanBlock * kPlanMaxTiles));
+  uint32_t items = (uint32_t)((n + (uint64_t)kPlanBlock * kPlanMaxTiles - 1) / ((uint64_t)kPlanBlock * kPlanMaxTiles));
+  if (n >= 65536 && items < idx->opts.plan_items) items = idx->opts.plan_items;   // (regions per thread of the plan's kernels: see EngineOpts::plan_items)
   const uint32_t ntiles = (uint32_t)((n + (uint64_t)kPlanBlock * items - 1) / ((uint64_t)kPlanBlock * items));
   ShareMax* tile_max = nullptr;
   Scan5* tile_sums = nullptr;
