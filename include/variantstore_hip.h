@@ -252,7 +252,7 @@ int vs_result_get_raw(vs_result* r, int with_carriers, vs_result_raw* raw);
 /* Duration of the result's carrier expansion by its OWN pair of HIP events on the stream the kernel ran on (waits for the
  * kernel): every type-6 batch that shares rows and lists carries one, as does every "async_fill" batch; -1 for the other
  * result forms (vs_index_last_timing().ms_fill has it then).
- * "async_submit" (default 1): a type-6 batch of more than 64 regions returns when it is ENQUEUED -- sizes known, buffers
+ * "async_submit" (default 1): a type-6 batch of more than 64 regions returns when it is ENQUEUED -- sizes known (or, option "t6_speculate", taken from the handle's previous batch and settled when the result is first asked for anything), buffers
  * allocated, last kernel launched.  Everything that reads the result is ordered behind the batch on the handle's stream
  * (copies, digests, packs, the collective) or waits for it (this call, vs_index_last_timing); freeing it early is safe.
  * "async_fill" (default 0): the call returns as soon as rows and per-region arrays are in HBM while the expansion runs

@@ -61,7 +61,7 @@ struct EngineOpts {
   bool share_lists = true;      // "share_lists": type-6 batches of more than 64 regions hold one row and one carrier list per covered site, shared
                                 // by the regions that report it; type-4 / 5 batches one list per reported vertex
   bool resident_lists = false;  // "resident_lists": carrier lists expanded once into an arena that stays with the index (build_resident_lists)
-  bool async_submit = true;     // "async_submit": a type-6 batch of more than 64 regions returns once it is ENQUEUED (its sizes are known, its
+  bool async_submit = true;     // "async_submit": a type-6 batch of more than 64 regions returns once it is ENQUEUED (its sizes are known -- or speculated: t6_speculate --, its
                                 // buffers allocated, its last kernel launched); everything that reads the result is ordered behind it on the
                                 // handle's stream, so callers see no difference except that the host is free while the GPU works
   bool async_fill = false;      // "async_fill": the carrier expansion of a type-6 batch runs on a second stream and the call returns while it
@@ -1410,7 +1410,7 @@ static int run_type6_shared(vs_index* idx, const vs_region* regions, uint64_t n,
   }
   idx->timing_pending = true;
   idx->timing_fill_launches = n_fill ? 1 : 0;   // (async_fill: ms_fill is what the first stream saw of it, ~0; vs_result_fill_ms has the kernel's time)
-  // async_submit: the batch is enqueued, its sizes are known (the plan's totals) and its buffers are the result's -- the call
+  // async_submit: the batch is enqueued, its sizes are known (the plan's totals; a speculative batch: result_sizes) and its buffers are the result's -- the call
   // returns here.  Whatever reads the result (copies, digests, packs, the next batch's kernels that reuse the temporaries
   // released below) is ordered behind the batch on the handle's stream; the timing events are read when asked for.
   if (!async_submit) {
