@@ -1376,11 +1376,18 @@ def main():
                          "frac_of_box_mix_ceiling": (achieved / ceil["mix_2to3_GBps"]) if ceil and ceil.get("mix_2to3_GBps") else None,
                          "frac_alone_of_box_mix_ceiling": (achieved * (fill_ms / args.steps) / alone_ms / ceil["mix_2to3_GBps"])
                                                           if ceil and ceil.get("mix_2to3_GBps") and alone_ms > 0 else None,
+                         # ALGORITHMIC bytes of one launch: what the data layout obliges the kernel to move -- the counters' traffic
+                         # above is within a few per cent of it (no wasted re-reads)
+                         "algorithmic_bytes": fill_bytes_layout,
                          "layout": {"bytes_per_launch": fill_bytes_layout, "GBps": layout_gbps, "frac": layout_gbps / HBM_PEAK_GBPS,
-                                    "note": "bytes the data layout obliges the kernel to move (DESIGN.md section 5)"},
-                         "survey_formula": {"bytes_per_launch": fill_bytes_survey, "GBps": survey_gbps,
-                                            "note": "SURVEY 8(d) terms of this kernel; prices 5 B per carrier written where "
-                                                    "the arena holds 2 -- a time-per-algorithmic-unit figure, not pin traffic"},
+                                    "note": "bytes the data layout obliges the kernel to move (DESIGN.md section 6)"},
+                         # SURVEY 8(d)'s per-unit terms priced on this launch: NOT a bandwidth (it exceeds the pins': a sorted batch writes a covered
+                         # site once where the survey's formula prices every region's copy, and a carrier word is 2 bytes, not 5) -- kept as the time
+                         # the kernel takes per survey-formula gigabyte
+                         "survey_8d_terms": {"bytes_per_launch_by_the_surveys_formula": fill_bytes_survey,
+                                             "ns_per_formula_gigabyte": (fill_s / (fill_bytes_survey / 1e9) * 1e9) if fill_bytes_survey else None,
+                                             "ratio_to_algorithmic_bytes": (fill_bytes_survey / fill_bytes_layout) if fill_bytes_layout else None,
+                                             "note": "not pin traffic and not a bandwidth: SURVEY 8(d) prices private rows and 5 B per carrier"},
                          "emit_kernel_ms": emit_ms / args.steps,
                          "pipeline_ms": tot_ms / args.steps,
                          # (the committed counters of the other kernels, abridged: profiles/traffic_<workload>.json has every counter)
