@@ -88,6 +88,38 @@ def _synth_windows_exe(td):
     return exe
 
 
+def plan_baseline_windows(w, regions, vcf_bytes_budget=1.0e9):
+    """Which windows of a full-size cohort the CPU baseline reads (pure host logic, tests/test_abi_and_host.py): K runs of `per` consecutive
+    regions of the sorted timed batch, evenly spaced, each with the window [first start - 20 kb, last end + 20 kb] (clamped to the
+    reference) -- K from the volume of VCF text the windows make (a line is ~4 bytes per sample; ~1 GB in all, 4 <= K <= 40) -- and, for
+    class-row cohorts, four runs of two regions with 150 kb margins for query type 4 (the backward search; dropped where the margin leaves
+    the reference).  Returns (windows [(lo, hi)], type-6 runs [(window, origin shift, [region indices])], type-4 runs [same])."""
+    import numpy as np
+    n = len(regions)
+    ns = w["num_samples"]
+    per, margin = min(25, n), 20_000
+    span = per * (w["ref_length"] / max(n, 1)) + w["region_len"] + 2 * margin
+    bytes_per_window = span * (w["num_variants"] / w["ref_length"]) * (4 * ns + 40)
+    K = int(max(4, min(40, vcf_bytes_budget // max(bytes_per_window, 1))))
+    wins, runs, wins4 = [], [], []
+    for i0 in np.linspace(0, n - per, K).astype(np.int64):
+        idx = list(range(int(i0), int(i0) + per))
+        lo = max(1, int(regions[idx[0], 0]) - margin)
+        hi = min(w["ref_length"], int(regions[idx, 1].max()) + margin)
+        wins.append((lo, hi))
+        runs.append((len(wins) - 1, lo - 1, idx))
+    m4 = 150_000
+    n4 = 4 if ns <= 4032 and n >= 16 else 0   # (explicit-id cohorts: a sample's previous vertex lies megabases back -- type 4 stays with the tests)
+    for i0 in (np.linspace(n // 8, n - n // 8 - 2, n4).astype(np.int64) if n4 else []):
+        idx = [int(i0), int(i0) + 1]
+        lo, hi = int(regions[idx[0], 0]) - m4, int(regions[idx, 1].max()) + m4
+        if lo < 1 or hi > w["ref_length"]:
+            continue
+        wins.append((lo, hi))
+        wins4.append((len(wins) - 1, lo - 1, idx))
+    return wins, runs, wins4
+
+
 def cpu_baseline(w, vs, regions, budget_s=20.0, all_cores=True):
     """The CPU oracle (literal restatement of the reference path, 1 thread) on the bench's OWN index and the bench's OWN timed
     regions ("same index, same region file"; the reference's loop: src/commands.cc:145-180).
@@ -119,31 +151,7 @@ def cpu_baseline(w, vs, regions, budget_s=20.0, all_cores=True):
             runs.append((plain, 0, list(range(take))))
             wins4 = []
         else:
-            # volume of VCF text: a line is ~4 bytes per sample; ~1 GB in all
-            per, margin = 25, 20_000
-            span = per * (w["ref_length"] / max(n, 1)) + w["region_len"] + 2 * margin
-            bytes_per_window = span * (w["num_variants"] / w["ref_length"]) * (4 * ns + 40)
-            K = int(max(4, min(40, 1.0e9 // max(bytes_per_window, 1))))
-            per = min(per, n)
-            first = np.linspace(0, n - per, K).astype(np.int64)
-            wins = []
-            for i0 in first:
-                idx = list(range(int(i0), int(i0) + per))
-                lo = max(1, int(regions[idx[0], 0]) - margin)
-                hi = min(w["ref_length"], int(regions[idx, 1].max()) + margin)
-                wins.append((lo, hi))
-                runs.append((len(wins) - 1, lo - 1, idx))
-            # query type 4: two timed regions each, margins wide enough for the backward search (tests/test_gpu_full_size.py)
-            wins4 = []
-            m4 = 150_000
-            n4 = 4 if ns <= 4032 else 0   # (explicit-id cohorts: a sample's previous vertex lies megabases back -- type 4 stays with the tests)
-            for i0 in np.linspace(n // 8, n - n // 8, n4).astype(np.int64) if n4 else []:
-                idx = [int(i0), int(i0) + 1]
-                lo, hi = int(regions[idx[0], 0]) - m4, int(regions[idx, 1].max()) + m4
-                if lo < 1 or hi > w["ref_length"]:
-                    continue
-                wins.append((lo, hi))
-                wins4.append((len(wins) - 1, lo - 1, idx))
+            wins, runs, wins4 = plan_baseline_windows(w, regions)
             exe = _synth_windows_exe(td)
             kw = synth_kwargs(w)
             args = [str(kw[k]) for k in ("ref_length", "num_variants", "num_samples", "seed", "first_pos", "frac_ins", "frac_del", "frac_multi",

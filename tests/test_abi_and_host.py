@@ -189,3 +189,33 @@ def test_rccl_stand_in_exports_what_the_engine_binds():
     src = open(os.path.join(ROOT, "variantstore_amd", "csrc", "hip", "comm.hip.h")).read()
     want = set(re.findall(r'dlsym\(api\.lib, "(nccl\w+)"\)', src))
     assert len(want) == 6 and want <= have, (sorted(want), sorted(have))
+
+
+def test_bench_baseline_windows_cover_their_timed_regions():
+    """bench.py's CPU baseline reads the full-size cohorts through windows around runs of its own TIMED regions (plan_baseline_windows):
+    every run's regions lie inside their window with the margin the oracle needs (20 kb; 150 kb for the type-4 runs), windows stay inside
+    the reference, the volume of VCF text stays near the budget, and the runs are spread over the whole sorted batch."""
+    import numpy as np
+    import bench
+    for name in ("chr1-2504", "tcga-10k"):
+        w = bench.WORKLOADS[name]
+        regions = bench.make_regions(w, 0, w["regions"])
+        wins, runs, runs4 = bench.plan_baseline_windows(w, regions)
+        assert 4 <= len(runs) <= 40 and len(wins) == len(runs) + len(runs4)
+        assert (len(runs4) > 0) == (w["num_samples"] <= 4032)
+        text = 0.0
+        for (k, shift, idx), margin in [(r, 20_000) for r in runs] + [(r, 150_000) for r in runs4]:
+            lo, hi = wins[k]
+            assert 1 <= lo <= hi <= w["ref_length"] and shift == lo - 1
+            assert idx == list(range(idx[0], idx[0] + len(idx))), "consecutive regions of the sorted batch"
+            x0, y1 = int(regions[idx[0], 0]), int(regions[idx, 1].max())
+            assert lo <= max(1, x0 - margin) and hi >= min(w["ref_length"], y1 + margin)
+            text += (hi - lo) * (w["num_variants"] / w["ref_length"]) * (4 * w["num_samples"] + 40)
+        assert text < 2.5e9, text
+        firsts = [idx[0] for _k, _s, idx in runs]
+        assert firsts[0] == 0 and firsts[-1] == len(regions) - len(runs[-1][2]) and firsts == sorted(firsts)
+    # a batch too small for the type-4 runs, and one smaller than a run
+    w = bench.WORKLOADS["chr1-2504"]
+    few = bench.make_regions(w, 0, 10)
+    wins, runs, runs4 = bench.plan_baseline_windows(w, few)
+    assert all(len(idx) == 10 for _k, _s, idx in runs) and not runs4
