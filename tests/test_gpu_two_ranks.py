@@ -135,3 +135,37 @@ def test_cli_nprocs_2_ends_rank_0_when_rank_1_is_killed(fake_env, golden_dir, tm
     assert out.returncode != 0, out.stdout + out.stderr
     assert "a rank of --nprocs failed; stopping the others" in out.stdout + out.stderr
     assert took < 10.0, f"the parent took {took:.1f} s to end the surviving rank"
+
+
+def test_cli_nprocs_3_on_a_midsize_index_with_thousands_of_regions(fake_env, tmp_path):
+    """THREE ranks (uneven shards: 3001 regions) on a 20,000-variant x 200-sample index saved to disk: `--nprocs 3` against the plain
+    form -- the count line of every region (printed by rank 0 from records that ranks 1 and 2 produced) and the whole --batch-out text
+    (three shards put together by the parent)."""
+    import hashlib
+    import numpy as np
+    from variantstore_amd import VariantStore
+    vs = VariantStore.synthetic(device=0, ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21,
+                                first_pos=500, frac_ins=0.05, frac_del=0.05, frac_multi=0.02, max_indel=6, af_exponent=3.0)
+    d = str(tmp_path / "ser")
+    os.makedirs(d)
+    vs.save(d)
+    vs.close()
+    rng = np.random.default_rng(31)
+    starts = np.sort(rng.integers(1, 1_990_000, size=3001))
+    rfile = str(tmp_path / "regions.txt")
+    with open(rfile, "w") as f:
+        for s in starts:
+            f.write(f"{int(s)}:{int(s) + 4000}\n")
+    got = []
+    for flag in ([], ["--nprocs", "3", "--nprocs-same-device"]):
+        bfile = str(tmp_path / f"b{len(flag)}.txt")
+        out = _cli(["-p", d, "-t", "6", "-r", "@" + rfile, "-m", "1", "--batch-out", bfile] + flag, fake_env, timeout=600)
+        assert out.returncode == 0, (flag, out.stdout[-2000:] + out.stderr[-2000:])
+        if flag:
+            assert out.stderr.count("fake RCCL") == 3
+        counts = [ln for ln in out.stdout.split("\n") if ln.startswith("Number of variants")]
+        assert len(counts) == 3001
+        text = open(bfile, "rb").read()
+        got.append((counts, len(text), hashlib.sha256(text).hexdigest()))
+    assert got[0] == got[1]
+    assert got[0][1] > 1_000_000       # (megabytes of rows: the shards are not trivially small)
