@@ -259,6 +259,44 @@ def test_type6_batches_that_outgrow_the_previous_batch_are_redone(tmp_path):
     vs.close()
 
 
+def test_plan_with_several_regions_per_thread(tmp_path, monkeypatch):
+    """The plan's kernels take `items` regions per thread when a batch has more than 256 x 4096 regions -- a path no other test reaches
+    (the 1 M-region batch of the full-size tests is just below it).  VS_PLAN_ITEMS (read when a handle is opened) asks for it from 64 k
+    regions on: a 70,000-region batch, sorted and shuffled, speculative and not, on a handle opened with 4 regions per thread against a
+    handle opened without -- same totals, digests and layout, and 300 of the regions against the oracle."""
+    kw = dict(ref_length=2_000_000, num_variants=20_000, num_samples=200, seed=21, first_pos=500, frac_ins=0.05, frac_del=0.05,
+              frac_multi=0.02, max_indel=6, af_exponent=3.0)
+    rng = np.random.default_rng(17)
+    starts = np.sort(rng.integers(1, 1_995_000, size=70_000))
+    regions = np.stack([starts, starts + rng.integers(1, 3000, size=70_000)], axis=1).astype(np.uint64)
+    shuffled = regions[rng.permutation(len(regions))]
+    answers = []
+    for items in (None, "4"):
+        if items:
+            monkeypatch.setenv("VS_PLAN_ITEMS", items)
+        else:
+            monkeypatch.delenv("VS_PLAN_ITEMS", raising=False)
+        vs = VariantStore.synthetic(device=0, **kw)
+        got = []
+        for regs in (regions, regions, shuffled):          # (the second one is submitted speculatively)
+            r = vs.get_var_in_ref(regs)
+            got.append((r.totals(), r.digest(), r.layout()))
+            if items and regs is regions:
+                plain = os.path.join(tmp_path, "p.bin")
+                if not os.path.exists(plain):
+                    vs.export_plain(plain)
+                orc = Oracle(plain)
+                for q in range(0, len(regs), 233):
+                    c, _, text = orc.get_var_in_ref(int(regs[q, 0]), int(regs[q, 1]))
+                    if c >= 0:
+                        assert r.region_text(q) == text, q
+            r.close()
+        assert got[0] == got[1]
+        answers.append(got)
+        vs.close()
+    assert answers[0] == answers[1]
+
+
 def test_digest_properties(tmp_path):
     """Size-independent properties used at full scale: the device digest is a function of the result
     only (same batch twice, and any permutation of the batch re-indexed, give the same per-region
