@@ -259,6 +259,38 @@ def test_type6_batches_that_outgrow_the_previous_batch_are_redone(tmp_path):
     vs.close()
 
 
+@pytest.mark.parametrize("shape", ["wide", "explicit"])
+def test_many_short_scattered_regions_wide_and_explicit_cohorts(shape, tmp_path):
+    """The many-runs shape of a shared batch (test_many_short_scattered_regions_many_runs) through the OTHER instantiation of
+    k_fill_sites2 -- 32-bit carrier words: a class-row cohort of 4,100 samples, and an explicit-id cohort of 10,000 (lane per group for
+    every variant) -- 2,500 regions of 25 bases, every region against the oracle, shared against private rows."""
+    kw = dict(ref_length=1_500_000, num_variants=30_000, seed=9, first_pos=2_000, frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6)
+    if shape == "wide":
+        kw.update(num_samples=4_100, af_exponent=3.0)
+    else:
+        kw.update(num_samples=10_000, af_exponent=2.0, max_af=0.0004)
+    vs = VariantStore.synthetic(device=0, **kw)
+    info = vs.info()
+    assert bool(info.use_bit_vector) == (shape == "wide")
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    rng = np.random.default_rng(6)
+    starts = np.sort(rng.integers(3_000, 1_495_000, size=2_500))
+    regions = [(int(x), int(x) + 25) for x in starts]
+    res = vs.get_var_in_ref(regions)
+    assert res.layout()[4] and res.layout()[1] > 200     # (hundreds of table rows: hundreds of runs)
+    for q, (x, y) in enumerate(regions):
+        c, _, text = orc.get_var_in_ref(x, y)
+        if c >= 0:
+            assert res.region_text(q) == text, (q, x, y)
+    vs.set_option("share_lists", 0)
+    private = vs.get_var_in_ref(regions)
+    vs.set_option("share_lists", 1)
+    assert (private.totals(), private.digest()) == (res.totals(), res.digest())
+    private.close(); res.close(); vs.close()
+
+
 def test_plan_with_several_regions_per_thread(tmp_path, monkeypatch):
     """The plan's kernels take `items` regions per thread when a batch has more than 256 x 4096 regions -- a path no other test reaches
     (the 1 M-region batch of the full-size tests is just below it).  VS_PLAN_ITEMS (read when a handle is opened) asks for it from 64 k
