@@ -291,6 +291,35 @@ def test_many_short_scattered_regions_wide_and_explicit_cohorts(shape, tmp_path)
     private.close(); res.close(); vs.close()
 
 
+def test_run_table_sizes_around_the_window_of_64(tmp_path):
+    """A wave task of the shared expansion finds its rows' runs in a window of 64 run records; batches of at most 64 runs load the whole
+    table, larger ones go through the coarse index (shared_row_run).  Batches with EXACTLY 2, 63, 64, 65, 66, 128, 129 and 200 runs --
+    that many far-apart regions with sites, plus a hundred repeats of the first one (more than 64 regions: the throughput path; repeats
+    cover nothing new) -- every region against the oracle, shared against private rows."""
+    vs = VariantStore.synthetic(device=0, ref_length=10_000_000, num_variants=200_000, num_samples=200, seed=3, first_pos=10_000,
+                                frac_ins=0.05, frac_del=0.05, frac_multi=0.01, max_indel=6, af_exponent=3.0)
+    plain = os.path.join(tmp_path, "p.bin")
+    vs.export_plain(plain)
+    orc = Oracle(plain)
+    for runs in (2, 63, 64, 65, 66, 128, 129, 200):
+        spaced = [(20_000 + 40_000 * k, 20_000 + 40_000 * k + 700 + 13 * (k % 7)) for k in range(runs)]   # ~14 sites each, 40 kb apart
+        regions = sorted(spaced + [spaced[0]] * 100)
+        res = vs.get_var_in_ref(regions)
+        assert res.layout()[4]
+        seen = {}
+        for q, (x, y) in enumerate(regions):
+            if (x, y) not in seen:
+                seen[(x, y)] = orc.get_var_in_ref(x, y)
+            c, _, text = seen[(x, y)]
+            assert c > 0 and res.region_text(q) == text, (runs, q, x, y)
+        vs.set_option("share_lists", 0)
+        private = vs.get_var_in_ref(regions)
+        vs.set_option("share_lists", 1)
+        assert (private.totals(), private.digest()) == (res.totals(), res.digest()), runs
+        private.close(); res.close()
+    vs.close()
+
+
 def test_plan_with_several_regions_per_thread(tmp_path, monkeypatch):
     """The plan's kernels take `items` regions per thread when a batch has more than 256 x 4096 regions -- a path no other test reaches
     (the 1 M-region batch of the full-size tests is just below it).  VS_PLAN_ITEMS (read when a handle is opened) asks for it from 64 k
