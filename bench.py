@@ -740,6 +740,10 @@ def main():
     # ("cli" saves and reloads the index through the on-disk format -- minutes for the 5 M-site cohort: only when asked for by name)
     extras = {"t4", "points", "sc", "delivery", "resident"} if args.extras == "all" else set(filter(None, args.extras.split(","))) - {"none"}
 
+    # This process opens up to two index handles (the sample-coordinate legs run on a second one) with seven HIP streams between them; the
+    # runtime maps streams onto FOUR hardware queues by default, and two streams of one handle on one queue no longer run beside each other
+    # (profiles/r06_exp_hw_queues.txt: types 2 / 3 / 5 140 / 153 / 145 against 155 / 167 / 161 M regions/s).  Read when the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
 

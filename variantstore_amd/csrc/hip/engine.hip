@@ -76,6 +76,8 @@ struct EngineOpts {
   // ---- read from the environment when the handle is opened ----
   bool phase_events = false;    // walking batches record all five phase events (vs_index_last_timing's phases); default: first and last only
   bool no_t4_events = false;    // VS_T4_NO_EVENTS: do not build the event bitmaps at all
+  int plan_stream_priority = 0; // VS_PLAN_STREAM_PRIORITY: high (+1) / low (-1): the priority of the stream the plan of a type-6 batch and the part of a walking
+                                // batch in front of its host wait run on (0: default priority)
   uint32_t plan_items = 1;      // VS_PLAN_ITEMS: regions per thread of the plan's kernels for batches of 64 k regions and more (fewer, longer waves beside
                                 // the previous batch's expansion: what the plan costs the expansion is the wave slots its waves hold)
   bool t4_exact_rows = false;   // VS_T4_EXACT_ROWS: an explicit-id cohort gets exact per-sample rows (a bit per slot and a hold row) instead of round 4's
@@ -707,6 +709,7 @@ static void read_env_opts(vs_index* idx) {
   o.resident_lists = getenv("VS_RESIDENT_LISTS") != nullptr;   // (the arena itself is built at the end of finish_open)
   o.no_t4_events = getenv("VS_T4_NO_EVENTS") != nullptr;
   o.t4_exact_rows = getenv("VS_T4_EXACT_ROWS") != nullptr;
+  if (const char* pp = getenv("VS_PLAN_STREAM_PRIORITY")) o.plan_stream_priority = !strcmp(pp, "high") ? 1 : (!strcmp(pp, "low") ? -1 : 0);
   if (const char* pi = getenv("VS_PLAN_ITEMS")) o.plan_items = (uint32_t)std::max(1, std::min(64, atoi(pi)));
   if (const char* lm = getenv("VS_LIST_MAX")) idx->im.list_max = (uint32_t)atoi(lm);   // tuning aid (default: kListMaxDefault)
 #ifdef VS_TUNING
@@ -805,6 +808,12 @@ static int ensure_plan_stream(vs_index* idx) {
   if (idx->plan_stream) return VS_OK;
   // (stream priorities, lowest and highest, were measured: the expansion beside a plan takes 0.031 ms longer than alone
   //  whatever the plan's priority -- the plan's 137 MB of scattered lines are what it shares, not wave slots)
+  if (idx->opts.plan_stream_priority) {   // (tuning aid, VS_PLAN_STREAM_PRIORITY = high | low when the handle is opened)
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
+    HIP_TRY(hipStreamCreateWithPriority(&idx->plan_stream, hipStreamNonBlocking, idx->opts.plan_stream_priority > 0 ? hi : lo));
+    return VS_OK;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&idx->plan_stream, hipStreamNonBlocking));
   return VS_OK;
 }
